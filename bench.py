@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the BCn encode hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one synthetic surface resident in HBM: CompressBlocks<fmt> called through
+the drop-in C ABI with device pointers (kernel only; no PCIe in the timed region), plus -- when world_size > 1 --
+the gather of the per-GPU output bands (the path's only exchange step).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bc7_slow] [--size 4096]
+
+N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+(one process per GPU, RCCL).  Sharding is by block-row bands: rank r owns band r of a (size*N) x size surface, so
+per-GPU work is fixed ("weak").  Rank 0 prints ONE JSON line.
+
+Headline workload (default): BC7 `GetProfile_slow` on synthetic 4096x4096 RGBA8 -- BASELINE.json configs[2], the
+configuration north_star's target is quoted on.  The same line carries `formats`: short measurements of
+BC1 / BC3 / BC6H on the same size (configs[1], [3]) each with its own HBM roofline.
+
+cpu_baseline: the scalar C oracle (oracle/, test infrastructure) timed on this box's host cores on a bounded sample,
+rank 0, N=1 only.  It is a *port* (scalar restatement), not ISPC SIMD code: the reference cannot be built here.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "intel-texture-works-plugin_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, separate mul/add (contract=off => no FMA credit)
+
+# algorithmic bytes per 4x4 block: texels read + block written
+ALG_BYTES = {"bc1": 64 + 8, "bc3": 64 + 16, "bc7": 64 + 16, "bc6h": 128 + 16}
+
+WORKLOADS = {
+    "bc1": ("bc1", None), "bc3": ("bc3", None),
+    "bc7_ultrafast": ("bc7", "ultrafast"), "bc7_veryfast": ("bc7", "veryfast"), "bc7_fast": ("bc7", "fast"),
+    "bc7_basic": ("bc7", "basic"), "bc7_slow": ("bc7", "slow"),
+    "bc7_alpha_basic": ("bc7", "alpha_basic"), "bc7_alpha_slow": ("bc7", "alpha_slow"),
+    "bc6h_fast": ("bc6h", "fast"), "bc6h_basic": ("bc6h", "basic"), "bc6h_slow": ("bc6h", "slow"),
+}
+
+
+def make_surface(fmt, size, rank):
+    from itw_amd import surfaces
+    if fmt == "bc6h":
+        return surfaces.hdr_smooth(size, size, seed=surfaces.SEED + 3 + 100 * rank)
+    return surfaces.ldr_smooth(size, size, seed=surfaces.SEED + 100 * rank)
+
+
+def time_kernel(itw, fmt, prof, d_img, d_out, steps, warmup):
+    """Average launch duration (ms) from HIP events recorded on the stream the kernel runs on."""
+    for _ in range(warmup):
+        itw.compress(fmt, d_img, prof, out=d_out)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a, b in evs:
+        a.record()
+        itw.compress(fmt, d_img, prof, out=d_out)
+        b.record()
+    torch.cuda.synchronize()
+    ts = [a.elapsed_time(b) for a, b in evs]
+    return float(np.mean(ts)), float(np.min(ts))
+
+
+def cpu_baseline(fmt, prof, img, budget_s=15.0):
+    """Oracle on host cores, bounded sample of the same surface: grow the band until ~budget_s of CPU work."""
+    from oracle import pyoracle            # checker / baseline leg only
+    pyoracle.build()
+    cores = os.cpu_count() or 1
+    h, w = img.shape[:2]
+    rows = min(h, max(4 * cores, 16))
+    t0 = time.perf_counter()
+    pyoracle.encode_mt(fmt, img[:rows], prof, threads=cores)
+    dt = time.perf_counter() - t0
+    if dt < budget_s / 4 and rows < h:
+        rows2 = int(min(h, max(rows, rows * (budget_s * 0.8) / max(dt, 1e-3)))) // 4 * 4
+        t0 = time.perf_counter()
+        pyoracle.encode_mt(fmt, img[:rows2], prof, threads=cores)
+        dt = time.perf_counter() - t0
+        rows = rows2
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(rows * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": f"first {rows} of {h} texel rows of the same {w}x{h} surface, {dt:.1f} s, "
+                      f"scalar C oracle (not ISPC SIMD), {cores} threads, reference band rule; cpu: {model}"}
+
+
+def pmc_traffic(workload):
+    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), if present."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="bc7_slow", choices=sorted(WORKLOADS))
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--no-formats", action="store_true", help="skip the side measurements of the other formats")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import itw_amd
+    itw_amd.lib()                                   # fail loudly if the HIP library is missing
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    fmt, prof = WORKLOADS[args.workload]
+    heavy = fmt in ("bc7", "bc6h")
+    steps = args.steps if args.steps is not None else (10 if heavy else 50)
+    warmup = args.warmup if args.warmup is not None else (2 if heavy else 5)
+    size = args.size
+
+    img = make_surface(fmt, size, rank)
+    d_img = torch.from_numpy(img).to(dev)
+    bx = size // 4
+    nblocks = bx * bx
+    band_bytes = nblocks * itw_amd.BYTES_PER_BLOCK[fmt]
+    # whole-image output: rank r's band lives at [r*band_bytes, (r+1)*band_bytes)
+    d_full = torch.empty(world * band_bytes, dtype=torch.uint8, device=dev)
+    d_band = d_full[rank * band_bytes:(rank + 1) * band_bytes]
+
+    def step():
+        itw_amd.compress(fmt, d_img, prof, out=d_band)
+        if dist is not None:
+            dist.all_gather_into_tensor(d_full, d_band)     # gather of output bands over xGMI (RCCL)
+
+    for _ in range(warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel-only duration on the launch stream (HIP events), for the roofline
+    k_avg_ms, k_min_ms = time_kernel(itw_amd, fmt, prof, d_img, d_band, steps=max(3, min(steps, 20)), warmup=1)
+
+    result = None
+    if rank == 0:
+        pixels = size * size * world
+        alg = ALG_BYTES[fmt] * nblocks
+        achieved = alg / (k_avg_ms * 1e-3) / 1e9
+        result = {
+            "metric": "Mpixels/s encode (BC1/BC3/BC7/BC6H) at 4k x 4k; bit-exact vs pinned-arithmetic oracle",
+            "value": round(pixels * steps / elapsed / 1e6, 2), "unit": "Mpixels/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {fmt.upper()}" + (f" GetProfile_{prof}" if prof else "")
+                       + f" on synthetic {size}x{size} " + ("RGBA16F" if fmt == "bc6h" else "RGBA8")
+                       + " per GPU, surfaces resident in HBM, device-pointer C ABI call",
+                       "blocks_per_gpu": nblocks, "sharding": "block-row bands, one per rank; all_gather of output bands"
+                       if world > 1 else "single GPU", "device": itw_amd.device_info(), "lib": itw_amd.version()},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.workload),
+                         "kernel_ms_avg": round(k_avg_ms, 4), "kernel_ms_min": round(k_min_ms, 4),
+                         "algorithmic_bytes_per_launch": alg,
+                         "note": "BC7/BC6H are fp32-VALU bound (no MFMA-shaped work); HBM fraction is reported "
+                                 "because the contract asks for it, see DESIGN.md for the VALU ceiling"},
+        }
+
+    if rank == 0 and world == 1 and not args.no_formats:
+        side = {}
+        for wl in ("bc1", "bc3", "bc7_basic", "bc7_slow", "bc7_alpha_slow", "bc6h_fast", "bc6h_slow"):
+            if wl == args.workload:
+                continue
+            f2, p2 = WORKLOADS[wl]
+            try:
+                im2 = make_surface(f2, size, 0)
+                d2 = torch.from_numpy(im2).to(dev)
+                o2 = torch.empty(nblocks * itw_amd.BYTES_PER_BLOCK[f2], dtype=torch.uint8, device=dev)
+                n = 3 if f2 in ("bc7", "bc6h") else 20
+                avg, mn = time_kernel(itw_amd, f2, p2, d2, o2, steps=n, warmup=1)
+                gbs = ALG_BYTES[f2] * nblocks / (avg * 1e-3) / 1e9
+                side[wl] = {"Mpixels/s": round(size * size / (avg * 1e-3) / 1e6, 1), "kernel_ms_avg": round(avg, 4),
+                            "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5),
+                            "traffic": pmc_traffic(wl)}
+                del d2, o2
+            except Exception as e:  # a format whose kernel is not built yet aborts in C; anything else lands here
+                side[wl] = {"error": repr(e)}
+        result["formats"] = side
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        result["cpu_baseline"] = cpu_baseline(fmt, prof, img)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

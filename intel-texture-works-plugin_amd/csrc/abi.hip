@@ -1,0 +1,290 @@
+// abi.hip -- the extern "C" boundary of libispc_texcomp.so.
+//
+// Exports exactly the BC symbols of the reference's L1 layer
+//   CompressBlocksBC1/BC3/BC6H/BC7   (ispc_texcomp.cpp:417-435)
+//   GetProfile_*                     (ispc_texcomp.cpp:20-410)
+// plus the itw* extensions of include/itw_amd.h.  The reference forwards these
+// calls to ISPC-generated x86 code; here the device boundary (H2D / launch /
+// D2H) sits at the same line.  There is no CPU implementation behind this file:
+// a HIP failure is reported on stderr and the process aborts.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include "../../include/itw_amd.h"
+#include "kernels.hpp"
+#include "x86_math.hpp"
+
+namespace {
+
+[[noreturn]] void die(const char* what, hipError_t e, const char* file, int line)
+{
+    std::fprintf(stderr, "libispc_texcomp (itw-amd): %s failed: %s (%d) at %s:%d -- no CPU fallback, aborting\n",
+                 what, hipGetErrorString(e), (int)e, file, line);
+    std::abort();
+}
+#define ITW_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) die(#expr, e_, __FILE__, __LINE__); } while (0)
+
+// Per host thread: stream for device-resident calls and grow-only staging
+// buffers for host-pointer calls.  The reference is called from up to 64 pool
+// threads at once (win32Threads.cpp:211-249); thread_local state keeps those
+// calls independent without a lock.
+struct ThreadCtx {
+    hipStream_t user_stream = nullptr;     // itwSetStream
+    hipStream_t own_stream  = nullptr;     // staging path
+    void*  d_in = nullptr;  size_t in_cap = 0;
+    void*  d_out = nullptr; size_t out_cap = 0;
+    int    device = -1;
+    char   info[256] = {0};
+    ~ThreadCtx() {
+        // best effort; the runtime may already be gone at process exit
+        if (d_in)  (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+    }
+};
+thread_local ThreadCtx tls;
+
+void ensure_device_ctx()
+{
+    int dev = 0;
+    ITW_CHECK(hipGetDevice(&dev));
+    if (tls.device != dev) {
+        // buffers belong to the device they were allocated on
+        if (tls.d_in)  { (void)hipFree(tls.d_in);  tls.d_in = nullptr;  tls.in_cap = 0; }
+        if (tls.d_out) { (void)hipFree(tls.d_out); tls.d_out = nullptr; tls.out_cap = 0; }
+        if (tls.own_stream) { (void)hipStreamDestroy(tls.own_stream); tls.own_stream = nullptr; }
+        tls.device = dev;
+    }
+    if (!tls.own_stream) ITW_CHECK(hipStreamCreateWithFlags(&tls.own_stream, hipStreamNonBlocking));
+}
+
+void* grow(void*& buf, size_t& cap, size_t need)
+{
+    if (need > cap) {
+        if (buf) ITW_CHECK(hipFree(buf));
+        size_t want = need + need / 4 + 4096;
+        ITW_CHECK(hipMalloc(&buf, want));
+        cap = want;
+    }
+    return buf;
+}
+
+bool is_device_pointer(const void* p)
+{
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof(a));
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc'd memory on older runtimes
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+enum class Fmt { BC1, BC3, BC7, BC6H };
+
+struct Job {
+    Fmt fmt;
+    const bc7_enc_settings*  s7 = nullptr;
+    const bc6h_enc_settings* s6 = nullptr;
+};
+
+void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, uint8_t* d_dst, hipStream_t st)
+{
+    switch (j.fmt) {
+    case Fmt::BC1:  itw::launch_bc1(d_src, stride, w, h, d_dst, st); break;
+    case Fmt::BC3:  itw::launch_bc3(d_src, stride, w, h, d_dst, st); break;
+    case Fmt::BC7:  itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, st); break;
+    case Fmt::BC6H: itw::launch_bc6h(d_src, stride, w, h, d_dst, *j.s6, st); break;
+    }
+    ITW_CHECK(hipGetLastError());
+}
+
+void compress(const Job& j, const rgba_surface* src, uint8_t* dst)
+{
+    if (!src || !src->ptr || !dst) {
+        std::fprintf(stderr, "libispc_texcomp (itw-amd): null surface or destination\n");
+        std::abort();
+    }
+    const int w = src->width, h = src->height;
+    const int bx = w / 4, by = h / 4;                 // partial blocks dropped (kernel.ispc:600-601)
+    if (bx <= 0 || by <= 0) return;
+    const int bpb = (j.fmt == Fmt::BC1) ? 8 : 16;
+    const int texel_bytes = (j.fmt == Fmt::BC6H) ? 8 : 4;
+    const size_t row_bytes = (size_t)bx * 4 * texel_bytes;
+    const size_t out_bytes = (size_t)bx * by * bpb;
+
+    const bool src_dev = is_device_pointer(src->ptr);
+    const bool dst_dev = is_device_pointer(dst);
+
+    if (src_dev && dst_dev) {                         // resident pipeline: asynchronous
+        launch(j, src->ptr, src->stride, w, h, dst, tls.user_stream);
+        return;
+    }
+
+    ensure_device_ctx();
+    hipStream_t st = tls.own_stream;
+    const uint8_t* d_src = src->ptr;
+    int64_t d_stride = src->stride;
+    if (!src_dev) {
+        // tight staging pitch, 16-byte aligned rows so the vector load path applies
+        const size_t pitch = (row_bytes + 15) & ~(size_t)15;
+        uint8_t* in = (uint8_t*)grow(tls.d_in, tls.in_cap, pitch * (size_t)by * 4);
+        ITW_CHECK(hipMemcpy2DAsync(in, pitch, src->ptr, (size_t)src->stride, row_bytes, (size_t)by * 4,
+                                   hipMemcpyHostToDevice, st));
+        d_src = in; d_stride = (int64_t)pitch;
+    } else if (tls.user_stream != st) {
+        // producer of the device surface may still be running on the caller's stream
+        ITW_CHECK(hipStreamSynchronize(tls.user_stream));
+    }
+    uint8_t* d_dst = dst_dev ? dst : (uint8_t*)grow(tls.d_out, tls.out_cap, out_bytes);
+    launch(j, d_src, d_stride, w, h, d_dst, st);
+    if (!dst_dev) ITW_CHECK(hipMemcpyAsync(dst, d_dst, out_bytes, hipMemcpyDeviceToHost, st));
+    ITW_CHECK(hipStreamSynchronize(st));
+}
+
+// ---- quality presets (values: ispc_texcomp.cpp:20-410) ----------------------
+struct Bc7Preset {
+    int channels;
+    bool sel[4];            // modes {0,2} {1,3,7} {4,5} {6}
+    bool skip_mode2;
+    int n1, n3, n7;         // partitions tried after PCA ranking
+    int ch0, refine_channel;
+    int refine[8];          // per mode; [7] < 0 = "left untouched" (the RGB profiles never write it)
+};
+
+constexpr Bc7Preset kUltrafast      {3, {false, false, false, true}, true,  3,  1,  0, 0, 0, {2, 2, 2, 1, 2, 2, 1, -1}};
+constexpr Bc7Preset kVeryfast       {3, {false, true,  false, true}, true,  3,  1,  0, 0, 0, {2, 2, 2, 1, 2, 2, 1, -1}};
+constexpr Bc7Preset kFast           {3, {false, true,  false, true}, true,  12, 4,  0, 0, 0, {2, 2, 2, 1, 2, 2, 2, -1}};
+constexpr Bc7Preset kBasic          {3, {true,  true,  true,  true}, true,  12, 8,  0, 0, 2, {2, 2, 2, 2, 2, 2, 2, -1}};
+constexpr Bc7Preset kSlow           {3, {true,  true,  true,  true}, false, 64, 64, 0, 0, 4, {4, 4, 4, 4, 4, 4, 4, -1}};
+constexpr Bc7Preset kAlphaUltrafast {4, {false, false, true,  true}, true,  0,  0,  4, 3, 1, {2, 1, 2, 1, 1, 1, 2, 2}};
+constexpr Bc7Preset kAlphaVeryfast  {4, {false, true,  true,  true}, true,  0,  0,  4, 3, 2, {2, 1, 2, 1, 2, 2, 2, 2}};
+constexpr Bc7Preset kAlphaFast      {4, {false, true,  true,  true}, true,  4,  4,  8, 3, 2, {2, 1, 2, 1, 2, 2, 2, 2}};
+constexpr Bc7Preset kAlphaBasic     {4, {true,  true,  true,  true}, true,  12, 8,  8, 0, 2, {2, 2, 2, 2, 2, 2, 2, 2}};
+constexpr Bc7Preset kAlphaSlow      {4, {true,  true,  true,  true}, false, 64, 64, 64, 0, 4, {4, 4, 4, 4, 4, 4, 4, 4}};
+
+void apply(const Bc7Preset& p, bc7_enc_settings* s)
+{
+    // field-wise on purpose: padding bytes and (for RGB presets) refineIterations[7]
+    // keep whatever the caller had there, like the reference's assignment lists.
+    s->channels = p.channels;
+    for (int i = 0; i < 4; i++) s->mode_selection[i] = p.sel[i];
+    s->skip_mode2 = p.skip_mode2;
+    s->fastSkipTreshold_mode1 = p.n1;
+    s->fastSkipTreshold_mode3 = p.n3;
+    s->fastSkipTreshold_mode7 = p.n7;
+    s->mode45_channel0 = p.ch0;
+    s->refineIterations_channel = p.refine_channel;
+    for (int i = 0; i < 8; i++) if (p.refine[i] >= 0) s->refineIterations[i] = p.refine[i];
+}
+
+struct Bc6hPreset { bool slow, fast; int n, r1p, r2p; };
+void apply(const Bc6hPreset& p, bc6h_enc_settings* s)
+{
+    s->slow_mode = p.slow; s->fast_mode = p.fast;
+    s->fastSkipTreshold = p.n; s->refineIterations_1p = p.r1p; s->refineIterations_2p = p.r2p;
+}
+
+// ---- device self-test kernels ------------------------------------------------
+__global__ void k_test_rcp(const float* in, float* out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = itw::ispc_rcp(in[i], itw::global_seed_tables());
+}
+__global__ void k_test_rsqrt(const float* in, float* out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = itw::ispc_rsqrt(in[i], itw::global_seed_tables());
+}
+__global__ void k_test_f2i(const float* in, int32_t* out, int64_t n)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = itw::f2i_x86(in[i]);
+}
+
+} // namespace
+
+extern "C" {
+
+void GetProfile_ultrafast(bc7_enc_settings* s) { apply(kUltrafast, s); }
+void GetProfile_veryfast (bc7_enc_settings* s) { apply(kVeryfast, s); }
+void GetProfile_fast     (bc7_enc_settings* s) { apply(kFast, s); }
+void GetProfile_basic    (bc7_enc_settings* s) { apply(kBasic, s); }
+void GetProfile_slow     (bc7_enc_settings* s) { apply(kSlow, s); }
+void GetProfile_alpha_ultrafast(bc7_enc_settings* s) { apply(kAlphaUltrafast, s); }
+void GetProfile_alpha_veryfast (bc7_enc_settings* s) { apply(kAlphaVeryfast, s); }
+void GetProfile_alpha_fast     (bc7_enc_settings* s) { apply(kAlphaFast, s); }
+void GetProfile_alpha_basic    (bc7_enc_settings* s) { apply(kAlphaBasic, s); }
+void GetProfile_alpha_slow     (bc7_enc_settings* s) { apply(kAlphaSlow, s); }
+
+void GetProfile_bc6h_veryfast(bc6h_enc_settings* s) { apply(Bc6hPreset{false, true,  0,  0, 0}, s); }
+void GetProfile_bc6h_fast    (bc6h_enc_settings* s) { apply(Bc6hPreset{false, true,  2,  0, 1}, s); }
+void GetProfile_bc6h_basic   (bc6h_enc_settings* s) { apply(Bc6hPreset{false, false, 4,  2, 2}, s); }
+void GetProfile_bc6h_slow    (bc6h_enc_settings* s) { apply(Bc6hPreset{true,  false, 10, 2, 2}, s); }
+void GetProfile_bc6h_veryslow(bc6h_enc_settings* s) { apply(Bc6hPreset{true,  false, 32, 2, 2}, s); }
+
+void CompressBlocksBC1(const rgba_surface* src, uint8_t* dst)
+{
+    Job j; j.fmt = Fmt::BC1; compress(j, src, dst);
+}
+void CompressBlocksBC3(const rgba_surface* src, uint8_t* dst)
+{
+    Job j; j.fmt = Fmt::BC3; compress(j, src, dst);
+}
+void CompressBlocksBC7(const rgba_surface* src, uint8_t* dst, bc7_enc_settings* settings)
+{
+    if (!settings) { std::fprintf(stderr, "libispc_texcomp (itw-amd): null bc7 settings\n"); std::abort(); }
+    Job j; j.fmt = Fmt::BC7; j.s7 = settings; compress(j, src, dst);
+}
+void CompressBlocksBC6H(const rgba_surface* src, uint8_t* dst, bc6h_enc_settings* settings)
+{
+    if (!settings) { std::fprintf(stderr, "libispc_texcomp (itw-amd): null bc6h settings\n"); std::abort(); }
+    Job j; j.fmt = Fmt::BC6H; j.s6 = settings; compress(j, src, dst);
+}
+
+void  itwSetStream(void* s) { tls.user_stream = (hipStream_t)s; }
+void* itwGetStream(void)    { return (void*)tls.user_stream; }
+
+const char* itwDeviceInfo(void)
+{
+    int dev = 0;
+    ITW_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    ITW_CHECK(hipGetDeviceProperties(&p, dev));
+    std::snprintf(tls.info, sizeof(tls.info), "%s / %s / %d CUs / %.0f MHz", p.gcnArchName, p.name,
+                  p.multiProcessorCount, p.clockRate / 1000.0);
+    return tls.info;
+}
+
+const char* itwVersion(void) { return "itw-amd 0.1 gfx950 arith=x86-lut-nr contract=off"; }
+
+int64_t itwBandForPart(int32_t width, int32_t height, int32_t bytes_per_block,
+                       int32_t part, int32_t parts, int32_t* first_row, int32_t* row_count)
+{
+    const int64_t R = height / 4, bx = width / 4;
+    if (parts <= 0 || part < 0 || part >= parts) { if (first_row) *first_row = 0; if (row_count) *row_count = 0; return -1; }
+    const int64_t r0 = R * part / parts, r1 = R * (part + 1) / parts;
+    if (first_row) *first_row = (int32_t)(r0 * 4);
+    if (row_count) *row_count = (int32_t)((r1 - r0) * 4);
+    return r0 * bx * bytes_per_block;
+}
+
+void itwTestRcp(const float* in, float* out, int64_t n)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_test_rcp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tls.user_stream, in, out, n);
+    ITW_CHECK(hipGetLastError());
+}
+void itwTestRsqrt(const float* in, float* out, int64_t n)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_test_rsqrt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tls.user_stream, in, out, n);
+    ITW_CHECK(hipGetLastError());
+}
+void itwTestF2I(const float* in, int32_t* out, int64_t n)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_test_f2i, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tls.user_stream, in, out, n);
+    ITW_CHECK(hipGetLastError());
+}
+
+} // extern "C"

@@ -1,0 +1,18 @@
+// kernels.hpp -- host-visible launchers of the gfx950 encoder kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ispc_texcomp.h"
+
+namespace itw {
+
+// All launchers: `src`/`dst` are DEVICE pointers, rows `stride` bytes apart,
+// output tightly packed in raster block order; asynchronous on `st`.
+void launch_bc1 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
+void launch_bc3 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
+void launch_bc7 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
+                 const bc7_enc_settings& s, hipStream_t st);
+void launch_bc6h(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
+                 const bc6h_enc_settings& s, hipStream_t st);
+
+} // namespace itw

@@ -1,0 +1,16 @@
+"""itw_amd -- thin host binding of libispc_texcomp.so (the MI355X-native BCn encoder).
+
+The product is the C-ABI shared library built from ../csrc (extern "C"
+CompressBlocksBC1/BC3/BC7/BC6H + GetProfile_*, the reference's own entry points,
+/root/reference/3rdParty/Intel/Source/ispc_texcomp.h:67-107).  This package only
+binds it with ctypes for tests and benchmarks and offers torch-tensor
+conveniences (device memory, streams, torch.distributed are plumbing here).
+
+There is no CPU implementation in this package: if the library is missing or no
+GPU is present, calls raise / the library aborts.  Nothing here imports oracle/.
+"""
+from .abi import (  # noqa: F401
+    lib, lib_path, RgbaSurface, Bc7Settings, Bc6hSettings, BC7_PROFILES, BC6H_PROFILES,
+    bc7_profile, bc6h_profile, compress, compress_numpy, band_for_part, version, device_info,
+    BYTES_PER_BLOCK, EXPORTED_SYMBOLS,
+)

@@ -1,0 +1,161 @@
+"""ctypes binding of the drop-in C ABI (include/ispc_texcomp.h, include/itw_amd.h)."""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.normpath(os.path.join(_PKG, "..", "lib", "libispc_texcomp.so"))
+
+BYTES_PER_BLOCK = {"bc1": 8, "bc3": 16, "bc7": 16, "bc6h": 16}
+BC7_PROFILES = ("ultrafast", "veryfast", "fast", "basic", "slow",
+                "alpha_ultrafast", "alpha_veryfast", "alpha_fast", "alpha_basic", "alpha_slow")
+BC6H_PROFILES = ("veryfast", "fast", "basic", "slow", "veryslow")
+
+# every symbol include/*.h declares
+EXPORTED_SYMBOLS = tuple(
+    ["CompressBlocksBC1", "CompressBlocksBC3", "CompressBlocksBC6H", "CompressBlocksBC7"]
+    + ["GetProfile_" + p for p in BC7_PROFILES] + ["GetProfile_bc6h_" + p for p in BC6H_PROFILES]
+    + ["itwSetStream", "itwGetStream", "itwDeviceInfo", "itwVersion", "itwBandForPart",
+       "itwTestRcp", "itwTestRsqrt", "itwTestF2I"])
+
+
+class RgbaSurface(C.Structure):
+    """struct rgba_surface (ispc_texcomp.h:19-25): 24 bytes."""
+    _fields_ = [("ptr", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32)]
+
+
+class Bc7Settings(C.Structure):
+    """struct bc7_enc_settings (ispc_texcomp.h:27-41): 64 bytes."""
+    _fields_ = [("mode_selection", C.c_bool * 4), ("refineIterations", C.c_int * 8),
+                ("skip_mode2", C.c_bool), ("fastSkipTreshold_mode1", C.c_int),
+                ("fastSkipTreshold_mode3", C.c_int), ("fastSkipTreshold_mode7", C.c_int),
+                ("mode45_channel0", C.c_int), ("refineIterations_channel", C.c_int),
+                ("channels", C.c_int)]
+
+
+class Bc6hSettings(C.Structure):
+    """struct bc6h_enc_settings (ispc_texcomp.h:43-50): 16 bytes."""
+    _fields_ = [("slow_mode", C.c_bool), ("fast_mode", C.c_bool), ("refineIterations_1p", C.c_int),
+                ("refineIterations_2p", C.c_int), ("fastSkipTreshold", C.c_int)]
+
+
+assert C.sizeof(RgbaSurface) == 24 and C.sizeof(Bc7Settings) == 64 and C.sizeof(Bc6hSettings) == 16
+
+_lib = None
+
+
+def lib_path():
+    return _LIB
+
+
+def lib():
+    """Load libispc_texcomp.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise RuntimeError(
+                f"{_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C intel-texture-works-plugin_amd/csrc`.  There is no CPU fallback.")
+        L = C.CDLL(_LIB, mode=C.RTLD_GLOBAL)
+        L.CompressBlocksBC1.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
+        L.CompressBlocksBC3.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
+        L.CompressBlocksBC7.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.POINTER(Bc7Settings)]
+        L.CompressBlocksBC6H.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.POINTER(Bc6hSettings)]
+        for n in ("CompressBlocksBC1", "CompressBlocksBC3", "CompressBlocksBC7", "CompressBlocksBC6H"):
+            getattr(L, n).restype = None
+        L.itwSetStream.argtypes = [C.c_void_p]
+        L.itwSetStream.restype = None
+        L.itwGetStream.restype = C.c_void_p
+        L.itwDeviceInfo.restype = C.c_char_p
+        L.itwVersion.restype = C.c_char_p
+        L.itwBandForPart.argtypes = [C.c_int32] * 5 + [C.POINTER(C.c_int32)] * 2
+        L.itwBandForPart.restype = C.c_int64
+        for n in ("itwTestRcp", "itwTestRsqrt", "itwTestF2I"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+            getattr(L, n).restype = None
+        _lib = L
+    return _lib
+
+
+def version():
+    return lib().itwVersion().decode()
+
+
+def device_info():
+    return lib().itwDeviceInfo().decode()
+
+
+def bc7_profile(name):
+    """GetProfile_<name> (ispc_texcomp.h:67-79) into a zero-initialised struct."""
+    if name not in BC7_PROFILES:
+        raise KeyError(name)
+    s = Bc7Settings()
+    getattr(lib(), "GetProfile_" + name)(C.byref(s))
+    return s
+
+
+def bc6h_profile(name):
+    """GetProfile_bc6h_<name> (ispc_texcomp.h:81-85)."""
+    if name not in BC6H_PROFILES:
+        raise KeyError(name)
+    s = Bc6hSettings()
+    getattr(lib(), "GetProfile_bc6h_" + name)(C.byref(s))
+    return s
+
+
+def band_for_part(width, height, fmt, part, parts):
+    """(first_texel_row, texel_rows, output_byte_offset) of `part` among `parts` (itwBandForPart)."""
+    y0, n = C.c_int32(), C.c_int32()
+    off = lib().itwBandForPart(width, height, BYTES_PER_BLOCK[fmt], part, parts, C.byref(y0), C.byref(n))
+    if off < 0:
+        raise ValueError((part, parts))
+    return y0.value, n.value, off
+
+
+def _call(fmt, surf, dst_ptr, settings):
+    L = lib()
+    if fmt == "bc1":
+        L.CompressBlocksBC1(C.byref(surf), dst_ptr)
+    elif fmt == "bc3":
+        L.CompressBlocksBC3(C.byref(surf), dst_ptr)
+    elif fmt == "bc7":
+        st = settings if isinstance(settings, Bc7Settings) else bc7_profile(settings or "slow")
+        L.CompressBlocksBC7(C.byref(surf), dst_ptr, C.byref(st))
+    elif fmt == "bc6h":
+        st = settings if isinstance(settings, Bc6hSettings) else bc6h_profile(settings or "slow")
+        L.CompressBlocksBC6H(C.byref(surf), dst_ptr, C.byref(st))
+    else:
+        raise ValueError(fmt)
+
+
+def compress_numpy(fmt, img, settings=None):
+    """Host-pointer path (what the Photoshop plugin does): img (H, W, 4) uint8, or uint16 half bits for bc6h.
+    Synchronous; returns a uint8 numpy array of packed blocks."""
+    import numpy as np
+    assert img.ndim == 3 and img.shape[2] == 4 and img.strides[2] == img.itemsize and img.strides[1] == 4 * img.itemsize
+    assert img.dtype == (np.uint16 if fmt == "bc6h" else np.uint8)
+    h, w = img.shape[:2]
+    out = np.empty((h // 4) * (w // 4) * BYTES_PER_BLOCK[fmt], dtype=np.uint8)
+    surf = RgbaSurface(img.ctypes.data, w, h, img.strides[0])
+    _call(fmt, surf, out.ctypes.data, settings)
+    return out
+
+
+def compress(fmt, img, settings=None, out=None):
+    """Device-resident path: img is a CUDA(HIP) torch tensor (H, W, 4) uint8, or int16/uint16/float16 for bc6h;
+    rows may be strided.  Launches asynchronously on torch's current stream and returns a uint8 CUDA tensor."""
+    import torch
+    assert img.is_cuda and img.dim() == 3 and img.shape[2] == 4
+    es = img.element_size()
+    assert es == (2 if fmt == "bc6h" else 1), "texel type does not match the format"
+    assert img.stride(2) == 1 and img.stride(1) == 4
+    h, w = img.shape[:2]
+    nbytes = (h // 4) * (w // 4) * BYTES_PER_BLOCK[fmt]
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+    assert out.is_cuda and out.numel() >= nbytes and out.is_contiguous()
+    L = lib()
+    with torch.cuda.device(img.device):
+        L.itwSetStream(torch.cuda.current_stream(img.device).cuda_stream)
+        surf = RgbaSurface(img.data_ptr(), w, h, img.stride(0) * es)
+        _call(fmt, surf, out.data_ptr(), settings)
+    return out

@@ -1,0 +1,78 @@
+/*
+ * oracle/oracle.h -- TEST INFRASTRUCTURE: public face of the CPU parity oracle.
+ *
+ * A scalar, one-lane-at-a-time C restatement of the reference's SPMD encoders
+ * (/root/reference/IntelCompressionPlugin/kernel.ispc:17-3139) under the pinned
+ * arithmetic of x86_math.h.  ISPC lanes never communicate in these kernels
+ * (kernel.ispc:598-614, 2030-2037, 3132-3139: one 4x4 block per program
+ * instance), so a scalar loop over blocks is an exact model of the gang.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
+ * this library.  The product (libispc_texcomp.so) never links or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no golden outputs and cannot be built
+ * here (needs the ispc compiler).  See x86_math.h / DESIGN.md.
+ *
+ * Symbols carry an oracle_ prefix so both libraries can live in one process.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* layout twins of ispc_texcomp.h:19-50 (kept separate on purpose: the oracle
+ * does not include product headers) */
+typedef struct { uint8_t* ptr; int32_t width, height, stride; } oracle_surface;
+
+typedef struct {
+    uint8_t mode_selection[4];
+    int32_t refineIterations[8];
+    uint8_t skip_mode2;
+    int32_t fastSkipTreshold_mode1, fastSkipTreshold_mode3, fastSkipTreshold_mode7;
+    int32_t mode45_channel0;
+    int32_t refineIterations_channel;
+    int32_t channels;
+} oracle_bc7_settings;
+
+typedef struct {
+    uint8_t slow_mode, fast_mode;
+    int32_t refineIterations_1p, refineIterations_2p, fastSkipTreshold;
+} oracle_bc6h_settings;
+
+void oracle_CompressBlocksBC1 (const oracle_surface* src, uint8_t* dst);
+void oracle_CompressBlocksBC3 (const oracle_surface* src, uint8_t* dst);
+void oracle_CompressBlocksBC7 (const oracle_surface* src, uint8_t* dst, const oracle_bc7_settings* s);
+void oracle_CompressBlocksBC6H(const oracle_surface* src, uint8_t* dst, const oracle_bc6h_settings* s);
+
+/* name = "ultrafast" | "veryfast" | "fast" | "basic" | "slow" | "alpha_*";
+ * returns 0 on success.  Fields a reference profile leaves unwritten stay as
+ * they were in *s (ispc_texcomp.cpp:20-189 never writes refineIterations[7]). */
+int oracle_GetProfile_bc7 (const char* name, oracle_bc7_settings* s);
+int oracle_GetProfile_bc6h(const char* name, oracle_bc6h_settings* s);
+
+/* single-block entry points for unit tests: block = planar floats as built by
+ * load_block_interleaved* (kernel.ispc:105-151) */
+void oracle_bc1_block(const float block[48], uint32_t data[2]);
+void oracle_bc3_alpha_block(const float alpha[16], uint32_t data[2]);
+
+/* arithmetic primitives, exported for the LUT / NR self tests */
+float   oracle_rcp(float v);
+float   oracle_rsqrt(float v);
+float   oracle_rcpps(float v);
+float   oracle_rsqrtps(float v);
+int32_t oracle_f2i(float v);
+
+/* from-spec decoders (independent check that emitted blocks are valid):
+ * out = 16 texels, RGBA8 for BC1/BC3/BC7, 3 x uint16 half bit patterns for BC6H */
+void oracle_decode_bc1 (const uint8_t blk[8],  uint8_t out_rgba[64]);
+void oracle_decode_bc3 (const uint8_t blk[16], uint8_t out_rgba[64]);
+int  oracle_decode_bc7 (const uint8_t blk[16], uint8_t out_rgba[64]);   /* returns mode, -1 if reserved */
+int  oracle_decode_bc6h(const uint8_t blk[16], uint16_t out_rgb[48]);  /* unsigned; returns mode 0..13 (kernel.ispc numbering), -1 if reserved */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,183 @@
+"""TEST INFRASTRUCTURE -- ctypes face of oracle/liboracle_bcn.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
+module.  It is the checker, never the product: the product library
+(libispc_texcomp.so) has no dependency on anything in oracle/.
+
+PARITY UNPINNED by the reference (no golden outputs exist upstream, ispc is not
+installable here); see oracle/x86_math.h and DESIGN.md.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle_bcn.so")
+
+
+class Surface(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32)]
+
+
+class Bc7Settings(C.Structure):
+    _fields_ = [("mode_selection", C.c_uint8 * 4), ("refineIterations", C.c_int32 * 8),
+                ("skip_mode2", C.c_uint8), ("fastSkipTreshold_mode1", C.c_int32),
+                ("fastSkipTreshold_mode3", C.c_int32), ("fastSkipTreshold_mode7", C.c_int32),
+                ("mode45_channel0", C.c_int32), ("refineIterations_channel", C.c_int32),
+                ("channels", C.c_int32)]
+
+
+class Bc6hSettings(C.Structure):
+    _fields_ = [("slow_mode", C.c_uint8), ("fast_mode", C.c_uint8), ("refineIterations_1p", C.c_int32),
+                ("refineIterations_2p", C.c_int32), ("fastSkipTreshold", C.c_int32)]
+
+
+def build(force=False):
+    """Compile the C restatement (gcc).  Building the checker is not using it."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if (not force and os.path.exists(_LIB_PATH)
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(s) for s in srcs)):
+        return _LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                   stdout=subprocess.DEVNULL if not force else None)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        for n in ("oracle_rcp", "oracle_rsqrt", "oracle_rcpps", "oracle_rsqrtps"):
+            getattr(L, n).restype = C.c_float
+            getattr(L, n).argtypes = [C.c_float]
+        L.oracle_f2i.restype = C.c_int32
+        L.oracle_f2i.argtypes = [C.c_float]
+        for n in ("oracle_CompressBlocksBC1", "oracle_CompressBlocksBC3"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
+            getattr(L, n).restype = None
+        for n in ("oracle_CompressBlocksBC7", "oracle_CompressBlocksBC6H"):
+            if hasattr(L, n):
+                getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+                getattr(L, n).restype = None
+        for n in ("oracle_GetProfile_bc7", "oracle_GetProfile_bc6h"):
+            if hasattr(L, n):
+                getattr(L, n).argtypes = [C.c_char_p, C.c_void_p]
+                getattr(L, n).restype = C.c_int
+        for n in ("oracle_decode_bc1", "oracle_decode_bc3", "oracle_decode_bc7", "oracle_decode_bc6h"):
+            if hasattr(L, n):
+                getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
+                getattr(L, n).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def has(symbol):
+    return hasattr(lib(), symbol)
+
+
+def _surface(arr):
+    assert arr.flags["C_CONTIGUOUS"] and arr.ndim == 3
+    h, w = arr.shape[:2]
+    return Surface(arr.ctypes.data, w, h, arr.strides[0])
+
+
+def bc7_profile(name):
+    s = Bc7Settings()
+    rc = lib().oracle_GetProfile_bc7(name.encode(), C.byref(s))
+    if rc != 0:
+        raise KeyError(name)
+    return s
+
+
+def bc6h_profile(name):
+    s = Bc6hSettings()
+    rc = lib().oracle_GetProfile_bc6h(name.encode(), C.byref(s))
+    if rc != 0:
+        raise KeyError(name)
+    return s
+
+
+def encode(fmt, img, profile=None, rows=None):
+    """img: (H, W, 4) uint8 (bc1/bc3/bc7) or uint16 half bits (bc6h).  Returns bytes as a uint8 array.
+    rows=(y0, y1) restricts to a texel-row band (multiples of 4)."""
+    img = np.ascontiguousarray(img)
+    if rows is not None:
+        img = img[rows[0]:rows[1]]
+    h, w = img.shape[:2]
+    bpb = 8 if fmt == "bc1" else 16
+    out = np.zeros((h // 4) * (w // 4) * bpb, dtype=np.uint8)
+    s = _surface(img)
+    L = lib()
+    dst = out.ctypes.data_as(C.c_void_p)
+    if fmt == "bc1":
+        assert img.dtype == np.uint8
+        L.oracle_CompressBlocksBC1(C.byref(s), dst)
+    elif fmt == "bc3":
+        assert img.dtype == np.uint8
+        L.oracle_CompressBlocksBC3(C.byref(s), dst)
+    elif fmt == "bc7":
+        assert img.dtype == np.uint8
+        st = profile if isinstance(profile, Bc7Settings) else bc7_profile(profile or "slow")
+        L.oracle_CompressBlocksBC7(C.byref(s), dst, C.byref(st))
+    elif fmt == "bc6h":
+        assert img.dtype == np.uint16
+        st = profile if isinstance(profile, Bc6hSettings) else bc6h_profile(profile or "slow")
+        L.oracle_CompressBlocksBC6H(C.byref(s), dst, C.byref(st))
+    else:
+        raise ValueError(fmt)
+    return out
+
+
+def encode_mt(fmt, img, profile=None, threads=None):
+    """Row-band threaded encode with the reference's band rule (win32Threads.cpp:217-231):
+    linesPerThread = ceil(h/n), y_start = lines*i/4*4.  ctypes releases the GIL."""
+    from concurrent.futures import ThreadPoolExecutor
+    h, w = img.shape[:2]
+    n = threads or os.cpu_count() or 1
+    lines = (h + n - 1) // n
+    bands = []
+    for i in range(n):
+        y0 = (lines * i) // 4 * 4
+        y1 = h if i == n - 1 else (lines * (i + 1)) // 4 * 4
+        y1 = min(y1, h)
+        if y1 > y0:
+            bands.append((y0, y1))
+    with ThreadPoolExecutor(max_workers=len(bands)) as ex:
+        parts = list(ex.map(lambda b: encode(fmt, img, profile, rows=b), bands))
+    return np.concatenate(parts)
+
+
+def decode(fmt, blocks, width, height):
+    """From-spec decode of a tightly packed block stream -> (H, W, 4) uint8, or (H, W, 3) uint16 for bc6h."""
+    L = lib()
+    bpb = 8 if fmt == "bc1" else 16
+    bx, by = width // 4, height // 4
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(by * bx, bpb)
+    if fmt == "bc6h":
+        out = np.zeros((by * 4, bx * 4, 3), dtype=np.uint16)
+        tmp = (C.c_uint16 * 48)()
+        modes = np.zeros(by * bx, dtype=np.int32)
+        for i in range(by * bx):
+            modes[i] = L.oracle_decode_bc6h(blocks[i].ctypes.data_as(C.c_void_p), tmp)
+            t = np.frombuffer(tmp, dtype=np.uint16).reshape(3, 4, 4)   # planar [ch][y][x]
+            y, x = divmod(i, bx)
+            out[y * 4:y * 4 + 4, x * 4:x * 4 + 4, :] = np.transpose(t, (1, 2, 0))
+        return out, modes
+    out = np.zeros((by * 4, bx * 4, 4), dtype=np.uint8)
+    tmp = (C.c_uint8 * 64)()
+    modes = np.zeros(by * bx, dtype=np.int32)
+    fn = {"bc1": L.oracle_decode_bc1, "bc3": L.oracle_decode_bc3, "bc7": L.oracle_decode_bc7}[fmt]
+    fn.restype = C.c_int
+    for i in range(by * bx):
+        r = fn(blocks[i].ctypes.data_as(C.c_void_p), tmp)
+        modes[i] = r if fmt == "bc7" else 0
+        t = np.frombuffer(tmp, dtype=np.uint8).reshape(4, 4, 4)        # [y][x][rgba]
+        y, x = divmod(i, bx)
+        out[y * 4:y * 4 + 4, x * 4:x * 4 + 4, :] = t
+    return out, modes

@@ -1,0 +1,116 @@
+"""The drop-in boundary: libispc_texcomp.so loads on a CPU-only box, exports every symbol that
+include/ispc_texcomp.h and include/itw_amd.h declare, keeps the reference's struct layouts
+(ispc_texcomp.h:19-50) and fills the quality presets with the reference's values
+(ispc_texcomp.cpp:20-410).  No compute call is made here (no GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol(itw):
+    L = itw.lib()
+    for name in itw.EXPORTED_SYMBOLS:
+        assert hasattr(L, name), f"missing export {name}"
+
+
+def test_headers_and_binding_agree_on_the_symbol_list(itw):
+    """Every function declared in include/*.h is in EXPORTED_SYMBOLS and vice versa."""
+    declared = set()
+    for h in ("ispc_texcomp.h", "itw_amd.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        declared |= set(re.findall(r"\b((?:CompressBlocks|GetProfile_|itw)\w+)\s*\(", src))
+    assert declared == set(itw.EXPORTED_SYMBOLS)
+
+
+def test_no_etc_or_astc_exports(itw):
+    L = itw.lib()
+    for name in ("CompressBlocksETC1", "CompressBlocksASTC", "GetProfile_etc_slow", "GetProfile_astc_fast"):
+        assert not hasattr(L, name)
+
+
+def test_struct_layouts_match_reference(itw):
+    assert C.sizeof(itw.RgbaSurface) == 24
+    assert C.sizeof(itw.Bc7Settings) == 64
+    assert C.sizeof(itw.Bc6hSettings) == 16
+    off = {f[0]: getattr(itw.Bc7Settings, f[0]).offset for f in itw.Bc7Settings._fields_}
+    assert off == {"mode_selection": 0, "refineIterations": 4, "skip_mode2": 36,
+                   "fastSkipTreshold_mode1": 40, "fastSkipTreshold_mode3": 44, "fastSkipTreshold_mode7": 48,
+                   "mode45_channel0": 52, "refineIterations_channel": 56, "channels": 60}
+    off6 = {f[0]: getattr(itw.Bc6hSettings, f[0]).offset for f in itw.Bc6hSettings._fields_}
+    assert off6 == {"slow_mode": 0, "fast_mode": 1, "refineIterations_1p": 4, "refineIterations_2p": 8,
+                    "fastSkipTreshold": 12}
+    # the C++ side asserts the same numbers at compile time (include/ispc_texcomp.h static_asserts)
+
+
+# (channels, mode_selection, skip_mode2, n1, n3, n7, channel0, refine_channel, refineIterations[0..7])
+# restated from ispc_texcomp.cpp:20-365; None = field the reference leaves unwritten
+BC7_EXPECT = {
+    "ultrafast":       (3, (0, 0, 0, 1), 1, 3, 1, 0, 0, 0, (2, 2, 2, 1, 2, 2, 1, None)),
+    "veryfast":        (3, (0, 1, 0, 1), 1, 3, 1, 0, 0, 0, (2, 2, 2, 1, 2, 2, 1, None)),
+    "fast":            (3, (0, 1, 0, 1), 1, 12, 4, 0, 0, 0, (2, 2, 2, 1, 2, 2, 2, None)),
+    "basic":           (3, (1, 1, 1, 1), 1, 12, 8, 0, 0, 2, (2, 2, 2, 2, 2, 2, 2, None)),
+    "slow":            (3, (1, 1, 1, 1), 0, 64, 64, 0, 0, 4, (4, 4, 4, 4, 4, 4, 4, None)),
+    "alpha_ultrafast": (4, (0, 0, 1, 1), 1, 0, 0, 4, 3, 1, (2, 1, 2, 1, 1, 1, 2, 2)),
+    "alpha_veryfast":  (4, (0, 1, 1, 1), 1, 0, 0, 4, 3, 2, (2, 1, 2, 1, 2, 2, 2, 2)),
+    "alpha_fast":      (4, (0, 1, 1, 1), 1, 4, 4, 8, 3, 2, (2, 1, 2, 1, 2, 2, 2, 2)),
+    "alpha_basic":     (4, (1, 1, 1, 1), 1, 12, 8, 8, 0, 2, (2, 2, 2, 2, 2, 2, 2, 2)),
+    "alpha_slow":      (4, (1, 1, 1, 1), 0, 64, 64, 64, 0, 4, (4, 4, 4, 4, 4, 4, 4, 4)),
+}
+BC6H_EXPECT = {  # slow_mode, fast_mode, fastSkipTreshold, refine_1p, refine_2p   (ispc_texcomp.cpp:367-410)
+    "veryfast": (0, 1, 0, 0, 0), "fast": (0, 1, 2, 0, 1), "basic": (0, 0, 4, 2, 2),
+    "slow": (1, 0, 10, 2, 2), "veryslow": (1, 0, 32, 2, 2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(BC7_EXPECT))
+def test_bc7_profiles(itw, name):
+    ch, sel, skip2, n1, n3, n7, ch0, rch, ref = BC7_EXPECT[name]
+    s = itw.Bc7Settings()
+    s.refineIterations[7] = 77              # sentinel: RGB profiles must not touch it
+    getattr(itw.lib(), "GetProfile_" + name)(C.byref(s))
+    assert s.channels == ch
+    assert tuple(int(b) for b in s.mode_selection) == sel
+    assert int(s.skip_mode2) == skip2
+    assert (s.fastSkipTreshold_mode1, s.fastSkipTreshold_mode3, s.fastSkipTreshold_mode7) == (n1, n3, n7)
+    assert (s.mode45_channel0, s.refineIterations_channel) == (ch0, rch)
+    for i, r in enumerate(ref):
+        assert s.refineIterations[i] == (77 if r is None else r)
+
+
+@pytest.mark.parametrize("name", sorted(BC6H_EXPECT))
+def test_bc6h_profiles(itw, name):
+    s = itw.bc6h_profile(name)
+    assert (int(s.slow_mode), int(s.fast_mode), s.fastSkipTreshold, s.refineIterations_1p,
+            s.refineIterations_2p) == BC6H_EXPECT[name]
+
+
+def test_oracle_profiles_agree_with_product_profiles(itw, oracle):
+    """Two independent restatements of ispc_texcomp.cpp:20-410 must give the same bytes."""
+    if not oracle.has("oracle_GetProfile_bc7"):
+        pytest.skip("BC7 oracle not built yet")
+    for name in itw.BC7_PROFILES:
+        a, b = itw.bc7_profile(name), oracle.bc7_profile(name)
+        assert bytes(a) == bytes(b), name
+    for name in itw.BC6H_PROFILES:
+        a, b = itw.bc6h_profile(name), oracle.bc6h_profile(name)
+        assert bytes(a) == bytes(b), name
+
+
+@pytest.mark.parametrize("h,parts", [(4096, 8), (16384, 8), (220, 3), (4, 8), (36, 5)])
+def test_band_rule_partitions_block_rows(itw, h, parts):
+    """Bands tile [0, h/4*4) exactly, are 4-row aligned, and their output offsets are contiguous."""
+    w = 64
+    y = 0
+    off_expect = 0
+    for p in range(parts):
+        y0, n, off = itw.band_for_part(w, h, "bc7", p, parts)
+        assert y0 == y and y0 % 4 == 0 and n % 4 == 0
+        assert off == off_expect
+        y += n
+        off_expect += (n // 4) * (w // 4) * 16
+    assert y == h // 4 * 4
