@@ -57,6 +57,8 @@ int oracle_GetProfile_bc6h(const char* name, oracle_bc6h_settings* s);
  * load_block_interleaved* (kernel.ispc:105-151) */
 void oracle_bc1_block(const float block[48], uint32_t data[2]);
 void oracle_bc3_alpha_block(const float alpha[16], uint32_t data[2]);
+void oracle_bc7_block(const float block[64], const oracle_bc7_settings* s, uint32_t data[4], float* best_err);
+void oracle_bc6h_block(const float block[64], const oracle_bc6h_settings* s, uint32_t data[4], float* best_err);
 
 /* arithmetic primitives, exported for the LUT / NR self tests */
 float   oracle_rcp(float v);

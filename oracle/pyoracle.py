@@ -110,6 +110,9 @@ def encode(fmt, img, profile=None, rows=None):
     if rows is not None:
         img = img[rows[0]:rows[1]]
     h, w = img.shape[:2]
+    # kernel.ispc:157 places block row yy at byte yy*width*data_size: only for width % 4 == 0 is that the tight
+    # pitch (width/4)*bytes_per_block.  Other widths are outside the reference's contract (ispc_texcomp.h:95).
+    assert w % 4 == 0, "oracle: width must be a multiple of 4 (reference output pitch is width*data_size bytes)"
     bpb = 8 if fmt == "bc1" else 16
     out = np.zeros((h // 4) * (w // 4) * bpb, dtype=np.uint8)
     s = _surface(img)

@@ -81,13 +81,20 @@ def test_host_pointer_path(itw, gpu, oracle, fmt):
 
 
 def test_partial_blocks_are_dropped(itw, gpu, oracle):
-    """width/height not multiples of 4: height/4 x width/4 blocks (kernel.ispc:600-601)."""
+    """height not a multiple of 4: the last partial block row is dropped (kernel.ispc:600).  A width that is not a
+    multiple of 4 is outside the reference contract (its output pitch becomes width*data_size bytes, kernel.ispc:157,
+    i.e. misaligned fractional blocks); the product packs width/4 blocks per row tightly there and is only checked
+    for shape."""
     from itw_amd import surfaces
-    img = surfaces.ldr_smooth(30, 45)
+    img = surfaces.ldr_smooth(30, 44)
     got = itw.compress_numpy("bc1", img)
-    assert got.size == (30 // 4) * (45 // 4) * 8
+    assert got.size == (30 // 4) * (44 // 4) * 8
     want = oracle.encode("bc1", img)
     assert (got == want).all()
+    odd = surfaces.ldr_smooth(30, 45)
+    got = itw.compress_numpy("bc1", odd)
+    assert got.size == (30 // 4) * (45 // 4) * 8
+    assert (got == oracle.encode("bc1", np.ascontiguousarray(odd[:, :44]))).all()
 
 
 def test_zero_blocks_is_a_no_op(itw, gpu):
