@@ -1,0 +1,333 @@
+// bcn_core.hpp -- device building blocks shared by the BC7 and BC6H kernels (gfx950).
+//
+// What the reference calls block_segment / block_pca_bound_split / block_quant /
+// opt_endpoints (kernel.ispc:763-971, 1133-1262) lives here, re-expressed for a
+// SIMT lane:
+//   * texels of the lane's block sit in registers as px[channel][texel];
+//   * a subset is a 16-bit texel mask; loops are written `if (mask bit k) {...}`.
+//     When the mask is wave-uniform (partition chosen by a loop counter) hipcc
+//     turns that into scalar branches and the masked-out texels cost nothing;
+//     when it differs per lane (ranked partition lists, refinement of the lane's
+//     own winner) it becomes exec masking.  Skipping a texel is bit-identical to
+//     the reference's multiply-by-0/1-flag formulation: all texel values are
+//     non-negative finite, every accumulator starts at +0 and x + (+0) == x.
+//   * every float sum runs in texel order inside the lane (no cross-lane float
+//     reduction anywhere), every divide is lowered as catalogued in SURVEY 8c.
+#pragma once
+#include "x86_math.hpp"
+
+namespace itw {
+
+#define BCN_TABLE_QUAL __device__ const
+#include "bc7_tables.h"
+#undef BCN_TABLE_QUAL
+
+// ---- partition table access (kernel.ispc:688-758) --------------------------
+struct Shape {
+    uint32_t pattern;   // 2 bits / texel
+    uint32_t masks;     // subset0 | subset1 << 16
+    uint32_t anchors;   // anchor(subset1) << 4 | anchor(subset2)
+};
+
+__device__ __forceinline__ Shape load_shape(int table_index)
+{
+    return Shape{BCN_PATTERN[table_index], BCN_SUBSET_MASKS[table_index], (uint32_t)BCN_ANCHORS[table_index]};
+}
+
+__device__ __forceinline__ uint32_t subset_mask(const Shape& s, int j)
+{
+    const uint32_t m0 = s.masks & 0xffffu, m1 = s.masks >> 16;
+    return (j == 0) ? m0 : ((j == 1) ? m1 : (~m0 & ~m1 & 0xffffu));
+}
+
+// ---- second-moment statistics of a subset (kernel.ispc:763-803) -------------
+template <int CH>
+struct Stats {
+    float m[10];   // packed upper triangle of the 4x4 moment matrix: 00 01 02 03 11 12 13 22 23 33
+    float s[4];    // channel sums
+    float n;       // texel count
+};
+
+template <int CH>
+__device__ __forceinline__ void stats_of(Stats<CH>& st, const float (&px)[4][16], uint32_t mask)
+{
+    for (int i = 0; i < 10; i++) st.m[i] = 0.f;
+    for (int i = 0; i < 4; i++) st.s[i] = 0.f;
+    st.n = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if ((mask >> k) & 1u) {
+            const float r = px[0][k], g = px[1][k], b = px[2][k];
+            st.n += 1.0f;
+            st.s[0] += r; st.s[1] += g; st.s[2] += b;
+            st.m[0] += r * r; st.m[1] += r * g; st.m[2] += r * b;
+            st.m[4] += g * g; st.m[5] += g * b;
+            st.m[7] += b * b;
+            if (CH == 4) {
+                const float a = px[3][k];
+                st.s[3] += a;
+                st.m[3] += r * a; st.m[6] += g * a; st.m[8] += b * a; st.m[9] += a * a;
+            }
+        }
+    }
+}
+
+// covariance = moments - sum*sum*rcp(n)                       (kernel.ispc:805-823)
+template <int CH>
+__device__ __forceinline__ void covariance_of(float (&cv)[10], const Stats<CH>& st, float rn)
+{
+    cv[0] = st.m[0] - st.s[0] * st.s[0] * rn;
+    cv[1] = st.m[1] - st.s[0] * st.s[1] * rn;
+    cv[2] = st.m[2] - st.s[0] * st.s[2] * rn;
+    cv[4] = st.m[4] - st.s[1] * st.s[1] * rn;
+    cv[5] = st.m[5] - st.s[1] * st.s[2] * rn;
+    cv[7] = st.m[7] - st.s[2] * st.s[2] * rn;
+    if (CH == 4) {
+        cv[3] = st.m[3] - st.s[0] * st.s[3] * rn;
+        cv[6] = st.m[6] - st.s[1] * st.s[3] * rn;
+        cv[8] = st.m[8] - st.s[2] * st.s[3] * rn;
+        cv[9] = st.m[9] - st.s[3] * st.s[3] * rn;
+    } else {
+        cv[3] = cv[6] = cv[8] = cv[9] = 0.f;
+    }
+}
+
+// Power iteration from (1,..,1), renormalised (rsqrt) after every second step.  (kernel.ispc:207-229)
+template <int CH, int ITERS>
+__device__ __forceinline__ void principal_axis(float (&v)[4], const float (&cv)[10], const SeedTables& T)
+{
+    v[0] = v[1] = v[2] = v[3] = 1.f;
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        float a[4];
+        if (CH == 3) {
+            a[0] = cv[0] * v[0] + cv[1] * v[1] + cv[2] * v[2];
+            a[1] = cv[1] * v[0] + cv[4] * v[1] + cv[5] * v[2];
+            a[2] = cv[2] * v[0] + cv[5] * v[1] + cv[7] * v[2];
+            a[3] = 0.f;
+        } else {
+            a[0] = cv[0] * v[0] + cv[1] * v[1] + cv[2] * v[2] + cv[3] * v[3];
+            a[1] = cv[1] * v[0] + cv[4] * v[1] + cv[5] * v[2] + cv[6] * v[3];
+            a[2] = cv[2] * v[0] + cv[5] * v[1] + cv[7] * v[2] + cv[8] * v[3];
+            a[3] = cv[3] * v[0] + cv[6] * v[1] + cv[8] * v[2] + cv[9] * v[3];
+        }
+        for (int p = 0; p < CH; p++) v[p] = a[p];
+        if (it & 1) {
+            float nsq = 0.f;
+            for (int p = 0; p < CH; p++) nsq += a[p] * a[p];
+            const float rn = ispc_rsqrt(nsq, T);
+            for (int p = 0; p < CH; p++) v[p] *= rn;
+        }
+    }
+}
+
+// PCA line fit of one subset: endpoints = mean + extreme projections * axis.
+// CLAMP255: BC7 clamps to [0,255] (kernel.ispc:896-905); BC6H keeps the raw fit (857-894).
+// ep[0][p] / ep[1][p]: low / high endpoint.  Slots p >= CH are left untouched.
+template <int CH, bool CLAMP255>
+__device__ __forceinline__ void fit_subset(float (&ep)[2][4], const float (&px)[4][16], uint32_t mask, const SeedTables& T)
+{
+    Stats<CH> st;
+    stats_of<CH>(st, px, mask);
+    const float rn = ispc_rcp(st.n, T);
+    float cv[10];
+    covariance_of<CH>(cv, st, rn);
+    float dc[4];
+    for (int p = 0; p < CH; p++) dc[p] = st.s[p] * rn;
+
+    const float inv_var = 1.0f / 65536.0f;
+    for (int i = 0; i < 10; i++) cv[i] *= inv_var;
+    const float eps = 0.001f * 0.001f;
+    cv[0] += eps; cv[4] += eps; cv[7] += eps; cv[9] += eps;
+
+    float axis[4];
+    principal_axis<CH, 8>(axis, cv, T);
+
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if ((mask >> k) & 1u) {
+            float dot = 0.f;
+            for (int p = 0; p < CH; p++) dot += axis[p] * (px[p][k] - dc[p]);
+            lo = fmin_x86(lo, dot);
+            hi = fmax_x86(hi, dot);
+        }
+    }
+    if (hi - lo < 1.0f) { lo -= 0.5f; hi += 0.5f; }
+    for (int p = 0; p < CH; p++) {
+        float a = lo * axis[p] + dc[p], b = hi * axis[p] + dc[p];
+        if (CLAMP255) { a = fclamp_x86(a, 0.f, 255.f); b = fclamp_x86(b, 0.f, 255.f); }
+        ep[0][p] = a; ep[1][p] = b;
+    }
+}
+
+// trace - largest eigenvalue (4 power iterations) of a scaled covariance.   (kernel.ispc:907-939)
+template <int CH>
+__device__ __forceinline__ float pca_residual(float (&cv)[10], const SeedTables& T)
+{
+    const float inv_var = 1.0f / 65536.0f;
+    for (int i = 0; i < 10; i++) cv[i] *= inv_var;
+    const float eps = 0.001f * 0.001f;
+    cv[0] += eps; cv[4] += eps; cv[7] += eps;           // not cv[9]: reference quirk
+    float axis[4];
+    principal_axis<CH, 4>(axis, cv, T);
+    float w[4];
+    if (CH == 3) {
+        w[0] = cv[0] * axis[0] + cv[1] * axis[1] + cv[2] * axis[2];
+        w[1] = cv[1] * axis[0] + cv[4] * axis[1] + cv[5] * axis[2];
+        w[2] = cv[2] * axis[0] + cv[5] * axis[1] + cv[7] * axis[2];
+    } else {
+        w[0] = cv[0] * axis[0] + cv[1] * axis[1] + cv[2] * axis[2] + cv[3] * axis[3];
+        w[1] = cv[1] * axis[0] + cv[4] * axis[1] + cv[5] * axis[2] + cv[6] * axis[3];
+        w[2] = cv[2] * axis[0] + cv[5] * axis[1] + cv[7] * axis[2] + cv[8] * axis[3];
+        w[3] = cv[3] * axis[0] + cv[6] * axis[1] + cv[8] * axis[2] + cv[9] * axis[3];
+    }
+    float sq_sum = 0.f;
+    for (int p = 0; p < CH; p++) sq_sum += sq(w[p]);
+    const float lambda = sqrtf(sq_sum);
+    float bound = cv[0] + cv[4] + cv[7];
+    if (CH == 4) bound += cv[9];
+    bound -= lambda;
+    return fmax_x86(bound, 0.0f);
+}
+
+// Lower bound on the two-subset error of a shape, as an integer sort key component:
+// (int)(sqrt(res(subset0) + res(rest)) * 256), rest = full - subset0.   (kernel.ispc:952-971, 1404-1409)
+template <int CH>
+__device__ __forceinline__ int32_t split_bound(const float (&px)[4][16], uint32_t mask0, const Stats<CH>& full, const SeedTables& T)
+{
+    Stats<CH> a;
+    stats_of<CH>(a, px, mask0);
+    float cv1[10], cv2[10];
+    covariance_of<CH>(cv1, a, ispc_rcp(a.n, T));
+    Stats<CH> b;
+    for (int i = 0; i < 10; i++) b.m[i] = full.m[i] - a.m[i];
+    for (int i = 0; i < 4; i++) b.s[i] = full.s[i] - a.s[i];
+    b.n = full.n - a.n;
+    covariance_of<CH>(cv2, b, ispc_rcp(b.n, T));
+    float bound = 0.f;
+    bound += pca_residual<CH>(cv1, T);
+    bound += pca_residual<CH>(cv2, T);
+    return f2i_x86(sqrtf(bound) * 256.0f);
+}
+
+// ---- index selection (kernel.ispc:1133-1193) -------------------------------
+// Interpolation weight of index q at BITS bits: round(64*q/(2^BITS-1)) = the format's weight tables.
+template <int BITS>
+__device__ __forceinline__ int32_t weight_of(int32_t q)
+{
+    constexpr int D = (1 << BITS) - 1;
+    return (q * 128 + D) / (2 * D);
+}
+
+// For every texel: project on its subset's segment, try the two neighbouring indices, keep the better.
+// Returns the summed (integer-truncated) squared error; indices packed 4 bits/texel into qb[2].
+// HDR selects cvttps2dq semantics for the error truncation (BC6H errors overflow int; BC7's cannot).
+template <int BITS, int CH, bool HDR>
+__device__ __forceinline__ float select_indices(uint32_t (&qb)[2], const float (&px)[4][16], const float (&ep)[3][2][4], uint32_t pattern)
+{
+    constexpr int LEVELS = 1 << BITS;
+    float total = 0.f;
+    qb[0] = qb[1] = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const uint32_t j = (pattern >> (2 * k)) & 3u;
+        float a[CH], b[CH];
+        for (int p = 0; p < CH; p++) {
+            a[p] = (j == 0) ? ep[0][0][p] : ((j == 1) ? ep[1][0][p] : ep[2][0][p]);
+            b[p] = (j == 0) ? ep[0][1][p] : ((j == 1) ? ep[1][1][p] : ep[2][1][p]);
+        }
+        float proj = 0.f, div = 0.f;
+        for (int p = 0; p < CH; p++) {
+            proj += (px[p][k] - a[p]) * (b[p] - a[p]);
+            div += sq(b[p] - a[p]);
+        }
+        proj = proj / div;                                   // IEEE divide (compound `/=` in the reference)
+        int32_t q1 = f2i_x86(proj * (float)LEVELS + 0.5f);
+        q1 = iclamp(q1, 1, LEVELS - 1);
+        const float w0 = (float)weight_of<BITS>(q1 - 1), w1 = (float)weight_of<BITS>(q1);
+        const float u0 = 64.0f - w0, u1 = 64.0f - w1;       // (64-w) is exact in int and in float
+        float err0 = 0.f, err1 = 0.f;
+        for (int p = 0; p < CH; p++) {
+            const float d0 = (float)f2i_x86((u0 * a[p] + w0 * b[p] + 32.0f) * 0.015625f);
+            const float d1 = (float)f2i_x86((u1 * a[p] + w1 * b[p] + 32.0f) * 0.015625f);
+            err0 += sq(d0 - px[p][k]);
+            err1 += sq(d1 - px[p][k]);
+        }
+        const bool first = err0 < err1;
+        const float e = first ? err0 : err1;
+        const int32_t ei = HDR ? f2i_x86(e) : (int32_t)e;
+        const uint32_t q = (uint32_t)(first ? q1 - 1 : q1);
+        if (k < 8) qb[0] += q << (4 * k); else qb[1] += q << (4 * (k - 8));
+        total += (float)ei;
+    }
+    return total;
+}
+
+// ---- least-squares endpoints for fixed indices (kernel.ispc:1198-1262) ------
+template <int BITS, int CH>
+__device__ __forceinline__ void refit_subset(float (&ep)[2][4], const float (&px)[4][16], const uint32_t (&qb)[2], uint32_t mask, const SeedTables& T)
+{
+    constexpr float L1 = (float)((1 << BITS) - 1);
+    float atb1[4] = {0.f, 0.f, 0.f, 0.f}, sum[4] = {0.f, 0.f, 0.f, 0.f};
+    float sum_q = 0.f, sum_qq = 0.f, cnt = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if ((mask >> k) & 1u) {
+            const float q = (float)((k < 8 ? qb[0] >> (4 * k) : qb[1] >> (4 * (k - 8))) & 15u);
+            const float x = L1 - q;
+            sum_q += q;
+            sum_qq += q * q;
+            cnt += 1.0f;
+            for (int p = 0; p < CH; p++) sum[p] += px[p][k];
+            for (int p = 0; p < CH; p++) atb1[p] += x * px[p][k];
+        }
+    }
+    const float cxx = cnt * (L1 * L1) - (2.0f * L1) * sum_q + sum_qq;
+    const float cyy = sum_qq;
+    const float cxy = L1 * sum_q - sum_qq;
+    const float det = cxx * cyy - cxy * cxy;
+    const float scale = L1 * ispc_rcp(det, T);
+    const bool flat = fabsf(det) < 0.001f;
+    const float rcnt = ispc_rcp(cnt, T);
+    for (int p = 0; p < CH; p++) {
+        const float atb2 = L1 * sum[p] - atb1[p];
+        const float e0 = (atb1[p] * cyy - atb2 * cxy) * scale;
+        const float e1 = (atb2 * cxx - atb1[p] * cxy) * scale;
+        const float mean = sum[p] * rcnt;
+        ep[0][p] = flat ? mean : e0;
+        ep[1][p] = flat ? mean : e1;
+    }
+}
+
+// ---- 128-bit block assembly --------------------------------------------------
+// Fields are appended LSB first.  Header fields have lane-independent positions; the index fields are
+// written full width and the implicit MSBs of the anchor texels are deleted afterwards (highest
+// position first), like kernel.ispc:1746-1805 -- the deleted bits are zero by construction.
+struct BlockBits {
+    unsigned long long lo = 0, hi = 0;
+    uint32_t ext = 0;          // bits 128.. while anchor MSBs are still in place
+    __device__ __forceinline__ void put(int pos, int n, uint32_t v)
+    {
+        const unsigned long long x = (unsigned long long)v;
+        if (pos < 64) {
+            lo |= x << pos;
+            if (pos + n > 64) hi |= x >> (64 - pos);
+        } else if (pos < 128) {
+            hi |= x << (pos - 64);
+            if (pos + n > 128) ext |= (uint32_t)(x >> (128 - pos));
+        } else {
+            ext |= v << (pos - 128);
+        }
+    }
+    // remove bit `at` (64 <= at < 128 + valid ext bits); everything above moves down by one
+    __device__ __forceinline__ void drop_bit(int at)
+    {
+        const unsigned long long keep = (at >= 128) ? ~0ull : ((1ull << (at - 64)) - 1ull);
+        const unsigned long long shifted = (hi >> 1) | ((unsigned long long)(ext & 1u) << 63);
+        if (at < 128) { hi = (hi & keep) | (shifted & ~keep); ext >>= 1; }
+        else          { const uint32_t k2 = (1u << (at - 128)) - 1u; ext = (ext & k2) | ((ext >> 1) & ~k2); }
+    }
+};
+
+} // namespace itw

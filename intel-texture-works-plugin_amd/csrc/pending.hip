@@ -3,8 +3,6 @@
 #include <cstdlib>
 #include "kernels.hpp"
 namespace itw {
-void launch_bc7(const uint8_t*, int64_t, int, int, uint8_t*, const bc7_enc_settings&, hipStream_t)
-{ std::fprintf(stderr, "libispc_texcomp (itw-amd): BC7 kernel not built\n"); std::abort(); }
 void launch_bc6h(const uint8_t*, int64_t, int, int, uint8_t*, const bc6h_enc_settings&, hipStream_t)
 { std::fprintf(stderr, "libispc_texcomp (itw-amd): BC6H kernel not built\n"); std::abort(); }
 }
