@@ -1,0 +1,425 @@
+// bc6h.hip -- BC6H (unsigned half) encoder kernel for gfx950 (MI355X).
+//
+// Replaces kernel.ispc:2039-3139 (CompressBlocksBC6H_ispc) behind CompressBlocksBC6H
+// (ispc_texcomp.cpp:432-435).  The reference has no signed encoder (BC6H_SF16 routes
+// to the same code, IntelPlugin.cpp:841); half bit patterns are consumed as integers.
+//
+// Mapping: one 4x4 block per lane; 128 B in (16 x RGBA16F, two dwordx4 loads per texel
+// row), 16 B out.  Search structure follows the reference -- span gated mode
+// selection, PCA-ranked two-region shapes, unclamped PCA fits, LS refinement -- built
+// from the shared device routines of bcn_core.hpp.  Differences in organisation:
+//   * the PCA ranking of the 32 shapes depends only on the block, not on the mode
+//     being tried, so it is computed once per block (the reference recomputes it for
+//     each of the up to seven two-region modes) and kept in LDS;
+//   * headers are packed from the format's bit-layout table (bc6h_layout.hpp, derived
+//     from the decoder's mode descriptors), one compile-time specialisation per mode,
+//     instead of the reference's per-mode arithmetic scatter (kernel.ispc:2392-2980).
+// fp32 VALU bound; no MFMA-shaped work.
+#include "bcn_core.hpp"
+#include "bc6h_layout.hpp"
+#include "kernels.hpp"
+
+namespace itw {
+
+constexpr int TPB6 = 64;
+constexpr float INV65535 = 1.0f / 65535.0f;     // ep/(256*256f-1) under fast-math
+constexpr float INV31 = 1.0f / 31.0f;
+
+struct HLane {
+    float px[4][16];          // uf16-domain texels (plane 3 unused)
+    float best_err;
+    uint32_t best[4];
+    float lo[3], hi[3];       // per-channel bounds
+    float max_span;
+    int32_t max_span_idx;
+    int32_t mode, epb;
+    int32_t qlo[3], qhi[3];   // endpoint clamp window in code space
+    SeedTables T;
+    int32_t* keys;            // LDS column, 32 entries
+    bool ranked;
+};
+
+// ---- format data (kernel.ispc:2080-2125) -----------------------------------
+__device__ __forceinline__ float span_of(int mode)
+{
+    // float expressions truncated to int, as the reference's `uniform int span = span_table[mode]` does
+    switch (mode) {
+    case 0:  return (float)(int)(0.9f * 65535.f / 64);
+    case 1:  return (float)(int)(0.9f * 65535.f / 4);
+    case 2:  return (float)(int)(0.8f * 65535.f / 256);
+    case 5:  return (float)(int)(0.9f * 65535.f / 32);
+    case 6:  return (float)(int)(0.9f * 65535.f / 16);
+    case 9:  return 65535.f;
+    case 10: return 65535.f;
+    case 11: return (float)(int)(0.95f * 65535.f / 8);
+    case 12: return (float)(int)(0.95f * 65535.f / 32);
+    default: return 6.f;   // 13
+    }
+}
+
+__device__ __forceinline__ int bits_of(int mode)
+{
+    switch (mode) {
+    case 0: return 10; case 1: return 7; case 2: return 11; case 5: return 9; case 6: return 8; case 9: return 6;
+    case 10: return 10; case 11: return 11; case 12: return 12; default: return 16;
+    }
+}
+
+__device__ __forceinline__ int32_t code_to_uf16(uint32_t v, int32_t bits)             // kernel.ispc:2130-2137
+{
+    if (bits >= 15) return (int32_t)v;
+    if (v == 0u) return 0;
+    if (v == (1u << bits) - 1u) return 0xFFFF;
+    return (int32_t)((v * 2u + 1u) << (15 - bits));
+}
+
+// quantise one endpoint pair to the lane's precision, clamp into the delta window, reconstruct. [2139-2169]
+__device__ __forceinline__ void quant_pair(int32_t (&q)[2][4], float (&e)[2][4], const HLane& ln)
+{
+    const int32_t levels = 1 << ln.epb;
+    for (int i = 0; i < 2; i++)
+        for (int p = 0; p < 3; p++) {
+            int32_t v = f2i_x86(e[i][p] * INV65535 * (float)(levels - 1) + 0.5f);
+            v = iclamp(v, 0, levels - 1);
+            v = iclamp(v, ln.qlo[p], ln.qhi[p]);
+            q[i][p] = v;
+            e[i][p] = (float)code_to_uf16((uint32_t)v, ln.epb);
+        }
+    q[0][3] = q[1][3] = 0;
+}
+
+// clamp window centred on the block's mid-range                                          [2302-2330]
+__device__ __forceinline__ void set_window(HLane& ln, float span, int wide_channel)
+{
+    const int32_t levels = 1 << ln.epb;
+    for (int p = 0; p < 3; p++) {
+        float s = span;
+        if (wide_channel >= 0) s *= (p == wide_channel) ? 2.0f : 1.0f;
+        const float middle = (ln.lo[p] + ln.hi[p]) * 0.5f;
+        const float b0 = middle - s * 0.5f, b1 = middle + s * 0.5f;
+        ln.qlo[p] = iclamp(f2i_x86(b0 * INV65535 * (float)(levels - 1) + 0.5f), 0, levels - 1);
+        ln.qhi[p] = iclamp(f2i_x86(b1 * INV65535 * (float)(levels - 1) + 0.5f), 0, levels - 1);
+    }
+}
+
+// ---- header packing from the layout table -------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ void pack_header(BlockBits& bb, const int32_t (&q)[2][2][4], uint32_t shape)
+{
+    constexpr Bc6hLayout L = BC6H_LAYOUT[MODE];
+    constexpr int HEADER = L.two_regions ? 82 : 65;
+    // field values: W = region 0 low endpoint (absolute); X, Y, Z absolute or delta against W
+    uint32_t f[4][3];
+    for (int ch = 0; ch < 3; ch++) {
+        const uint32_t w = (uint32_t)q[0][0][ch];
+        f[0][ch] = w;
+        f[1][ch] = L.transformed ? (uint32_t)q[0][1][ch] - w : (uint32_t)q[0][1][ch];
+        f[2][ch] = L.transformed ? (uint32_t)q[1][0][ch] - w : (uint32_t)q[1][0][ch];
+        f[3][ch] = L.transformed ? (uint32_t)q[1][1][ch] - w : (uint32_t)q[1][1][ch];
+    }
+#pragma unroll
+    for (int i = 0; i < HEADER; i++) {
+        const int field = L.slot[i] >> 4, bit = L.slot[i] & 15;
+        uint32_t src;
+        if (field == 1)      src = (uint32_t)L.prefix;
+        else if (field == 2) src = shape;
+        else                 src = f[(field - 3) & 3][(field - 3) >> 2];
+        bb.put(i, 1, (src >> bit) & 1u);
+    }
+}
+
+__device__ __forceinline__ void pack_header_dyn(BlockBits& bb, int mode, const int32_t (&q)[2][2][4], uint32_t shape)
+{
+    switch (mode) {
+    case 0: pack_header<0>(bb, q, shape); break;   case 1: pack_header<1>(bb, q, shape); break;
+    case 2: pack_header<2>(bb, q, shape); break;   case 3: pack_header<3>(bb, q, shape); break;
+    case 4: pack_header<4>(bb, q, shape); break;   case 5: pack_header<5>(bb, q, shape); break;
+    case 6: pack_header<6>(bb, q, shape); break;   case 7: pack_header<7>(bb, q, shape); break;
+    case 8: pack_header<8>(bb, q, shape); break;   case 9: pack_header<9>(bb, q, shape); break;
+    case 10: pack_header<10>(bb, q, shape); break; case 11: pack_header<11>(bb, q, shape); break;
+    case 12: pack_header<12>(bb, q, shape); break; default: pack_header<13>(bb, q, shape); break;
+    }
+}
+
+__device__ __forceinline__ void store_bits(uint32_t (&out)[4], const BlockBits& bb)
+{
+    out[0] = (uint32_t)bb.lo; out[1] = (uint32_t)(bb.lo >> 32); out[2] = (uint32_t)bb.hi; out[3] = (uint32_t)(bb.hi >> 32);
+}
+
+// two-region block: anchor rule as BC7 mode 1, 3-bit indices                             [2982-3010]
+__device__ __forceinline__ void emit_two_region(uint32_t (&out)[4], int32_t (&q)[2][2][4], const uint32_t (&qb)[2], int shape, int mode)
+{
+    const Shape sh = load_shape(shape);
+    const int a1 = (int)(sh.anchors >> 4);
+    uint32_t flips = 0;
+    for (int j = 0; j < 2; j++) {
+        const int k0 = (j == 0) ? 0 : a1;
+        const uint32_t word = (k0 < 8) ? qb[0] : qb[1];
+        if (((word >> (4 * (k0 & 7))) & 15u) >= 4u) {
+            for (int p = 0; p < 4; p++) { const int32_t t = q[j][0][p]; q[j][0][p] = q[j][1][p]; q[j][1][p] = t; }
+            flips |= subset_mask(sh, j);
+        }
+    }
+    BlockBits bb;
+    pack_header_dyn(bb, mode, q, (uint32_t)shape);
+    int pos = 82;
+    for (int k = 0; k < 16; k++) {
+        uint32_t v = ((k < 8 ? qb[0] >> (4 * k) : qb[1] >> (4 * (k - 8))) & 15u);
+        if ((flips >> k) & 1u) v = 7u - v;
+        const int n = (k == 0) ? 2 : 3;
+        bb.put(pos, n, v); pos += n;
+    }
+    bb.drop_bit(82 + 3 * a1 + 1);
+    store_bits(out, bb);
+}
+
+// one-region block: 4-bit indices                                                         [3012-3031]
+__device__ __forceinline__ void emit_one_region(uint32_t (&out)[4], int32_t (&q)[2][4], uint32_t (&qb)[2], int mode)
+{
+    if ((qb[0] & 15u) >= 8u) {
+        for (int p = 0; p < 4; p++) { const int32_t t = q[0][p]; q[0][p] = q[1][p]; q[1][p] = t; }
+        qb[0] = 0xFFFFFFFFu - qb[0];
+        qb[1] = 0xFFFFFFFFu - qb[1];
+    }
+    int32_t q2[2][2][4];
+    for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) { q2[0][i][p] = q[i][p]; q2[1][i][p] = 0; }
+    BlockBits bb;
+    pack_header_dyn(bb, mode, q2, 0u);
+    int pos = 65;
+    for (int k = 0; k < 16; k++) {
+        const uint32_t v = ((k < 8 ? qb[0] >> (4 * k) : qb[1] >> (4 * (k - 8))) & 15u);
+        const int n = (k == 0) ? 3 : 4;
+        bb.put(pos, n, v); pos += n;
+    }
+    store_bits(out, bb);
+}
+
+// ---- searches ----------------------------------------------------------------------------------
+__device__ __forceinline__ void rank_shapes32(HLane& ln)                                  // [2259-2269]
+{
+    if (ln.ranked) return;                          // depends on the block only: once per block
+    Stats<3> full;
+    stats_of<3>(full, ln.px, 0xffffu);
+    for (int part = 0; part < 32; part++) {
+        const uint32_t m0 = BCN_SUBSET_MASKS[part] & 0xffffu;
+        const int32_t bound = split_bound<3>(ln.px, m0, full, ln.T);
+        ln.keys[part * TPB6] = (int32_t)((uint32_t)part + (uint32_t)bound * 64u);
+    }
+    ln.ranked = true;
+}
+
+__device__ __forceinline__ int32_t next_key32(const HLane& ln, int32_t prev, bool first)
+{
+    int32_t cur = 0x7fffffff;
+    for (int i = 0; i < 32; i++) {
+        const int32_t k = ln.keys[i * TPB6];
+        if ((first || k > prev) && k <= cur) cur = k;
+    }
+    return cur;
+}
+
+// two-region search at the lane's current (mode, epb, window)                             [2174-2273]
+__device__ __forceinline__ void encode_two_region(HLane& ln, int count, int refine)
+{
+    rank_shapes32(ln);
+    if (count <= 0) return;
+    count = min(count, 32);
+
+    int32_t bq[2][2][4];
+    uint32_t bqb[2] = {0u, 0u};
+    int32_t bshape = 0;
+    float berr = __builtin_inff();
+    for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = 0;
+
+    int32_t prev = 0;
+    for (int c = 0; c < count; c++) {
+        prev = next_key32(ln, prev, c == 0);
+        const int shape = prev & 31;
+        const Shape sh = load_shape(shape);
+        float ep[3][2][4];
+        int32_t q[2][2][4];
+        for (int j = 0; j < 2; j++) {
+            fit_subset<3, false>(ep[j], ln.px, subset_mask(sh, j), ln.T);
+            quant_pair(q[j], ep[j], ln);
+        }
+        uint32_t qb[2];
+        const float err = select_indices<3, 3, true>(qb, ln.px, ep, sh.pattern);
+        if (err < berr) {
+            for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = q[j][i][p];
+            bqb[0] = qb[0]; bqb[1] = qb[1];
+            bshape = shape;
+            berr = err;
+        }
+    }
+
+    const Shape sh = load_shape(bshape);
+    for (int it = 0; it < refine; it++) {
+        float ep[3][2][4];
+        int32_t q[2][2][4];
+        for (int j = 0; j < 2; j++) {
+            refit_subset<3, 3>(ep[j], ln.px, bqb, subset_mask(sh, j), ln.T);
+            quant_pair(q[j], ep[j], ln);
+        }
+        uint32_t qb[2];
+        const float err = select_indices<3, 3, true>(qb, ln.px, ep, sh.pattern);
+        if (err < berr) {
+            for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = q[j][i][p];
+            bqb[0] = qb[0]; bqb[1] = qb[1];
+            berr = err;
+        }
+    }
+
+    if (berr < ln.best_err) {
+        ln.best_err = berr;
+        emit_two_region(ln.best, bq, bqb, bshape, ln.mode);
+    }
+}
+
+// one-region search                                                                        [2275-2300]
+__device__ __forceinline__ void encode_one_region(HLane& ln, int refine)
+{
+    float ep[3][2][4];
+    int32_t q[2][4];
+    uint32_t qb[2];
+    fit_subset<3, false>(ep[0], ln.px, 0xffffu, ln.T);
+    quant_pair(q, ep[0], ln);
+    float err = select_indices<4, 3, true>(qb, ln.px, ep, 0u);
+    for (int it = 0; it < refine; it++) {
+        refit_subset<4, 3>(ep[0], ln.px, qb, 0xffffu, ln.T);
+        quant_pair(q, ep[0], ln);
+        err = select_indices<4, 3, true>(qb, ln.px, ep, 0u);
+    }
+    if (err < ln.best_err) {
+        ln.best_err = err;
+        emit_one_region(ln.best, q, qb, ln.mode);
+    }
+}
+
+// gate a mode on the block's widest channel span; optionally encode with it               [2332-2365]
+__device__ __forceinline__ void test_mode(HLane& ln, const bc6h_enc_settings& S, int mode, bool enc, float margin)
+{
+    const float span = span_of(mode);
+    if (ln.max_span * margin > span) return;
+    ln.epb = bits_of(mode);
+    if (mode >= 10) {
+        ln.mode = mode;
+        set_window(ln, span, -1);
+        if (enc) encode_one_region(ln, S.refineIterations_1p);
+    } else if (mode <= 1 || mode == 5 || mode == 9) {
+        ln.mode = mode;
+        set_window(ln, span, -1);
+        if (enc) encode_two_region(ln, S.fastSkipTreshold, S.refineIterations_2p);
+    } else {
+        ln.mode = mode + ln.max_span_idx;           // 2 -> 2/3/4, 6 -> 6/7/8 by the widest channel
+        set_window(ln, span, ln.max_span_idx);
+        if (enc) encode_two_region(ln, S.fastSkipTreshold, S.refineIterations_2p);
+    }
+}
+
+template <bool VEC16>
+__global__ void __launch_bounds__(TPB6)
+bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
+            uint8_t* __restrict__ dst, const bc6h_enc_settings S)
+{
+    __shared__ int32_t s_keys[32 * TPB6];
+    const int32_t b = blockIdx.x * TPB6 + threadIdx.x;
+    if (b >= nblocks) return;
+    const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
+
+    HLane ln;
+    ln.T = global_seed_tables();
+    ln.keys = s_keys + threadIdx.x;
+    ln.ranked = false;
+
+    // load: 4 texels x 8 bytes per row; keep R,G,B half bit patterns as integers    [kernel.ispc:134-151]
+    const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 32;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        uint32_t w[8];
+        if (VEC16) {
+            const uint4 v0 = *reinterpret_cast<const uint4*>(p + y * stride);
+            const uint4 v1 = *reinterpret_cast<const uint4*>(p + y * stride + 16);
+            w[0] = v0.x; w[1] = v0.y; w[2] = v0.z; w[3] = v0.w; w[4] = v1.x; w[5] = v1.y; w[6] = v1.z; w[7] = v1.w;
+        } else {
+            const uint16_t* q = reinterpret_cast<const uint16_t*>(p + y * stride);
+            for (int i = 0; i < 8; i++) w[i] = (uint32_t)q[2 * i] | ((uint32_t)q[2 * i + 1] << 16);
+        }
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            ln.px[0][y * 4 + x] = (float)(w[2 * x] & 0xffffu);
+            ln.px[1][y * 4 + x] = (float)(w[2 * x] >> 16);
+            ln.px[2][y * 4 + x] = (float)(w[2 * x + 1] & 0xffffu);
+            ln.px[3][y * 4 + x] = 0.f;
+        }
+    }
+
+    // half bits -> uf16 code space (x/31*64), channel bounds, widest channel          [kernel.ispc:3036-3067]
+    for (int c = 0; c < 3; c++) { ln.lo[c] = 65535.f; ln.hi[c] = 0.f; }
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float v = (ln.px[c][k] * INV31) * 64.0f;
+            ln.px[c][k] = v;
+            ln.lo[c] = fmin_x86(ln.lo[c], v);
+            ln.hi[c] = fmax_x86(ln.hi[c], v);
+        }
+    ln.max_span = 0.f;
+    ln.max_span_idx = 0;
+    for (int c = 0; c < 3; c++) {
+        const float s = ln.hi[c] - ln.lo[c];
+        if (s > ln.max_span) { ln.max_span_idx = c; ln.max_span = s; }
+    }
+
+    ln.best_err = __builtin_inff();
+    ln.best[0] = ln.best[1] = ln.best[2] = ln.best[3] = 0u;
+    ln.mode = 0; ln.epb = 0;
+    for (int c = 0; c < 3; c++) { ln.qlo[c] = 0; ln.qhi[c] = 0; }
+
+    if (S.slow_mode) {                                                                  // [kernel.ispc:3073-3085]
+        test_mode(ln, S, 0, true, 0.f);
+        test_mode(ln, S, 1, true, 0.f);
+        test_mode(ln, S, 2, true, 0.f);
+        test_mode(ln, S, 5, true, 0.f);
+        test_mode(ln, S, 6, true, 0.f);
+        test_mode(ln, S, 9, true, 0.f);
+        test_mode(ln, S, 10, true, 0.f);
+        test_mode(ln, S, 11, true, 0.f);
+        test_mode(ln, S, 12, true, 0.f);
+        test_mode(ln, S, 13, true, 0.f);
+    } else {                                                                            // [kernel.ispc:3086-3106]
+        const float inv1_2 = 1.0f / 1.2f;
+        if (S.fastSkipTreshold > 0) {
+            test_mode(ln, S, 9, false, 0.f);
+            if (S.fast_mode) test_mode(ln, S, 1, false, 1.f);
+            test_mode(ln, S, 6, false, inv1_2);
+            test_mode(ln, S, 5, false, inv1_2);
+            test_mode(ln, S, 0, false, inv1_2);
+            test_mode(ln, S, 2, false, 1.f);
+            encode_two_region(ln, S.fastSkipTreshold, S.refineIterations_2p);
+            if (!S.fast_mode) test_mode(ln, S, 1, true, 0.f);
+        }
+        test_mode(ln, S, 10, false, 0.f);
+        test_mode(ln, S, 11, false, 1.f);
+        test_mode(ln, S, 12, false, 1.f);
+        test_mode(ln, S, 13, false, 1.f);
+        encode_one_region(ln, S.refineIterations_1p);
+    }
+
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
+    if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(ln.best[0], ln.best[1], ln.best[2], ln.best[3]);
+    else { d[0] = ln.best[0]; d[1] = ln.best[1]; d[2] = ln.best[2]; d[3] = ln.best[3]; }
+}
+
+void launch_bc6h(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
+                 const bc6h_enc_settings& s, hipStream_t st)
+{
+    const int bx = width / 4, by = height / 4;
+    const int64_t n = (int64_t)bx * by;
+    if (n <= 0) return;
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const dim3 grid((unsigned)((n + TPB6 - 1) / TPB6)), blk(TPB6);
+    if (vec) hipLaunchKernelGGL((bc6h_kernel<true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
+    else     hipLaunchKernelGGL((bc6h_kernel<false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
+}
+
+} // namespace itw
