@@ -100,13 +100,14 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
 
 void compress(const Job& j, const rgba_surface* src, uint8_t* dst)
 {
-    if (!src || !src->ptr || !dst) {
-        std::fprintf(stderr, "libispc_texcomp (itw-amd): null surface or destination\n");
-        std::abort();
-    }
+    if (!src) { std::fprintf(stderr, "libispc_texcomp (itw-amd): null surface\n"); std::abort(); }
     const int w = src->width, h = src->height;
     const int bx = w / 4, by = h / 4;                 // partial blocks dropped (kernel.ispc:600-601)
-    if (bx <= 0 || by <= 0) return;
+    if (bx <= 0 || by <= 0) return;                   // nothing to encode: the reference's loops do not run either
+    if (!src->ptr || !dst) {
+        std::fprintf(stderr, "libispc_texcomp (itw-amd): null texel or destination pointer\n");
+        std::abort();
+    }
     const int bpb = (j.fmt == Fmt::BC1) ? 8 : 16;
     const int texel_bytes = (j.fmt == Fmt::BC6H) ? 8 : 4;
     const size_t row_bytes = (size_t)bx * 4 * texel_bytes;
