@@ -73,7 +73,7 @@ def cpu_baseline(fmt, prof, img, budget_s=15.0):
     """Oracle on host cores, bounded sample of the same surface: grow the band until ~budget_s of CPU work."""
     from oracle import pyoracle            # checker / baseline leg only
     pyoracle.build()
-    cores = os.cpu_count() or 1
+    cores = pyoracle.usable_cores()           # honours the cgroup CPU quota of the box
     h, w = img.shape[:2]
     rows = min(h, max(4 * cores, 16))
     pyoracle.encode_mt(fmt, img[:rows], prof, threads=cores)          # warm the thread pool / caches
@@ -101,7 +101,8 @@ def cpu_baseline(fmt, prof, img, budget_s=15.0):
         pass
     return {"value": round(rows * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "sample": f"first {rows} of {h} texel rows of the same {w}x{h} surface, {reps} x {dt:.3f} s, "
-                      f"scalar C oracle (not ISPC SIMD), {cores} threads, reference band rule; cpu: {model}"}
+                      f"scalar C oracle (not ISPC SIMD), {cores} threads (= usable cores: min of cpu_count "
+                      f"{os.cpu_count()}, affinity, cgroup quota), reference band rule; cpu: {model}"}
 
 
 def pmc_traffic(workload):

@@ -137,12 +137,28 @@ def encode(fmt, img, profile=None, rows=None):
     return out
 
 
+def usable_cores():
+    """Hardware threads this process may actually use: min(cpu_count, affinity mask, cgroup CPU quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def encode_mt(fmt, img, profile=None, threads=None):
     """Row-band threaded encode with the reference's band rule (win32Threads.cpp:217-231):
     linesPerThread = ceil(h/n), y_start = lines*i/4*4.  ctypes releases the GIL."""
     from concurrent.futures import ThreadPoolExecutor
     h, w = img.shape[:2]
-    n = threads or os.cpu_count() or 1
+    n = threads or usable_cores()
     lines = (h + n - 1) // n
     bands = []
     for i in range(n):
