@@ -150,19 +150,23 @@ def main():
     warmup = args.warmup if args.warmup is not None else (2 if heavy else 5)
     size = args.size
 
+    from itw_amd import shard
+    # The job: one (size*world) x size surface, sharded by block-row bands (itwBandForPart); rank r holds and encodes
+    # band r (its texels are generated locally -- synthetic data -- so no scatter is timed), then the compressed
+    # bands are all-gathered so every rank ends with the whole-image block stream.
+    y0, rows, band_off, band_bytes = shard.band_of(size, size * world, fmt, rank, world)
+    assert rows == size and y0 == rank * size
     img = make_surface(fmt, size, rank)
     d_img = torch.from_numpy(img).to(dev)
     bx = size // 4
     nblocks = bx * bx
-    band_bytes = nblocks * itw_amd.BYTES_PER_BLOCK[fmt]
-    # whole-image output: rank r's band lives at [r*band_bytes, (r+1)*band_bytes)
     d_full = torch.empty(world * band_bytes, dtype=torch.uint8, device=dev)
-    d_band = d_full[rank * band_bytes:(rank + 1) * band_bytes]
+    d_band = d_full[band_off:band_off + band_bytes]
 
     def step():
         itw_amd.compress(fmt, d_img, prof, out=d_band)
         if dist is not None:
-            dist.all_gather_into_tensor(d_full, d_band)     # gather of output bands over xGMI (RCCL)
+            dist.all_gather_into_tensor(d_full, d_band)     # gather of output bands over xGMI (RCCL), equal bands
 
     for _ in range(warmup):
         step()

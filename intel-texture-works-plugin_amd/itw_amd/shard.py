@@ -1,0 +1,64 @@
+"""Multi-GPU sharding of one surface: block-row bands, one per rank, and the gather of the output bands.
+
+The reference already shards the path by rows twice -- 256 Ki-pixel slices (IntelPlugin.cpp:851-879) and one
+4-row-aligned band per pool thread (win32Threads.cpp:211-249), each band encoded by an independent
+CompressBlocks* call writing at dst + row0*(width/4)*bytes_per_block (win32Threads.cpp:228-230).  Blocks never
+interact (kernel.ispc:573-596, 2014-2028, 3118-3130), so the same rule shards across GPUs with no halo and no
+data-path collective; the only exchange is the gather of the compressed bands to whoever needs the whole image.
+
+One process per GPU; torch.distributed is the transport (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in
+the CPU tests).  Band geometry comes from the C ABI (itwBandForPart) so host code in any language shards alike.
+"""
+from . import abi
+
+
+def band_of(width, height, fmt, rank, world):
+    """(first_texel_row, texel_rows, out_byte_offset, out_byte_len) of `rank`'s band."""
+    y0, rows, off = abi.band_for_part(width, height, fmt, rank, world)
+    nbytes = (rows // 4) * (width // 4) * abi.BYTES_PER_BLOCK[fmt]
+    return y0, rows, off, nbytes
+
+
+def encode_band(fmt, surface, settings, rank, world, encode=None):
+    """Encode this rank's band of `surface` (the whole (H, W, 4) surface or a view of it).  `encode(fmt, band,
+    settings)` defaults to the HIP path (abi.compress); tests inject a CPU encoder."""
+    h, w = surface.shape[:2]
+    y0, rows, off, nbytes = band_of(w, h, fmt, rank, world)
+    band = surface[y0:y0 + rows]
+    enc = encode or abi.compress
+    out = enc(fmt, band, settings)
+    assert out.numel() == nbytes
+    return out, off, nbytes
+
+
+def gather_bands(local, width, height, fmt, group=None):
+    """All-gather the per-rank block streams into the whole-image stream on every rank.  Bands may differ by one
+    block row when ranks do not divide height/4, so each rank contributes a slot of the maximum band size."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = [band_of(width, height, fmt, r, world)[3] for r in range(world)]
+    offs = [band_of(width, height, fmt, r, world)[2] for r in range(world)]
+    slot = max(sizes)
+    if all(s == slot for s in sizes):
+        full = torch.empty(slot * world, dtype=torch.uint8, device=local.device)
+        dist.all_gather_into_tensor(full, local.contiguous(), group=group)
+        return full
+    padded = torch.zeros(slot, dtype=torch.uint8, device=local.device)
+    padded[:local.numel()] = local
+    slots = torch.empty(slot * world, dtype=torch.uint8, device=local.device)
+    dist.all_gather_into_tensor(slots, padded, group=group)
+    full = torch.empty(sum(sizes), dtype=torch.uint8, device=local.device)
+    for r in range(world):
+        full[offs[r]:offs[r] + sizes[r]] = slots[r * slot:r * slot + sizes[r]]
+    return full
+
+
+def encode_sharded(fmt, surface, settings=None, group=None, encode=None):
+    """Whole-image block stream, computed by all ranks of `group` together.  Every rank passes the same surface
+    geometry and holds (at least) its own band of texels."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    local, _, _ = encode_band(fmt, surface, settings, rank, world, encode)
+    h, w = surface.shape[:2]
+    return gather_bands(local, w, h, fmt, group)

@@ -1,0 +1,62 @@
+"""Multi-process path on CPU: world_size 2 and 3 over gloo.  The band geometry comes from the product library
+(itwBandForPart, loadable without a GPU); the per-band encoder is injected (the oracle) because there is no GPU
+here -- what is under test is the sharding/gather logic that bench.py --gpus N runs over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fmt, prof, h, w, q):
+    for p in (ROOT, os.path.join(ROOT, "intel-texture-works-plugin_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from itw_amd import shard, surfaces
+    from oracle import pyoracle
+    img = surfaces.hdr_smooth(h, w) if fmt == "bc6h" else surfaces.ldr_smooth(h, w)
+
+    def cpu_encode(f, band, settings):            # stands in for the HIP path on this GPU-less box
+        return torch.from_numpy(pyoracle.encode(f, band.numpy(), settings))
+
+    t = torch.from_numpy(img.view(np.int16) if fmt == "bc6h" else img)
+    src = torch.from_numpy(img)
+    full = shard.encode_sharded(fmt, src if fmt != "bc6h" else torch.from_numpy(img), prof, encode=cpu_encode)
+    want = pyoracle.encode(fmt, img, prof)
+    q.put((rank, bool((full.numpy() == want).all()), int(full.numel())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,fmt,prof,h,w", [(2, "bc1", None, 64, 32), (2, "bc7", "veryfast", 32, 32),
+                                                (3, "bc3", None, 40, 16), (2, "bc6h", "fast", 16, 32)])
+def test_band_sharding_and_gather(world, fmt, prof, h, w):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, fmt, prof, h, w, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert len({n for _, _, n in res}) == 1
