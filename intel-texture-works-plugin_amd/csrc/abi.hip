@@ -34,12 +34,15 @@ struct ThreadCtx {
     hipStream_t own_stream  = nullptr;     // staging path
     void*  d_in = nullptr;  size_t in_cap = 0;
     void*  d_out = nullptr; size_t out_cap = 0;
+    void*  d_ws = nullptr;  size_t ws_cap = 0;      // BC7 inter-family workspace
+    hipStream_t ws_stream = nullptr; bool ws_used = false;
     int    device = -1;
     char   info[256] = {0};
     ~ThreadCtx() {
         // best effort; the runtime may already be gone at process exit
         if (d_in)  (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
+        if (d_ws)  (void)hipFree(d_ws);
         if (own_stream) (void)hipStreamDestroy(own_stream);
     }
 };
@@ -53,6 +56,7 @@ void ensure_device_ctx()
         // buffers belong to the device they were allocated on
         if (tls.d_in)  { (void)hipFree(tls.d_in);  tls.d_in = nullptr;  tls.in_cap = 0; }
         if (tls.d_out) { (void)hipFree(tls.d_out); tls.d_out = nullptr; tls.out_cap = 0; }
+        if (tls.d_ws)  { (void)hipFree(tls.d_ws);  tls.d_ws = nullptr;  tls.ws_cap = 0; tls.ws_used = false; }
         if (tls.own_stream) { (void)hipStreamDestroy(tls.own_stream); tls.own_stream = nullptr; }
         tls.device = dev;
     }
@@ -87,12 +91,31 @@ struct Job {
     const bc6h_enc_settings* s6 = nullptr;
 };
 
+// The BC7 workspace is per host thread.  Work already queued on another stream may still be using it, so a change
+// of stream waits for the previous one; calls on one stream are ordered by the stream itself.
+float* bc7_workspace(int w, int h, hipStream_t st)
+{
+    int dev = 0;
+    ITW_CHECK(hipGetDevice(&dev));
+    if (tls.device != dev) {
+        if (tls.d_in)  { (void)hipFree(tls.d_in);  tls.d_in = nullptr;  tls.in_cap = 0; }
+        if (tls.d_out) { (void)hipFree(tls.d_out); tls.d_out = nullptr; tls.out_cap = 0; }
+        if (tls.d_ws)  { (void)hipFree(tls.d_ws);  tls.d_ws = nullptr;  tls.ws_cap = 0; tls.ws_used = false; }
+        if (tls.own_stream) { (void)hipStreamDestroy(tls.own_stream); tls.own_stream = nullptr; }
+        tls.device = dev;
+    }
+    if (tls.ws_used && tls.ws_stream != st) ITW_CHECK(hipStreamSynchronize(tls.ws_stream));
+    float* ws = (float*)grow(tls.d_ws, tls.ws_cap, itw::bc7_workspace_bytes(w, h));
+    tls.ws_stream = st; tls.ws_used = true;
+    return ws;
+}
+
 void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, uint8_t* d_dst, hipStream_t st)
 {
     switch (j.fmt) {
     case Fmt::BC1:  itw::launch_bc1(d_src, stride, w, h, d_dst, st); break;
     case Fmt::BC3:  itw::launch_bc3(d_src, stride, w, h, d_dst, st); break;
-    case Fmt::BC7:  itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, st); break;
+    case Fmt::BC7:  itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st), st); break;
     case Fmt::BC6H: itw::launch_bc6h(d_src, stride, w, h, d_dst, *j.s6, st); break;
     }
     ITW_CHECK(hipGetLastError());

@@ -26,7 +26,7 @@ constexpr float INV65535 = 1.0f / 65535.0f;     // ep/(256*256f-1) under fast-ma
 constexpr float INV31 = 1.0f / 31.0f;
 
 struct HLane {
-    float px[4][16];          // uf16-domain texels (plane 3 unused)
+    TexF tex;                 // uf16-domain texels (plane 3 unused)
     float best_err;
     uint32_t best[4];
     float lo[3], hi[3];       // per-channel bounds
@@ -199,10 +199,10 @@ __device__ __forceinline__ void rank_shapes32(HLane& ln)                        
 {
     if (ln.ranked) return;                          // depends on the block only: once per block
     Stats<3> full;
-    stats_of<3>(full, ln.px, 0xffffu);
+    stats_of<3>(full, ln.tex, 0xffffu);
     for (int part = 0; part < 32; part++) {
         const uint32_t m0 = BCN_SUBSET_MASKS[part] & 0xffffu;
-        const int32_t bound = split_bound<3>(ln.px, m0, full, ln.T);
+        const int32_t bound = split_bound<3>(ln.tex, m0, full, ln.T);
         ln.keys[part * TPB6] = (int32_t)((uint32_t)part + (uint32_t)bound * 64u);
     }
     ln.ranked = true;
@@ -239,11 +239,11 @@ __device__ __forceinline__ void encode_two_region(HLane& ln, int count, int refi
         float ep[3][2][4];
         int32_t q[2][2][4];
         for (int j = 0; j < 2; j++) {
-            fit_subset<3, false>(ep[j], ln.px, subset_mask(sh, j), ln.T);
+            fit_subset<3, false>(ep[j], ln.tex, subset_mask(sh, j), ln.T);
             quant_pair(q[j], ep[j], ln);
         }
         uint32_t qb[2];
-        const float err = select_indices<3, 3, true>(qb, ln.px, ep, sh.pattern);
+        const float err = select_indices<3, 3, true>(qb, ln.tex, ep, sh.pattern);
         if (err < berr) {
             for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = q[j][i][p];
             bqb[0] = qb[0]; bqb[1] = qb[1];
@@ -257,11 +257,11 @@ __device__ __forceinline__ void encode_two_region(HLane& ln, int count, int refi
         float ep[3][2][4];
         int32_t q[2][2][4];
         for (int j = 0; j < 2; j++) {
-            refit_subset<3, 3>(ep[j], ln.px, bqb, subset_mask(sh, j), ln.T);
+            refit_subset<3, 3>(ep[j], ln.tex, bqb, subset_mask(sh, j), ln.T);
             quant_pair(q[j], ep[j], ln);
         }
         uint32_t qb[2];
-        const float err = select_indices<3, 3, true>(qb, ln.px, ep, sh.pattern);
+        const float err = select_indices<3, 3, true>(qb, ln.tex, ep, sh.pattern);
         if (err < berr) {
             for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = q[j][i][p];
             bqb[0] = qb[0]; bqb[1] = qb[1];
@@ -281,13 +281,13 @@ __device__ __forceinline__ void encode_one_region(HLane& ln, int refine)
     float ep[3][2][4];
     int32_t q[2][4];
     uint32_t qb[2];
-    fit_subset<3, false>(ep[0], ln.px, 0xffffu, ln.T);
+    fit_subset<3, false>(ep[0], ln.tex, 0xffffu, ln.T);
     quant_pair(q, ep[0], ln);
-    float err = select_indices<4, 3, true>(qb, ln.px, ep, 0u);
+    float err = select_indices<4, 3, true>(qb, ln.tex, ep, 0u);
     for (int it = 0; it < refine; it++) {
-        refit_subset<4, 3>(ep[0], ln.px, qb, 0xffffu, ln.T);
+        refit_subset<4, 3>(ep[0], ln.tex, qb, 0xffffu, ln.T);
         quant_pair(q, ep[0], ln);
-        err = select_indices<4, 3, true>(qb, ln.px, ep, 0u);
+        err = select_indices<4, 3, true>(qb, ln.tex, ep, 0u);
     }
     if (err < ln.best_err) {
         ln.best_err = err;
@@ -346,10 +346,10 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
         }
 #pragma unroll
         for (int x = 0; x < 4; x++) {
-            ln.px[0][y * 4 + x] = (float)(w[2 * x] & 0xffffu);
-            ln.px[1][y * 4 + x] = (float)(w[2 * x] >> 16);
-            ln.px[2][y * 4 + x] = (float)(w[2 * x + 1] & 0xffffu);
-            ln.px[3][y * 4 + x] = 0.f;
+            ln.tex.v[0][y * 4 + x] = (float)(w[2 * x] & 0xffffu);
+            ln.tex.v[1][y * 4 + x] = (float)(w[2 * x] >> 16);
+            ln.tex.v[2][y * 4 + x] = (float)(w[2 * x + 1] & 0xffffu);
+            ln.tex.v[3][y * 4 + x] = 0.f;
         }
     }
 
@@ -358,8 +358,8 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
     for (int c = 0; c < 3; c++)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const float v = (ln.px[c][k] * INV31) * 64.0f;
-            ln.px[c][k] = v;
+            const float v = (ln.tex.v[c][k] * INV31) * 64.0f;
+            ln.tex.v[c][k] = v;
             ln.lo[c] = fmin_x86(ln.lo[c], v);
             ln.hi[c] = fmax_x86(ln.hi[c], v);
         }

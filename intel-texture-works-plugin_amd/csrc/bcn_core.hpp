@@ -40,6 +40,34 @@ __device__ __forceinline__ uint32_t subset_mask(const Shape& s, int j)
     return (j == 0) ? m0 : ((j == 1) ? m1 : (~m0 & ~m1 & 0xffffu));
 }
 
+// ---- texel storage ------------------------------------------------------------
+// TexF : planar floats (BC6H: uf16-domain values).  TexU8: the block as loaded, 16 packed RGBA8 words; a channel
+// value is one v_cvt_f32_ubyteN at the point of use -- 16 VGPRs instead of 64 for the whole search.
+struct TexF {
+    float v[4][16];
+    __device__ __forceinline__ float get(int p, int k) const { return v[p][k]; }
+    __device__ __forceinline__ void fence()
+    {
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("" : "+v"(v[p][k]));
+    }
+};
+struct TexU8 {
+    uint32_t w[16];
+    __device__ __forceinline__ float get(int p, int k) const { return (float)((w[k] >> (8 * p)) & 255u); }
+    // Compiler fence for candidate loops: everything derived from the texels (conversions, products r*r, r*g ...)
+    // is loop invariant, and LICM would hoist ~200 such values out of the shape loop and keep them in registers
+    // (or spill them).  Declaring the words "modified" at the top of an iteration keeps the working set at the
+    // 16 packed words; no instruction is emitted.
+    __device__ __forceinline__ void fence()
+    {
+#pragma unroll
+        for (int k = 0; k < 16; k++) asm volatile("" : "+v"(w[k]));
+    }
+};
+
 // ---- second-moment statistics of a subset (kernel.ispc:763-803) -------------
 template <int CH>
 struct Stats {
@@ -48,23 +76,25 @@ struct Stats {
     float n;       // texel count
 };
 
-template <int CH>
-__device__ __forceinline__ void stats_of(Stats<CH>& st, const float (&px)[4][16], uint32_t mask)
+template <int CH, class TX>
+__device__ __forceinline__ void stats_of(Stats<CH>& st, const TX& px, uint32_t mask)
 {
+    #pragma unroll
     for (int i = 0; i < 10; i++) st.m[i] = 0.f;
+    #pragma unroll
     for (int i = 0; i < 4; i++) st.s[i] = 0.f;
     st.n = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         if ((mask >> k) & 1u) {
-            const float r = px[0][k], g = px[1][k], b = px[2][k];
+            const float r = px.get(0, k), g = px.get(1, k), b = px.get(2, k);
             st.n += 1.0f;
             st.s[0] += r; st.s[1] += g; st.s[2] += b;
             st.m[0] += r * r; st.m[1] += r * g; st.m[2] += r * b;
             st.m[4] += g * g; st.m[5] += g * b;
             st.m[7] += b * b;
             if (CH == 4) {
-                const float a = px[3][k];
+                const float a = px.get(3, k);
                 st.s[3] += a;
                 st.m[3] += r * a; st.m[6] += g * a; st.m[8] += b * a; st.m[9] += a * a;
             }
@@ -111,11 +141,14 @@ __device__ __forceinline__ void principal_axis(float (&v)[4], const float (&cv)[
             a[2] = cv[2] * v[0] + cv[5] * v[1] + cv[7] * v[2] + cv[8] * v[3];
             a[3] = cv[3] * v[0] + cv[6] * v[1] + cv[8] * v[2] + cv[9] * v[3];
         }
+        #pragma unroll
         for (int p = 0; p < CH; p++) v[p] = a[p];
         if (it & 1) {
             float nsq = 0.f;
+            #pragma unroll
             for (int p = 0; p < CH; p++) nsq += a[p] * a[p];
             const float rn = ispc_rsqrt(nsq, T);
+            #pragma unroll
             for (int p = 0; p < CH; p++) v[p] *= rn;
         }
     }
@@ -124,18 +157,18 @@ __device__ __forceinline__ void principal_axis(float (&v)[4], const float (&cv)[
 // PCA line fit of one subset: endpoints = mean + extreme projections * axis.
 // CLAMP255: BC7 clamps to [0,255] (kernel.ispc:896-905); BC6H keeps the raw fit (857-894).
 // ep[0][p] / ep[1][p]: low / high endpoint.  Slots p >= CH are left untouched.
-template <int CH, bool CLAMP255>
-__device__ __forceinline__ void fit_subset(float (&ep)[2][4], const float (&px)[4][16], uint32_t mask, const SeedTables& T)
+template <int CH, bool CLAMP255, class TX>
+__device__ __forceinline__ void fit_from_stats(float (&ep)[2][4], const TX& px, uint32_t mask, const Stats<CH>& st, const SeedTables& T)
 {
-    Stats<CH> st;
-    stats_of<CH>(st, px, mask);
     const float rn = ispc_rcp(st.n, T);
     float cv[10];
     covariance_of<CH>(cv, st, rn);
     float dc[4];
+    #pragma unroll
     for (int p = 0; p < CH; p++) dc[p] = st.s[p] * rn;
 
     const float inv_var = 1.0f / 65536.0f;
+    #pragma unroll
     for (int i = 0; i < 10; i++) cv[i] *= inv_var;
     const float eps = 0.001f * 0.001f;
     cv[0] += eps; cv[4] += eps; cv[7] += eps; cv[9] += eps;
@@ -148,12 +181,14 @@ __device__ __forceinline__ void fit_subset(float (&ep)[2][4], const float (&px)[
     for (int k = 0; k < 16; k++) {
         if ((mask >> k) & 1u) {
             float dot = 0.f;
-            for (int p = 0; p < CH; p++) dot += axis[p] * (px[p][k] - dc[p]);
+            #pragma unroll
+            for (int p = 0; p < CH; p++) dot += axis[p] * (px.get(p, k) - dc[p]);
             lo = fmin_x86(lo, dot);
             hi = fmax_x86(hi, dot);
         }
     }
     if (hi - lo < 1.0f) { lo -= 0.5f; hi += 0.5f; }
+    #pragma unroll
     for (int p = 0; p < CH; p++) {
         float a = lo * axis[p] + dc[p], b = hi * axis[p] + dc[p];
         if (CLAMP255) { a = fclamp_x86(a, 0.f, 255.f); b = fclamp_x86(b, 0.f, 255.f); }
@@ -161,11 +196,20 @@ __device__ __forceinline__ void fit_subset(float (&ep)[2][4], const float (&px)[
     }
 }
 
+template <int CH, bool CLAMP255, class TX>
+__device__ __forceinline__ void fit_subset(float (&ep)[2][4], const TX& px, uint32_t mask, const SeedTables& T)
+{
+    Stats<CH> st;
+    stats_of<CH>(st, px, mask);
+    fit_from_stats<CH, CLAMP255>(ep, px, mask, st, T);
+}
+
 // trace - largest eigenvalue (4 power iterations) of a scaled covariance.   (kernel.ispc:907-939)
 template <int CH>
 __device__ __forceinline__ float pca_residual(float (&cv)[10], const SeedTables& T)
 {
     const float inv_var = 1.0f / 65536.0f;
+    #pragma unroll
     for (int i = 0; i < 10; i++) cv[i] *= inv_var;
     const float eps = 0.001f * 0.001f;
     cv[0] += eps; cv[4] += eps; cv[7] += eps;           // not cv[9]: reference quirk
@@ -183,6 +227,7 @@ __device__ __forceinline__ float pca_residual(float (&cv)[10], const SeedTables&
         w[3] = cv[3] * axis[0] + cv[6] * axis[1] + cv[8] * axis[2] + cv[9] * axis[3];
     }
     float sq_sum = 0.f;
+    #pragma unroll
     for (int p = 0; p < CH; p++) sq_sum += sq(w[p]);
     const float lambda = sqrtf(sq_sum);
     float bound = cv[0] + cv[4] + cv[7];
@@ -194,14 +239,14 @@ __device__ __forceinline__ float pca_residual(float (&cv)[10], const SeedTables&
 // Lower bound on the two-subset error of a shape, as an integer sort key component:
 // (int)(sqrt(res(subset0) + res(rest)) * 256), rest = full - subset0.   (kernel.ispc:952-971, 1404-1409)
 template <int CH>
-__device__ __forceinline__ int32_t split_bound(const float (&px)[4][16], uint32_t mask0, const Stats<CH>& full, const SeedTables& T)
+__device__ __forceinline__ int32_t split_bound_from(const Stats<CH>& a, const Stats<CH>& full, const SeedTables& T)
 {
-    Stats<CH> a;
-    stats_of<CH>(a, px, mask0);
     float cv1[10], cv2[10];
     covariance_of<CH>(cv1, a, ispc_rcp(a.n, T));
     Stats<CH> b;
+    #pragma unroll
     for (int i = 0; i < 10; i++) b.m[i] = full.m[i] - a.m[i];
+    #pragma unroll
     for (int i = 0; i < 4; i++) b.s[i] = full.s[i] - a.s[i];
     b.n = full.n - a.n;
     covariance_of<CH>(cv2, b, ispc_rcp(b.n, T));
@@ -209,6 +254,14 @@ __device__ __forceinline__ int32_t split_bound(const float (&px)[4][16], uint32_
     bound += pca_residual<CH>(cv1, T);
     bound += pca_residual<CH>(cv2, T);
     return f2i_x86(sqrtf(bound) * 256.0f);
+}
+
+template <int CH, class TX>
+__device__ __forceinline__ int32_t split_bound(const TX& px, uint32_t mask0, const Stats<CH>& full, const SeedTables& T)
+{
+    Stats<CH> a;
+    stats_of<CH>(a, px, mask0);
+    return split_bound_from<CH>(a, full, T);
 }
 
 // ---- index selection (kernel.ispc:1133-1193) -------------------------------
@@ -223,8 +276,8 @@ __device__ __forceinline__ int32_t weight_of(int32_t q)
 // For every texel: project on its subset's segment, try the two neighbouring indices, keep the better.
 // Returns the summed (integer-truncated) squared error; indices packed 4 bits/texel into qb[2].
 // HDR selects cvttps2dq semantics for the error truncation (BC6H errors overflow int; BC7's cannot).
-template <int BITS, int CH, bool HDR>
-__device__ __forceinline__ float select_indices(uint32_t (&qb)[2], const float (&px)[4][16], const float (&ep)[3][2][4], uint32_t pattern)
+template <int BITS, int CH, bool HDR, class TX>
+__device__ __forceinline__ float select_indices(uint32_t (&qb)[2], const TX& px, const float (&ep)[3][2][4], uint32_t pattern)
 {
     constexpr int LEVELS = 1 << BITS;
     float total = 0.f;
@@ -233,13 +286,18 @@ __device__ __forceinline__ float select_indices(uint32_t (&qb)[2], const float (
     for (int k = 0; k < 16; k++) {
         const uint32_t j = (pattern >> (2 * k)) & 3u;
         float a[CH], b[CH];
+        #pragma unroll
         for (int p = 0; p < CH; p++) {
             a[p] = (j == 0) ? ep[0][0][p] : ((j == 1) ? ep[1][0][p] : ep[2][0][p]);
             b[p] = (j == 0) ? ep[0][1][p] : ((j == 1) ? ep[1][1][p] : ep[2][1][p]);
         }
+        float t[CH];
+        #pragma unroll
+        for (int p = 0; p < CH; p++) t[p] = px.get(p, k);
         float proj = 0.f, div = 0.f;
+        #pragma unroll
         for (int p = 0; p < CH; p++) {
-            proj += (px[p][k] - a[p]) * (b[p] - a[p]);
+            proj += (t[p] - a[p]) * (b[p] - a[p]);
             div += sq(b[p] - a[p]);
         }
         proj = proj / div;                                   // IEEE divide (compound `/=` in the reference)
@@ -248,11 +306,12 @@ __device__ __forceinline__ float select_indices(uint32_t (&qb)[2], const float (
         const float w0 = (float)weight_of<BITS>(q1 - 1), w1 = (float)weight_of<BITS>(q1);
         const float u0 = 64.0f - w0, u1 = 64.0f - w1;       // (64-w) is exact in int and in float
         float err0 = 0.f, err1 = 0.f;
+        #pragma unroll
         for (int p = 0; p < CH; p++) {
             const float d0 = (float)f2i_x86((u0 * a[p] + w0 * b[p] + 32.0f) * 0.015625f);
             const float d1 = (float)f2i_x86((u1 * a[p] + w1 * b[p] + 32.0f) * 0.015625f);
-            err0 += sq(d0 - px[p][k]);
-            err1 += sq(d1 - px[p][k]);
+            err0 += sq(d0 - t[p]);
+            err1 += sq(d1 - t[p]);
         }
         const bool first = err0 < err1;
         const float e = first ? err0 : err1;
@@ -265,8 +324,8 @@ __device__ __forceinline__ float select_indices(uint32_t (&qb)[2], const float (
 }
 
 // ---- least-squares endpoints for fixed indices (kernel.ispc:1198-1262) ------
-template <int BITS, int CH>
-__device__ __forceinline__ void refit_subset(float (&ep)[2][4], const float (&px)[4][16], const uint32_t (&qb)[2], uint32_t mask, const SeedTables& T)
+template <int BITS, int CH, class TX>
+__device__ __forceinline__ void refit_subset(float (&ep)[2][4], const TX& px, const uint32_t (&qb)[2], uint32_t mask, const SeedTables& T)
 {
     constexpr float L1 = (float)((1 << BITS) - 1);
     float atb1[4] = {0.f, 0.f, 0.f, 0.f}, sum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -279,8 +338,8 @@ __device__ __forceinline__ void refit_subset(float (&ep)[2][4], const float (&px
             sum_q += q;
             sum_qq += q * q;
             cnt += 1.0f;
-            for (int p = 0; p < CH; p++) sum[p] += px[p][k];
-            for (int p = 0; p < CH; p++) atb1[p] += x * px[p][k];
+            #pragma unroll
+            for (int p = 0; p < CH; p++) { const float t = px.get(p, k); sum[p] += t; atb1[p] += x * t; }
         }
     }
     const float cxx = cnt * (L1 * L1) - (2.0f * L1) * sum_q + sum_qq;
@@ -290,6 +349,7 @@ __device__ __forceinline__ void refit_subset(float (&ep)[2][4], const float (&px
     const float scale = L1 * ispc_rcp(det, T);
     const bool flat = fabsf(det) < 0.001f;
     const float rcnt = ispc_rcp(cnt, T);
+    #pragma unroll
     for (int p = 0; p < CH; p++) {
         const float atb2 = L1 * sum[p] - atb1[p];
         const float e0 = (atb1[p] * cyy - atb2 * cxy) * scale;
