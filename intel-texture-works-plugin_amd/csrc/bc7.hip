@@ -6,40 +6,44 @@
 // least-squares refinement of each mode's winner, modes 0-7 -- organised for a
 // SIMT machine instead of an SPMD gang:
 //
-//   * one 4x4 block per lane; the block stays in 16 VGPRs as loaded (packed RGBA8,
-//     one v_cvt_f32_ubyteN per use); it is read from HBM with 4 coalesced dwordx4
-//     loads per lane and 16 B are written per lane;
+//   * one 4x4 block per lane, read from HBM with 4 coalesced dwordx4 loads per lane,
+//     16 B written per lane.  The block lives in 16 VGPRs as loaded plus 16 VGPRs of
+//     planar bytes (bc7_exact.hpp);
+//   * everything the reference computes in fp32 that cannot round (texels and decoded
+//     endpoints are integers <= 255) runs on the packed integer units: subset moment
+//     sums are masked v_dot4_u32_u8 chains, index selection is v_dot2_i32_i16 /
+//     v_pk_mad_i16 arithmetic with an exactly rounded quotient, least-squares sums are
+//     dot4 chains (proofs in bc7_exact.hpp).  What can round (PCA, endpoint
+//     quantisation, the 2x2 solve) is fp32 with the pinned x86 arithmetic;
 //   * one kernel per mode family ({0,2} {1,3} {7} {4,5,6}), run in the reference's
-//     order.  The families only communicate through "best error so far"
-//     (kernel.ispc:1358, 1638, 1684), which travels in a 4 B/block workspace; a later
-//     family overwrites the block only where it wins.  Each family gets its own
-//     register allocation and instruction footprint instead of the worst case of all;
-//   * shapes are visited in TABLE order wherever the candidate list is the whole
-//     table (modes 0/2 always; modes 1/3/7 when their fastSkipTreshold is >= 64, i.e.
-//     the `slow` profiles): the shape then lives in SGPRs, subset membership is a
-//     scalar branch, and a texel costs work only in the subset it belongs to.  The
-//     reference scans its PCA-ranked list with a strict `<`, so among equal errors
-//     the lowest rank wins; visiting in table order and breaking error ties by the
-//     rank key (part + 64*bound, distinct per shape) selects the same winner;
+//     order.  Families only communicate through "best error so far" (kernel.ispc:1358,
+//     1638, 1684), which travels in a 4 B/block workspace;
+//   * shapes are visited in TABLE order wherever the candidate list is the whole table
+//     (modes 0/2 always; modes 1/3/7 when their fastSkipTreshold is >= 64, the `slow`
+//     profiles): the shape is wave-uniform, its subset masks are scalars, a texel costs
+//     work only in the subset it belongs to (scalar branches), and the loop over subsets
+//     is rolled so every code path exists once.  The reference scans its PCA-ranked
+//     list with a strict `<`, i.e. among equal errors the lowest rank key wins; here the
+//     rank key (part + 64*bound) is only evaluated when two shapes actually tie;
 //   * shorter ranked lists (fast profiles) keep the per-lane order: the i-th entry of
 //     the reference's selection sort (kernel.ispc:1365-1384) is the smallest key above
 //     the previous one -- a 64-entry LDS scan, no sort, no dynamic register indexing;
 //   * fits that do not depend on the mode are shared: shapes 64..79 serve modes 0 and
-//     2, every two-subset shape serves modes 1 and 3 (kernel.ispc:1286-1291), and the
-//     subset-0 statistics serve both the rank bound and the fit;
-//   * during the search only (indices, error, shape, key) of a mode's winner are kept;
-//     its endpoint codes are recomputed (deterministically) at commit time.
+//     2, every two-subset shape serves modes 1 and 3 (kernel.ispc:1286-1291), the last
+//     subset's moments are the block's minus the others' (exact), one rotation's fit
+//     serves its three mode 4/5 candidates;
+//   * the RCPPS/RSQRTPS seed tables are staged in LDS once per workgroup.
 //
-// fp32 VALU bound (GetProfile_slow: ~1e6 separately rounded ops per block against 80
-// algorithmic bytes); nothing GEMM shaped, so no MFMA.  Bit-exactness with the oracle
-// forbids FMA contraction and any re-association of per-subset float sums.
-#include "bcn_core.hpp"
+// VALU bound; nothing GEMM shaped, so no MFMA.  Bit-exactness with the oracle forbids
+// FMA contraction and any re-association of sums that can round.
+#include "bc7_exact.hpp"
 #include "kernels.hpp"
 
 namespace itw {
 
-constexpr int TPB = 64;                   // one wave per workgroup
+constexpr int TPB = 256;                  // four waves share one staged seed table
 constexpr float INV255 = 1.0f / 255.0f;   // x/255f under fast-math = x*(1.f/255.f)
+constexpr int32_t ERR_MAX = 0x7fffffff;
 
 struct ModeTraits { int pairs, bits, ch; };
 __device__ __forceinline__ constexpr ModeTraits traits(int mode)
@@ -54,11 +58,19 @@ __device__ __forceinline__ int32_t expand_to_byte(int32_t v, int bits)        //
     return vv + (int32_t)((uint32_t)vv >> bits);
 }
 
-// ---- endpoint quantisers: quantise, then overwrite the floats with what a decoder reconstructs ----
+// float -> int of the reference (cvttps2dq).  SAFE: the caller guarantees a finite value inside the int range
+// (search-time endpoints are clamped to [0,255] by the fit), so the plain conversion gives the same result.
+template <bool SAFE>
+__device__ __forceinline__ int32_t f2i(float f) { return SAFE ? (int32_t)f : f2i_x86(f); }
+
+// ---- endpoint quantisers --------------------------------------------------------------------------
+// in : e[i][p]  fitted endpoint i, channel p (fp32)
+// out: q[i][p]  code as stored in the block (incl. p-bit in bit 0 where the mode has one)
+//      d[i][p]  what a decoder reconstructs from it (the reference overwrites e with this; kernel.ispc:1100-1128)
 
 // modes 0,3,6,7: one p-bit per endpoint, chosen by squared error over `err_ch` channels.  [kernel.ispc:983-1022]
-template <int MODE>
-__device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], float (&e)[2][4], int err_ch)
+template <int MODE, bool SAFE>
+__device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4], const float (&e)[2][4], int err_ch)
 {
     constexpr int BITS = (MODE == 0) ? 4 : (MODE == 7) ? 5 : 7;
     constexpr int L2 = (1 << BITS) * 2 - 1;
@@ -70,8 +82,8 @@ __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], float (&e)[2][4],
         for (int b = 0; b < 2; b++)
             #pragma unroll
             for (int p = 0; p < 4; p++) {
-                const int32_t v = f2i_x86((e[i][p] * INV255 * (float)L2 - (float)b) * 0.5f + 0.5f) * 2 + b;
-                qb[b][p] = iclamp(v, b, L2 - 1 + b);
+                const uint32_t v = (uint32_t)f2i<SAFE>((e[i][p] * INV255 * (float)L2 - (float)b) * 0.5f + 0.5f) * 2u + (uint32_t)b;
+                qb[b][p] = iclamp((int32_t)v, b, L2 - 1 + b);
                 // mode 0 compares in 8-bit space; modes 3/6 codes are 8-bit; mode 7 compares raw 6-bit codes
                 // against 8-bit targets (reference quirk, kernel.ispc:1003-1017)
                 db[b][p] = (float)((MODE == 0) ? expand_to_byte(qb[b][p], 5) : qb[b][p]);
@@ -84,13 +96,14 @@ __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], float (&e)[2][4],
         #pragma unroll
         for (int p = 0; p < 4; p++) {
             q[i][p] = first ? qb[0][p] : qb[1][p];
-            e[i][p] = (float)((MODE == 0) ? expand_to_byte(q[i][p], 5) : (MODE == 7) ? expand_to_byte(q[i][p], 6) : q[i][p]);
+            d[i][p] = (MODE == 0) ? expand_to_byte(q[i][p], 5) : (MODE == 7) ? expand_to_byte(q[i][p], 6) : q[i][p];
         }
     }
 }
 
 // mode 1: one p-bit shared by both endpoints of a subset, RGB error.            [kernel.ispc:1024-1052]
-__device__ __forceinline__ void quant_shared_pbit(int32_t (&q)[2][4], float (&e)[2][4])
+template <bool SAFE>
+__device__ __forceinline__ void quant_shared_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4], const float (&e)[2][4])
 {
     int32_t qb[2][2][4];
     float db[2][2][4];
@@ -100,8 +113,8 @@ __device__ __forceinline__ void quant_shared_pbit(int32_t (&q)[2][4], float (&e)
         for (int i = 0; i < 2; i++)
             #pragma unroll
             for (int p = 0; p < 4; p++) {
-                const int32_t v = f2i_x86((e[i][p] * INV255 * 127.0f - (float)b) * 0.5f + 0.5f) * 2 + b;
-                qb[b][i][p] = iclamp(v, b, 126 + b);
+                const uint32_t v = (uint32_t)f2i<SAFE>((e[i][p] * INV255 * 127.0f - (float)b) * 0.5f + 0.5f) * 2u + (uint32_t)b;
+                qb[b][i][p] = iclamp((int32_t)v, b, 126 + b);
                 db[b][i][p] = (float)expand_to_byte(qb[b][i][p], 7);
             }
     float err0 = 0.f, err1 = 0.f;
@@ -115,38 +128,40 @@ __device__ __forceinline__ void quant_shared_pbit(int32_t (&q)[2][4], float (&e)
         #pragma unroll
         for (int p = 0; p < 4; p++) {
             q[i][p] = first ? qb[0][i][p] : qb[1][i][p];
-            e[i][p] = (float)expand_to_byte(q[i][p], 7);
+            d[i][p] = expand_to_byte(q[i][p], 7);
         }
 }
 
 // modes 2,4 (5 bits) and 5 (7 bits): plain rounding.                            [kernel.ispc:1054-1065]
-template <int BITS>
-__device__ __forceinline__ void quant_plain(int32_t (&q)[2][4], float (&e)[2][4])
+template <int BITS, bool SAFE>
+__device__ __forceinline__ void quant_plain(int32_t (&q)[2][4], int32_t (&d)[2][4], const float (&e)[2][4])
 {
     constexpr int L = 1 << BITS;
     #pragma unroll
     for (int i = 0; i < 2; i++)
         #pragma unroll
         for (int p = 0; p < 4; p++) {
-            q[i][p] = iclamp(f2i_x86(e[i][p] * INV255 * (float)(L - 1) + 0.5f), 0, L - 1);
-            e[i][p] = (float)expand_to_byte(q[i][p], BITS);
+            q[i][p] = iclamp(f2i<SAFE>(e[i][p] * INV255 * (float)(L - 1) + 0.5f), 0, L - 1);
+            d[i][p] = expand_to_byte(q[i][p], BITS);
         }
 }
 
-template <int MODE>
-__device__ __forceinline__ void quant_mode(int32_t (&q)[2][4], float (&e)[2][4], int err_ch)
+template <int MODE, bool SAFE>
+__device__ __forceinline__ void quant_mode(int32_t (&q)[2][4], int32_t (&d)[2][4], const float (&e)[2][4], int err_ch)
 {
-    if (MODE == 0 || MODE == 3 || MODE == 6 || MODE == 7) quant_pbit<MODE>(q, e, err_ch);
-    else if (MODE == 1) quant_shared_pbit(q, e);
-    else if (MODE == 2 || MODE == 4) quant_plain<5>(q, e);
-    else quant_plain<7>(q, e);
+    if (MODE == 0 || MODE == 3 || MODE == 6 || MODE == 7) quant_pbit<MODE, SAFE>(q, d, e, err_ch);
+    else if (MODE == 1) quant_shared_pbit<SAFE>(q, d, e);
+    else if (MODE == 2 || MODE == 4) quant_plain<5, SAFE>(q, d, e);
+    else quant_plain<7, SAFE>(q, d, e);
 }
 
 // ---- per-lane state ---------------------------------------------------------------------------
+// All BC7 block errors are exact integers below 2^24 in the reference's float arithmetic (sums of per-texel
+// `(int)err`, plus the integer opaque_err), so they are carried as int32 here; +inf is ERR_MAX.
 struct Lane {
-    TexU8 tex;
-    float best_err;
-    float opaque_err;
+    Tex tx;
+    int32_t best_err;
+    int32_t opaque_err;
     uint32_t best[4];
     bool improved;
     SeedTables T;
@@ -155,17 +170,17 @@ struct Lane {
 
 struct Win {                  // winner of one multi-subset mode during the search
     uint32_t qb[2];
-    float err;
+    int32_t err;
     int32_t shape;            // table index 0..63 (two subsets) / 64..127 (three)
-    int32_t key;              // rank key of the shape (tie-break in table-order scans)
+    int32_t key;              // rank key of `shape`; < 0 = not evaluated yet (table-order scans)
 };
 
 __device__ __forceinline__ void reset(Win& w, int shape0)
 {
     w.qb[0] = w.qb[1] = 0u;
-    w.err = __builtin_inff();
+    w.err = ERR_MAX;
     w.shape = shape0;
-    w.key = 0x7fffffff;
+    w.key = -1;
 }
 
 __device__ __forceinline__ void store_bits(uint32_t (&out)[4], const BlockBits& bb)
@@ -332,61 +347,64 @@ __device__ __forceinline__ void emit_mode6(uint32_t (&out)[4], int32_t (&q)[2][4
 
 // ---- multi-subset modes ---------------------------------------------------------------------
 
-// Quantise a fitted shape for MODE and pick indices.  Keeps the candidate if its error is lower, or equal
-// with a lower rank key: in a table-order scan that is the candidate the reference's ranked, strict-`<`
-// scan keeps; in a ranked scan keys increase, so the second clause never fires.   [kernel.ispc:1279-1327]
-template <int MODE>
-__device__ __forceinline__ void try_shape(Win& best, const Lane& ln, const float (&fit)[3][2][4], const Shape& sh, int shape_index, int32_t key)
+// Rank key of a two-subset shape: shape + 64 * (int)(sqrt(residual bound) * 256).   [kernel.ispc:952-971, 1404-1409]
+// `shape` may differ per lane (table loads are then per lane).
+template <int RANK_CH>
+__device__ __forceinline__ int32_t rank_key(int shape, const Tex& tx, const Stats<RANK_CH>& full, const SeedTables& T)
 {
-    constexpr ModeTraits M = traits(MODE);
-    float ep[3][2][4];
-    #pragma unroll
-    for (int j = 0; j < M.pairs; j++) {
-        int32_t q[2][4];
-        #pragma unroll
-        for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) ep[j][i][p] = fit[j][i][p];
-        quant_mode<MODE>(q, ep[j], M.ch);
-    }
-    uint32_t qb[2];
-    const float err = select_indices<M.bits, M.ch, false>(qb, ln.tex, ep, sh.pattern);
-    if (err < best.err || (err == best.err && key < best.key)) {
-        best.qb[0] = qb[0]; best.qb[1] = qb[1];
-        best.err = err;
-        best.shape = shape_index;
-        best.key = key;
-    }
+    const SubsetMask sm = subset_of(shape, 0);
+    IStats<RANK_CH> s0;
+    stats_int<RANK_CH>(s0, tx.pl, sm);
+    Stats<RANK_CH> f0;
+    stats_float<RANK_CH>(f0, s0);
+    return (int32_t)((uint32_t)shape + (uint32_t)split_bound_from<RANK_CH>(f0, full, T) * 64u);
 }
 
 // Least-squares refinement of a mode's winner, then the mode competes for the block.  [kernel.ispc:1329-1362]
+// The winner's shape differs per lane: masks come from per-lane table loads, segments are chosen per texel.
 template <int MODE>
 __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iterations, int settings_channels)
 {
     constexpr ModeTraits M = traits(MODE);
     const Shape sh = load_shape(w.shape);
+    SubsetMask sm[3];
+    #pragma unroll
+    for (int j = 0; j < M.pairs; j++) sm[j] = subset_of(w.shape, j);
     // endpoint codes of the search-time winner: refit + quantise its shape again (same inputs, same bits)
     int32_t cq[3][2][4];
-    {
-        float ep[3][2][4];
+    #pragma unroll
+    for (int j = 0; j < 3; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) cq[j][i][p] = 0;
+    #pragma unroll 1
+    for (int j = 0; j < M.pairs; j++) {
+        const SubsetMask s = (j == 0) ? sm[0] : ((j == 1) ? sm[1] : sm[2]);
+        IStats<M.ch> st;
+        stats_int<M.ch>(st, ln.tx.pl, s);
+        float ep[2][4];
+        ep[0][3] = 0.f; ep[1][3] = 0.f;
+        fit_line<M.ch>(ep, ln.tx, s.bits, st, ispc_rcp((float)s.n, ln.T), ln.T);
+        int32_t q[2][4], d[2][4];
+        quant_mode<MODE, true>(q, d, ep, M.ch);
         #pragma unroll
-        for (int j = 0; j < M.pairs; j++) {
-            ep[j][0][3] = 0.f; ep[j][1][3] = 0.f;
-            fit_subset<M.ch, true>(ep[j], ln.tex, subset_mask(sh, j), ln.T);
-            quant_mode<MODE>(cq[j], ep[j], M.ch);
+        for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) {
+            if (j == 0) cq[0][i][p] = q[i][p]; else if (j == 1) cq[1][i][p] = q[i][p]; else cq[2][i][p] = q[i][p];
         }
-        if (M.pairs == 2) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) cq[2][i][p] = 0;
     }
     for (int it = 0; it < iterations; it++) {
-        ln.tex.fence();
-        float ep[3][2][4];
+        ln.tx.fence();
         int32_t q[3][2][4];
+        Segment sg[3];
         #pragma unroll
         for (int j = 0; j < M.pairs; j++) {
-            ep[j][0][3] = 0.f; ep[j][1][3] = 0.f;
-            refit_subset<M.bits, M.ch>(ep[j], ln.tex, w.qb, subset_mask(sh, j), ln.T);
-            quant_mode<MODE>(q[j], ep[j], settings_channels);          // :1343 passes the profile's channel count
+            float ep[2][4];
+            int32_t d[2][4];
+            ep[0][3] = 0.f; ep[1][3] = 0.f;
+            refit_line<M.bits, M.ch>(ep, ln.tx.pl, w.qb, sm[j], ln.T);
+            quant_mode<MODE, false>(q[j], d, ep, settings_channels);       // :1343 passes the profile's channel count
+            sg[j] = make_segment<M.ch>(d);
         }
+        if (M.pairs == 2) sg[2] = sg[1];
         uint32_t qb[2];
-        const float err = select_indices<M.bits, M.ch, false>(qb, ln.tex, ep, sh.pattern);
+        const int32_t err = select_block<M.bits, M.ch, M.pairs>(qb, ln.tx, sg, sh.pattern);
         if (err < w.err) {
             #pragma unroll
             for (int j = 0; j < M.pairs; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) cq[j][i][p] = q[j][i][p];
@@ -394,7 +412,7 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
             w.err = err;
         }
     }
-    float err = w.err;
+    int32_t err = w.err;
     if (MODE != 7) err += ln.opaque_err;
     if (err < ln.best_err) {
         ln.best_err = err;
@@ -403,24 +421,48 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
     }
 }
 
-// modes 0 and 2: three subsets; shapes in table order (wave-uniform), one fit per shape.  [kernel.ispc:1386-1394]
+__device__ __forceinline__ void take(Win& w, int32_t err, const uint32_t (&qb)[2], int shape, int32_t key)
+{
+    w.qb[0] = qb[0]; w.qb[1] = qb[1];
+    w.err = err; w.shape = shape; w.key = key;
+}
+
+// modes 0 and 2: three subsets; shapes in table order (wave-uniform), one fit per subset.  [kernel.ispc:1386-1394]
+// List order == table order, so the reference's strict `<` is reproduced by a strict `<`.
 __device__ __forceinline__ void modes_02(Lane& ln, const bc7_enc_settings& S)
 {
     Win b0, b2;
     reset(b0, 64); reset(b2, 64);
+    IStats<3> full;
+    stats_int<3>(full, ln.tx.pl, whole_block());
     const int count = S.skip_mode2 ? 16 : 64;
     for (int part = 0; part < count; part++) {
-        ln.tex.fence();
-        const Shape sh = load_shape(64 + part);
-        float fit[3][2][4];
-        #pragma unroll
+        ln.tx.fence();
+        const bool do0 = part < 16, do2 = !S.skip_mode2;
+        uint32_t q0[2] = {0u, 0u}, q2[2] = {0u, 0u};
+        int32_t e0 = 0, e2 = 0;
+        IStats<3> rest = full;
+        #pragma unroll 1
         for (int j = 0; j < 3; j++) {
-            fit_subset<3, true>(fit[j], ln.tex, subset_mask(sh, j), ln.T);
-            fit[j][0][3] = 0.f; fit[j][1][3] = 0.f;      // the reference's unwritten alpha slots, pinned to 0
+            const SubsetMask sm = subset_of(64 + part, j);
+            IStats<3> st;
+            if (j < 2) stats_int<3>(st, ln.tx.pl, sm); else st = rest;
+            stats_sub<3>(rest, st);
+            float fit[2][4];
+            fit[0][3] = 0.f; fit[1][3] = 0.f;            // the reference's unwritten alpha slots, pinned to 0
+            fit_line<3>(fit, ln.tx, sm.bits, st, rcp_of_count(sm.n), ln.T);
+            int32_t q[2][4], d[2][4];
+            if (do0) {
+                quant_mode<0, true>(q, d, fit, 3);
+                select_subset<3, 3>(q0, e0, ln.tx, make_segment<3>(d), sm.bits);
+            }
+            if (do2) {
+                quant_mode<2, true>(q, d, fit, 3);
+                select_subset<2, 3>(q2, e2, ln.tx, make_segment<3>(d), sm.bits);
+            }
         }
-        // list order == table order here: key = position
-        if (part < 16) try_shape<0>(b0, ln, fit, sh, 64 + part, part);
-        if (!S.skip_mode2) try_shape<2>(b2, ln, fit, sh, 64 + part, part);
+        if (do0 && e0 < b0.err) take(b0, e0, q0, 64 + part, part);
+        if (do2 && e2 < b2.err) take(b2, e2, q2, 64 + part, part);
     }
     refine_and_commit<0>(ln, b0, S.refineIterations[0], S.channels);
     if (!S.skip_mode2) refine_and_commit<2>(ln, b2, S.refineIterations[2], S.channels);
@@ -438,43 +480,77 @@ __device__ __forceinline__ void two_subset_modes(Lane& ln, const bc7_enc_setting
     Win wa, wb;
     reset(wa, 0); reset(wb, 0);
 
-    Stats<RANK_CH> full;
-    stats_of<RANK_CH>(full, ln.tex, 0xffffu);
+    IStats<FIT_CH> full;
+    stats_int<FIT_CH>(full, ln.tx.pl, whole_block());
+    Stats<RANK_CH> rfull;                                 // the ranking's view of the block (first RANK_CH channels)
+    {
+        IStats<RANK_CH> t;
+        #pragma unroll
+        for (int i = 0; i < 10; i++) t.m[i] = full.m[i];
+        #pragma unroll
+        for (int i = 0; i < 4; i++) t.s[i] = full.s[i];
+        t.n = 16;
+        stats_float<RANK_CH>(rfull, t);
+    }
 
     const bool whole_table = (na <= 0 || na >= 64) && (nb <= 0 || nb >= 64);
     if (whole_table) {
-        // every shape is a candidate: table order, rank key only breaks ties
+        // every shape is a candidate: table order; the rank key is only needed to order shapes of equal error
         for (int part = 0; part < 64; part++) {
-            ln.tex.fence();
-            const Shape sh = load_shape(part);
-            const uint32_t m0 = sh.masks & 0xffffu, m1 = sh.masks >> 16;
-            float fit[3][2][4];
-            int32_t key;
-            if constexpr (RANK_CH == FIT_CH) {
-                Stats<FIT_CH> s0;
-                stats_of<FIT_CH>(s0, ln.tex, m0);
-                key = (int32_t)((uint32_t)part + (uint32_t)split_bound_from<FIT_CH>(s0, reinterpret_cast<const Stats<FIT_CH>&>(full), ln.T) * 64u);
-                fit_from_stats<FIT_CH, true>(fit[0], ln.tex, m0, s0, ln.T);
-            } else {
-                key = (int32_t)((uint32_t)part + (uint32_t)split_bound<RANK_CH>(ln.tex, m0, full, ln.T) * 64u);
-                fit_subset<FIT_CH, true>(fit[0], ln.tex, m0, ln.T);
+            ln.tx.fence();
+            uint32_t qa[2] = {0u, 0u}, qc[2] = {0u, 0u};
+            int32_t ea = 0, ec = 0;
+            IStats<FIT_CH> rest = full;
+            #pragma unroll 1
+            for (int j = 0; j < 2; j++) {
+                const SubsetMask sm = subset_of(part, j);
+                IStats<FIT_CH> st;
+                if (j == 0) stats_int<FIT_CH>(st, ln.tx.pl, sm); else st = rest;
+                stats_sub<FIT_CH>(rest, st);
+                float fit[2][4];
+                fit[0][3] = 0.f; fit[1][3] = 0.f;
+                fit_line<FIT_CH>(fit, ln.tx, sm.bits, st, rcp_of_count(sm.n), ln.T);
+                int32_t q[2][4], d[2][4];
+                if (FAMILY7) {
+                    quant_mode<7, true>(q, d, fit, 4);
+                    select_subset<2, 4>(qa, ea, ln.tx, make_segment<4>(d), sm.bits);
+                } else {
+                    if (na > 0) {
+                        quant_mode<1, true>(q, d, fit, 3);
+                        select_subset<3, 3>(qa, ea, ln.tx, make_segment<3>(d), sm.bits);
+                    }
+                    if (nb > 0) {
+                        quant_mode<3, true>(q, d, fit, 3);
+                        select_subset<2, 3>(qc, ec, ln.tx, make_segment<3>(d), sm.bits);
+                    }
+                }
             }
-            fit_subset<FIT_CH, true>(fit[1], ln.tex, m1, ln.T);
-            if (FIT_CH == 3) for (int j = 0; j < 2; j++) { fit[j][0][3] = 0.f; fit[j][1][3] = 0.f; }
-            if (FAMILY7) {
-                try_shape<7>(wa, ln, fit, sh, part, key);
-            } else {
-                if (na > 0) try_shape<1>(wa, ln, fit, sh, part, key);
-                if (nb > 0) try_shape<3>(wb, ln, fit, sh, part, key);
+            const bool on_a = na > 0, on_b = !FAMILY7 && nb > 0;
+            const bool tie_a = on_a && ea == wa.err, tie_b = on_b && ec == wb.err;
+            if (on_a && ea < wa.err) take(wa, ea, qa, part, -1);
+            if (on_b && ec < wb.err) take(wb, ec, qc, part, -1);
+            if (tie_a || tie_b) {
+                // equal errors: the reference keeps whichever comes first in its ranked list = the lower key.
+                // One rolled loop evaluates the missing keys: this shape's, then the incumbents'.
+                int32_t key_here = 0;
+                #pragma unroll 1
+                for (int which = 0; which < 3; which++) {
+                    const int shape = (which == 0) ? part : ((which == 1) ? wa.shape : wb.shape);
+                    const bool need = (which == 0) || (which == 1 && tie_a && wa.key < 0) || (which == 2 && tie_b && wb.key < 0);
+                    if (need) {
+                        const int32_t k = rank_key<RANK_CH>(shape, ln.tx, rfull, ln.T);
+                        if (which == 0) key_here = k; else if (which == 1) wa.key = k; else wb.key = k;
+                    }
+                }
+                if (tie_a && key_here < wa.key) take(wa, ea, qa, part, key_here);
+                if (tie_b && key_here < wb.key) take(wb, ec, qc, part, key_here);
             }
         }
     } else {
         // ranked prefix: keys to LDS, then walk them in increasing order per lane        [kernel.ispc:1400-1414]
         for (int part = 0; part < 64; part++) {
-            ln.tex.fence();
-            const uint32_t m0 = BCN_SUBSET_MASKS[part] & 0xffffu;
-            const int32_t bound = split_bound<RANK_CH>(ln.tex, m0, full, ln.T);
-            ln.keys[part * TPB] = (int32_t)((uint32_t)part + (uint32_t)bound * 64u);
+            ln.tx.fence();
+            ln.keys[part * TPB] = rank_key<RANK_CH>(part, ln.tx, rfull, ln.T);
         }
         const int n = min(max(na, nb), 64);
         int32_t prev = 0;
@@ -485,20 +561,45 @@ __device__ __forceinline__ void two_subset_modes(Lane& ln, const bc7_enc_setting
                 if ((i == 0 || k > prev) && k <= cur) cur = k;
             }
             prev = cur;
-            ln.tex.fence();
+            ln.tx.fence();
             const int shape = prev & 63;
             const Shape sh = load_shape(shape);
-            float fit[3][2][4];
+            Segment sa[3], sc[3];
+            IStats<FIT_CH> rest = full;
             #pragma unroll
             for (int j = 0; j < 2; j++) {
-                fit_subset<FIT_CH, true>(fit[j], ln.tex, subset_mask(sh, j), ln.T);
-                if (FIT_CH == 3) { fit[j][0][3] = 0.f; fit[j][1][3] = 0.f; }
+                const SubsetMask sm = subset_of(shape, j);
+                IStats<FIT_CH> st;
+                if (j == 0) stats_int<FIT_CH>(st, ln.tx.pl, sm); else st = rest;
+                stats_sub<FIT_CH>(rest, st);
+                float fit[2][4];
+                fit[0][3] = 0.f; fit[1][3] = 0.f;
+                fit_line<FIT_CH>(fit, ln.tx, sm.bits, st, ispc_rcp((float)sm.n, ln.T), ln.T);
+                int32_t q[2][4], d[2][4];
+                if (FAMILY7) {
+                    quant_mode<7, true>(q, d, fit, 4);
+                    sa[j] = make_segment<4>(d);
+                } else {
+                    quant_mode<1, true>(q, d, fit, 3);
+                    sa[j] = make_segment<3>(d);
+                    quant_mode<3, true>(q, d, fit, 3);
+                    sc[j] = make_segment<3>(d);
+                }
             }
+            sa[2] = sa[1]; sc[2] = sc[1];
+            uint32_t qb[2];
             if (FAMILY7) {
-                try_shape<7>(wa, ln, fit, sh, shape, prev);
+                const int32_t e = select_block<2, 4, 2>(qb, ln.tx, sa, sh.pattern);
+                if (e < wa.err) take(wa, e, qb, shape, prev);
             } else {
-                if (i < na) try_shape<1>(wa, ln, fit, sh, shape, prev);
-                if (i < nb) try_shape<3>(wb, ln, fit, sh, shape, prev);
+                if (i < na) {
+                    const int32_t e = select_block<3, 3, 2>(qb, ln.tx, sa, sh.pattern);
+                    if (e < wa.err) take(wa, e, qb, shape, prev);
+                }
+                if (i < nb) {
+                    const int32_t e = select_block<2, 3, 2>(qb, ln.tx, sc, sh.pattern);
+                    if (e < wb.err) take(wb, e, qb, shape, prev);
+                }
             }
         }
     }
@@ -512,51 +613,69 @@ __device__ __forceinline__ void two_subset_modes(Lane& ln, const bc7_enc_setting
 
 // ---- modes 4 and 5: vector part (3 channels) + one separately coded channel ------------------
 
+template <int BITS>
+__device__ __forceinline__ int32_t weight_single(int32_t q)                       // kernel.ispc:675-686
+{
+    if (BITS == 2) return (int32_t)__builtin_amdgcn_perm(0u, 0x402b1500u, (uint32_t)q | 0x0c0c0c00u);
+    if (BITS == 3) return (int32_t)__builtin_amdgcn_perm(0x40372e25u, 0x1b120900u, (uint32_t)q | 0x0c0c0c00u);
+    return (int32_t)(((uint32_t)q * 68u + 8u) >> 4);
+}
+
 // scalar channel: min/max endpoints, then `iters` rounds of LS refit.             [kernel.ispc:1437-1563]
+// Values v are the block's bytes of channel `rot_ch` (16 integers); vp = the same channel in planar form.
+// Integer-exact parts: decode (int)(((64-w)*e0 + w*e1 + 32)/64) = e0 + ((w*(e1-e0)+32) >> 6), squared errors,
+// and all sums of channel_opt_endpoints (<= 16*15*255).  The projection keeps the reference's fp32 form:
+// (v - e0) is exact, * rcp(e1 - e0 + 0.001f), * LEVELS (exact) + 0.5 (one FMA = two roundings here).
 template <int BITS, int EPBITS>
-__device__ __forceinline__ float encode_scalar(uint32_t (&qb)[2], int32_t (&qe)[2], const float (&v)[16], int iters, const SeedTables& T)
+__device__ __forceinline__ int32_t encode_scalar(uint32_t (&qb)[2], int32_t (&qe)[2], const Tex& tx, int rot_ch,
+                                                 const uint32_t (&vp)[4], int iters, const SeedTables& T)
 {
     constexpr int LEVELS = 1 << BITS;
-    constexpr float L1 = (float)(LEVELS - 1);
+    constexpr uint32_t LM1 = LEVELS - 1;
+    constexpr float L1 = (float)LM1;
     constexpr int EL = 1 << EPBITS;
-    float ep[2] = {255.f, 0.f};
+    const uint32_t shift = 8u * (uint32_t)rot_ch;
+    int32_t lo = 255, hi = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) { ep[0] = fmin_x86(ep[0], v[k]); ep[1] = fmax_x86(ep[1], v[k]); }
-    float err = 0.f;
+    for (int k = 0; k < 16; k++) { const int32_t v = (int32_t)((tx.w[k] >> shift) & 255u); lo = min(lo, v); hi = max(hi, v); }
+    float ep[2] = {(float)lo, (float)hi};
+    int32_t err = 0;
     for (int round = 0; ; round++) {
+        int32_t de[2];
         #pragma unroll
         for (int i = 0; i < 2; i++) {                                            // channel_quant_dequant
-            qe[i] = iclamp(f2i_x86(ep[i] * INV255 * (float)(EL - 1) + 0.5f), 0, EL - 1);
-            ep[i] = (float)expand_to_byte(qe[i], EPBITS);
+            qe[i] = iclamp((int32_t)(ep[i] * INV255 * (float)(EL - 1) + 0.5f), 0, EL - 1);   // ep in [0,255]
+            de[i] = expand_to_byte(qe[i], EPBITS);
         }
         qb[0] = qb[1] = 0u;                                                      // channel_opt_quant
-        err = 0.f;
-        const float rspan = ispc_rcp(ep[1] - ep[0] + 0.001f, T);
+        err = 0;
+        const int32_t span = de[1] - de[0];
+        const float rspan = ispc_rcp((float)span + 0.001f, T);
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const float proj = (v[k] - ep[0]) * rspan;
-            int32_t q1 = iclamp(f2i_x86(proj * (float)LEVELS + 0.5f), 1, LEVELS - 1);
-            const float w0 = (float)weight_of<BITS>(q1 - 1), w1 = (float)weight_of<BITS>(q1);
-            const float d0 = (float)f2i_x86(((64.0f - w0) * ep[0] + w0 * ep[1] + 32.0f) * 0.015625f);
-            const float d1 = (float)f2i_x86(((64.0f - w1) * ep[0] + w1 * ep[1] + 32.0f) * 0.015625f);
-            float e0 = 0.f, e1 = 0.f;
-            e0 += sq(d0 - v[k]);
-            e1 += sq(d1 - v[k]);
+            const int32_t v = (int32_t)((tx.w[k] >> shift) & 255u);
+            const float proj = (float)(v - de[0]) * rspan;
+            const int32_t q1 = imed3((int32_t)__builtin_fmaf(proj, (float)LEVELS, 0.5f), 1, LEVELS - 1);
+            const int32_t w0 = weight_single<BITS>(q1 - 1), w1 = weight_single<BITS>(q1);
+            const int32_t x0 = de[0] + ((w0 * span + 32) >> 6) - v;
+            const int32_t x1 = de[0] + ((w1 * span + 32) >> 6) - v;
+            const int32_t e0 = x0 * x0, e1 = x1 * x1;
             const bool first = e0 < e1;
             const uint32_t q = (uint32_t)(first ? q1 - 1 : q1);
-            if (k < 8) qb[0] += q << (4 * k); else qb[1] += q << (4 * (k - 8));
-            err += (float)(int32_t)(first ? e0 : e1);
+            if (k < 8) qb[0] |= q << (4 * k); else qb[1] |= q << (4 * (k - 8));
+            err += min(e0, e1);
         }
         if (round >= iters) break;
-        float atb1 = 0.f, sum_q = 0.f, sum_qq = 0.f, sum = 0.f;                   // channel_opt_endpoints
+        const uint32_t qn[4] = {qb[0] & 0x0f0f0f0fu, (qb[0] >> 4) & 0x0f0f0f0fu, qb[1] & 0x0f0f0f0fu, (qb[1] >> 4) & 0x0f0f0f0fu};
+        uint32_t sq_ = 0, sqq = 0, ssum = 0, satb = 0;                           // channel_opt_endpoints
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const float q = (float)((k < 8 ? qb[0] >> (4 * k) : qb[1] >> (4 * (k - 8))) & 15u);
-            const float x = L1 - q;
-            sum_q += q; sum_qq += q * q;
-            sum += v[k];
-            atb1 += x * v[k];
+        for (int d = 0; d < 4; d++) {
+            sq_ = udot4(qn[d], 0x01010101u, sq_);
+            sqq = udot4(qn[d], qn[d], sqq);
+            ssum = udot4(vp[d], 0x01010101u, ssum);
+            satb = udot4(vp[d], LM1 * 0x01010101u - qn[d], satb);
         }
+        const float sum_q = (float)sq_, sum_qq = (float)sqq, sum = (float)ssum, atb1 = (float)satb;
         const float atb2 = L1 * sum - atb1;
         const float cxx = 16.0f * (L1 * L1) - (2.0f * L1) * sum_q + sum_qq;
         const float cyy = sum_qq;
@@ -570,48 +689,42 @@ __device__ __forceinline__ float encode_scalar(uint32_t (&qb)[2], int32_t (&qe)[
     return err;
 }
 
-// one (mode, rotation, index-swap) candidate                                       [kernel.ispc:1565-1621]
+// one (mode, rotation, index-swap) candidate, given the rotation's line fit      [kernel.ispc:1565-1621]
 template <int MODE, int SWAP>
-__device__ __forceinline__ void try_dual(Dual& best, float& best_err, const Lane& ln, const bc7_enc_settings& S, int rotation)
+__device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const Lane& ln, const Tex& rot, const float (&fit)[2][4],
+                                         const bc7_enc_settings& S, int rotation)
 {
     constexpr int BITS = SWAP ? 3 : 2;
     constexpr int ABITS = SWAP ? 2 : ((MODE == 4) ? 3 : 2);
     constexpr int AEPB = (MODE == 4) ? 6 : 8;
+    const SubsetMask all = whole_block();
 
-    // rotated colour block: channel `rotation` is replaced by alpha (RGBA profile) or 255 (RGB profile);
-    // the displaced channel is coded separately
-    TexU8 rot;
-    float scalar[16];
-    const uint32_t sh8 = 8u * (uint32_t)rotation;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const uint32_t w = ln.tex.w[k];
-        scalar[k] = (float)((w >> sh8) & 255u);
-        uint32_t r = w;
-        if (rotation < 3) {
-            const uint32_t fill = (S.channels == 4) ? (w >> 24) : 255u;
-            r = (w & ~(255u << sh8)) | (fill << sh8);
-        }
-        rot.w[k] = r;
-    }
-
-    float ep[3][2][4];
-    int32_t q[2][4];
+    int32_t q[2][4], d[2][4];
     uint32_t qb[2];
-    ep[0][0][3] = 0.f; ep[0][1][3] = 0.f;
-    fit_subset<3, true>(ep[0], rot, 0xffffu, ln.T);
-    quant_mode<MODE>(q, ep[0], 3);
-    float err = select_indices<BITS, 3, false>(qb, rot, ep, 0u);
+    Segment sg[3];
+    quant_mode<MODE, true>(q, d, fit, 3);
+    sg[0] = make_segment<3>(d); sg[1] = sg[0]; sg[2] = sg[0];
+    int32_t err = select_block<BITS, 3, 1>(qb, rot, sg, 0u);
     const int iters = S.refineIterations[MODE];
     for (int it = 0; it < iters; it++) {
-        refit_subset<BITS, 3>(ep[0], rot, qb, 0xffffu, ln.T);
-        quant_mode<MODE>(q, ep[0], 3);
-        err = select_indices<BITS, 3, false>(qb, rot, ep, 0u);
+        float ep[2][4];
+        ep[0][3] = 0.f; ep[1][3] = 0.f;
+        refit_line<BITS, 3>(ep, rot.pl, qb, all, ln.T);
+        quant_mode<MODE, false>(q, d, ep, 3);
+        sg[0] = make_segment<3>(d);
+        err = select_block<BITS, 3, 1>(qb, rot, sg, 0u);
     }
 
     int32_t aq[2];
     uint32_t aqb[2];
-    err += encode_scalar<ABITS, AEPB>(aqb, aq, scalar, S.refineIterations_channel, ln.T);
+    const uint32_t vp[4] = {ln.tx.pl[0][0], ln.tx.pl[0][1], ln.tx.pl[0][2], ln.tx.pl[0][3]};
+    const uint32_t vg[4] = {ln.tx.pl[1][0], ln.tx.pl[1][1], ln.tx.pl[1][2], ln.tx.pl[1][3]};
+    const uint32_t vb[4] = {ln.tx.pl[2][0], ln.tx.pl[2][1], ln.tx.pl[2][2], ln.tx.pl[2][3]};
+    const uint32_t va[4] = {ln.tx.pl[3][0], ln.tx.pl[3][1], ln.tx.pl[3][2], ln.tx.pl[3][3]};
+    uint32_t vsel[4];
+    #pragma unroll
+    for (int i = 0; i < 4; i++) vsel[i] = (rotation == 0) ? vp[i] : ((rotation == 1) ? vg[i] : ((rotation == 2) ? vb[i] : va[i]));
+    err += encode_scalar<ABITS, AEPB>(aqb, aq, ln.tx, rotation, vsel, S.refineIterations_channel, ln.T);
 
     if (err < best_err) {
         #pragma unroll
@@ -625,43 +738,82 @@ __device__ __forceinline__ void try_dual(Dual& best, float& best_err, const Lane
     }
 }
 
+__device__ __forceinline__ void clear(Dual& d)
+{
+    #pragma unroll
+    for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) d.q[i][p] = 0;
+    d.qb[0] = d.qb[1] = d.aqb[0] = d.aqb[1] = 0u;
+    d.aq[0] = d.aq[1] = 0; d.rotation = 0; d.swap = 0;
+}
+
+// The reference tries all mode 4 candidates (rotation-major, swap-minor), commits, then all mode 5 candidates.
+// Here one pass over the rotations serves both: a rotation's line fit does not depend on the mode.  Mode 5's
+// winner is found independently (first strict minimum in rotation order) and admitted afterwards against the
+// error left by mode 4 -- the same block the sequential scan produces.
 __device__ __forceinline__ void modes_45(Lane& ln, const bc7_enc_settings& S)      // [kernel.ispc:1623-1655]
 {
-    Dual best;
-    #pragma unroll
-    for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) best.q[i][p] = 0;
-    best.qb[0] = best.qb[1] = best.aqb[0] = best.aqb[1] = 0u;
-    best.aq[0] = best.aq[1] = 0; best.rotation = 0; best.swap = 0;
-    float best_err = ln.best_err;
+    Dual best4, best5;
+    clear(best4); clear(best5);
+    int32_t err4 = ln.best_err, err5 = ERR_MAX;
 
     for (int r = S.mode45_channel0; r < S.channels; r++) {
-        try_dual<4, 0>(best, best_err, ln, S, r);
-        try_dual<4, 1>(best, best_err, ln, S, r);
+        // rotated colour block: channel r is replaced by alpha (RGBA profile) or 255 (RGB profile);
+        // the displaced channel is coded separately
+        Tex rot;
+        const uint32_t sh8 = 8u * (uint32_t)r;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t w = ln.tx.w[k];
+            uint32_t v = w;
+            if (r < 3) {
+                const uint32_t fill = (S.channels == 4) ? (w >> 24) : 255u;
+                v = (w & ~(255u << sh8)) | (fill << sh8);
+            }
+            rot.w[k] = v;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                const uint32_t fill = (S.channels == 4) ? ln.tx.pl[3][d] : 0xffffffffu;
+                rot.pl[c][d] = (c == r && r < 3) ? fill : ln.tx.pl[c][d];
+            }
+        IStats<3> st;
+        stats_int<3>(st, rot.pl, whole_block());
+        float fit[2][4];
+        fit[0][3] = 0.f; fit[1][3] = 0.f;
+        fit_line<3>(fit, rot, 0xffffu, st, rcp_of_count(16), ln.T);
+        try_dual<4, 0>(best4, err4, ln, rot, fit, S, r);
+        try_dual<4, 1>(best4, err4, ln, rot, fit, S, r);
+        try_dual<5, 0>(best5, err5, ln, rot, fit, S, r);
     }
-    if (best_err < ln.best_err) { ln.best_err = best_err; ln.improved = true; emit_dual<4>(ln.best, best); }
-
-    for (int r = S.mode45_channel0; r < S.channels; r++)
-        try_dual<5, 0>(best, best_err, ln, S, r);
-    if (best_err < ln.best_err) { ln.best_err = best_err; ln.improved = true; emit_dual<5>(ln.best, best); }
+    if (err4 < ln.best_err) { ln.best_err = err4; ln.improved = true; emit_dual<4>(ln.best, best4); }
+    if (err5 < ln.best_err) { ln.best_err = err5; ln.improved = true; emit_dual<5>(ln.best, best5); }
 }
 
 // ---- mode 6: one subset, RGBA, 4-bit indices                                     [kernel.ispc:1657-1689]
 template <int CH>
 __device__ __forceinline__ void mode_6(Lane& ln, const bc7_enc_settings& S)
 {
-    float ep[3][2][4];
-    int32_t q[2][4];
+    const SubsetMask all = whole_block();
+    IStats<CH> st;
+    stats_int<CH>(st, ln.tx.pl, all);
+    float ep[2][4];
+    int32_t q[2][4], d[2][4];
     uint32_t qb[2];
-    ep[0][0][3] = 0.f; ep[0][1][3] = 0.f;
-    fit_subset<CH, true>(ep[0], ln.tex, 0xffffu, ln.T);
-    if (CH == 3) { ep[0][0][3] = 255.f; ep[0][1][3] = 255.f; }
-    quant_mode<6>(q, ep[0], CH);
-    float err = select_indices<4, CH, false>(qb, ln.tex, ep, 0u);
+    Segment sg[3];
+    ep[0][3] = 0.f; ep[1][3] = 0.f;
+    fit_line<CH>(ep, ln.tx, 0xffffu, st, rcp_of_count(16), ln.T);
+    if (CH == 3) { ep[0][3] = 255.f; ep[1][3] = 255.f; }
+    quant_mode<6, true>(q, d, ep, CH);
+    sg[0] = make_segment<CH>(d); sg[1] = sg[0]; sg[2] = sg[0];
+    int32_t err = select_block<4, CH, 1>(qb, ln.tx, sg, 0u);
     const int iters = S.refineIterations[6];
     for (int it = 0; it < iters; it++) {
-        refit_subset<4, CH>(ep[0], ln.tex, qb, 0xffffu, ln.T);
-        quant_mode<6>(q, ep[0], CH);
-        err = select_indices<4, CH, false>(qb, ln.tex, ep, 0u);
+        refit_line<4, CH>(ep, ln.tx.pl, qb, all, ln.T);
+        quant_mode<6, false>(q, d, ep, CH);
+        sg[0] = make_segment<CH>(d);
+        err = select_block<4, CH, 1>(qb, ln.tx, sg, 0u);
     }
     if (err < ln.best_err) {
         ln.best_err = err;
@@ -676,38 +828,43 @@ enum Family { F_MODES02 = 0, F_MODES13 = 1, F_MODE7 = 2, F_MODES456 = 3 };
 template <int FAMILY, bool VEC16>
 __global__ void __launch_bounds__(TPB)
 bc7_family_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
-                  uint8_t* __restrict__ dst, float* __restrict__ err_ws, const bc7_enc_settings S, const int first)
+                  uint8_t* __restrict__ dst, int32_t* __restrict__ err_ws, const bc7_enc_settings S, const int first)
 {
-    __shared__ int32_t s_keys[(FAMILY == F_MODES13 || FAMILY == F_MODE7) ? 64 * TPB : 1];
-    const int32_t b = blockIdx.x * TPB + threadIdx.x;
-    if (b >= nblocks) return;
+    __shared__ unsigned short s_seed[4096];
+    extern __shared__ int32_t s_keys[];            // 64 * TPB keys, only allocated for ranked lists
+    Lane ln;
+    ln.T = stage_seed_tables(s_seed, threadIdx.x, TPB);
+    __syncthreads();
+
+    const int32_t gid = blockIdx.x * TPB + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;    // idle lanes of the last workgroup redo its last block, store nothing
     const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
 
-    Lane ln;
-    ln.T = global_seed_tables();
-    ln.keys = s_keys + ((FAMILY == F_MODES13 || FAMILY == F_MODE7) ? threadIdx.x : 0);
+    ln.keys = s_keys + threadIdx.x;
     const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 16;
 #pragma unroll
     for (int y = 0; y < 4; y++) {
         if (VEC16) {
             const uint4 v = *reinterpret_cast<const uint4*>(p + y * stride);
-            ln.tex.w[y * 4 + 0] = v.x; ln.tex.w[y * 4 + 1] = v.y; ln.tex.w[y * 4 + 2] = v.z; ln.tex.w[y * 4 + 3] = v.w;
+            ln.tx.w[y * 4 + 0] = v.x; ln.tx.w[y * 4 + 1] = v.y; ln.tx.w[y * 4 + 2] = v.z; ln.tx.w[y * 4 + 3] = v.w;
         } else {
             const uint32_t* q = reinterpret_cast<const uint32_t*>(p + y * stride);
             #pragma unroll
-            for (int x = 0; x < 4; x++) ln.tex.w[y * 4 + x] = q[x];
+            for (int x = 0; x < 4; x++) ln.tx.w[y * 4 + x] = q[x];
         }
     }
+    ln.tx.make_planar();
 
-    ln.best_err = first ? __builtin_inff() : err_ws[b];
+    ln.best_err = first ? ERR_MAX : err_ws[b];
     ln.best[0] = ln.best[1] = ln.best[2] = ln.best[3] = 0u;
     ln.improved = (first != 0);                    // the first family always defines the block
-    ln.opaque_err = 0.f;                                                           // kernel.ispc:1267-1277
+    ln.opaque_err = 0;                                                             // kernel.ispc:1267-1277
     if (S.channels == 4) {
-        float e = 0.f;
+        uint32_t e = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) e += sq(ln.tex.get(3, k) - 255.0f);
-        ln.opaque_err = e;
+        for (int d = 0; d < 4; d++) { const uint32_t x = ~ln.tx.pl[3][d]; e = udot4(x, x, e); }   // (255 - a)^2, bytewise
+        ln.opaque_err = (int32_t)e;
     }
 
     if (FAMILY == F_MODES02) modes_02(ln, S);
@@ -718,7 +875,7 @@ bc7_family_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
         if (S.mode_selection[3]) { if (S.channels == 4) mode_6<4>(ln, S); else mode_6<3>(ln, S); }
     }
 
-    if (ln.improved) {
+    if (live && ln.improved) {
         uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
         if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(ln.best[0], ln.best[1], ln.best[2], ln.best[3]);
         else { d[0] = ln.best[0]; d[1] = ln.best[1]; d[2] = ln.best[2]; d[3] = ln.best[3]; }
@@ -727,16 +884,16 @@ bc7_family_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
 }
 
 template <int FAMILY>
-static void launch_family(bool vec, dim3 grid, hipStream_t st, const uint8_t* src, int64_t stride, int bx, int32_t n,
-                          uint8_t* dst, float* ws, const bc7_enc_settings& S, int first)
+static void launch_family(bool vec, dim3 grid, size_t lds, hipStream_t st, const uint8_t* src, int64_t stride, int bx, int32_t n,
+                          uint8_t* dst, int32_t* ws, const bc7_enc_settings& S, int first)
 {
-    if (vec) hipLaunchKernelGGL((bc7_family_kernel<FAMILY, true>),  grid, dim3(TPB), 0, st, src, stride, bx, n, dst, ws, S, first);
-    else     hipLaunchKernelGGL((bc7_family_kernel<FAMILY, false>), grid, dim3(TPB), 0, st, src, stride, bx, n, dst, ws, S, first);
+    if (vec) hipLaunchKernelGGL((bc7_family_kernel<FAMILY, true>),  grid, dim3(TPB), lds, st, src, stride, bx, n, dst, ws, S, first);
+    else     hipLaunchKernelGGL((bc7_family_kernel<FAMILY, false>), grid, dim3(TPB), lds, st, src, stride, bx, n, dst, ws, S, first);
 }
 
 size_t bc7_workspace_bytes(int width, int height)
 {
-    return (size_t)(width / 4) * (size_t)(height / 4) * sizeof(float);
+    return (size_t)(width / 4) * (size_t)(height / 4) * sizeof(int32_t);
 }
 
 // Families run in the reference's order (kernel.ispc:1970-1977): {0,2} -> {1,3} -> {7} -> {4,5} -> {6}.
@@ -748,18 +905,23 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
     if (n <= 0) return;
     bc7_enc_settings S = s;
     S.channels = (s.channels == 4) ? 4 : 3;
+    int32_t* ws = reinterpret_cast<int32_t*>(err_ws);
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const dim3 grid((unsigned)((n + TPB - 1) / TPB));
+    const size_t key_bytes = (size_t)64 * TPB * sizeof(int32_t);
+    auto ranked = [](int t) { return t > 0 && t < 64; };
     int first = 1;
-    if (S.mode_selection[0]) { launch_family<F_MODES02>(vec, grid, st, src, stride, bx, (int32_t)n, dst, err_ws, S, first); first = 0; }
+    if (S.mode_selection[0]) { launch_family<F_MODES02>(vec, grid, 0, st, src, stride, bx, (int32_t)n, dst, ws, S, first); first = 0; }
     if (S.mode_selection[1] && (S.fastSkipTreshold_mode1 > 0 || S.fastSkipTreshold_mode3 > 0)) {
-        launch_family<F_MODES13>(vec, grid, st, src, stride, bx, (int32_t)n, dst, err_ws, S, first); first = 0;
+        const size_t lds = (ranked(S.fastSkipTreshold_mode1) || ranked(S.fastSkipTreshold_mode3)) ? key_bytes : 0;
+        launch_family<F_MODES13>(vec, grid, lds, st, src, stride, bx, (int32_t)n, dst, ws, S, first); first = 0;
     }
     if (S.mode_selection[1] && S.fastSkipTreshold_mode7 > 0) {
-        launch_family<F_MODE7>(vec, grid, st, src, stride, bx, (int32_t)n, dst, err_ws, S, first); first = 0;
+        const size_t lds = ranked(S.fastSkipTreshold_mode7) ? key_bytes : 0;
+        launch_family<F_MODE7>(vec, grid, lds, st, src, stride, bx, (int32_t)n, dst, ws, S, first); first = 0;
     }
     if (S.mode_selection[2] || S.mode_selection[3]) {
-        launch_family<F_MODES456>(vec, grid, st, src, stride, bx, (int32_t)n, dst, err_ws, S, first); first = 0;
+        launch_family<F_MODES456>(vec, grid, 0, st, src, stride, bx, (int32_t)n, dst, ws, S, first); first = 0;
     }
     if (first) (void)hipMemsetAsync(dst, 0, (size_t)n * 16, st);   // no mode enabled: defined (zero) output
 }

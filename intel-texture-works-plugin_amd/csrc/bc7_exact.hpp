@@ -1,0 +1,378 @@
+// bc7_exact.hpp -- integer-exact building blocks of the BC7 kernels (gfx950).
+//
+// BC7 texels and dequantised endpoints are integers in [0,255].  Large parts of what
+// the reference computes in fp32 (kernel.ispc:763-803 moment sums, 1133-1193
+// block_quant, 1198-1240 the sums of opt_endpoints) therefore never round: every
+// intermediate is an integer below 2^24.  Those parts are restated here in integer
+// arithmetic on the packed-math units (v_dot4_u32_u8, v_dot2_i32_i16, v_pk_mad_i16),
+// which produce the SAME numbers with a third of the instructions.  Each function
+// states the bound that makes it exact.  Whatever can round in the reference (PCA,
+// endpoint quantisation, the tail of the least-squares solve) stays in fp32 with the
+// pinned arithmetic of x86_math.hpp, operation for operation.
+//
+// Planar texel layout ("EO order") used by the dot4 sums: for each channel four
+// dwords holding texels (0,2,4,6) (1,3,5,7) (8,10,12,14) (9,11,13,15), first texel in
+// byte 0.  Nibble-packed index words expand to the same order with one AND (even
+// texels) or shift+AND (odd texels); sums over texels are order-free because exact.
+#pragma once
+#include "bcn_core.hpp"
+
+namespace itw {
+
+#define BCN_TABLE_QUAL __device__ const
+#include "bc7_bytemasks.h"
+#undef BCN_TABLE_QUAL
+
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 as_s16x2(uint32_t v) { return __builtin_bit_cast(s16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return as_u32(as_s16x2(a) - as_s16x2(b)); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return as_u32(as_s16x2(a) + as_s16x2(b)); }
+__device__ __forceinline__ int32_t dot2(uint32_t a, uint32_t b, int32_t c)
+{
+    return __builtin_amdgcn_sdot2(as_s16x2(a), as_s16x2(b), c, false);
+}
+__device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+__device__ __forceinline__ uint32_t pack16(int32_t lo, int32_t hi) { return (uint32_t)lo | ((uint32_t)hi << 16); }   // both in [0,65535]
+__device__ __forceinline__ int32_t imed3(int32_t v, int32_t lo, int32_t hi) { return min(max(v, lo), hi); }
+
+// ISPC rcp(n) for n = 0..16 under the pinned arithmetic (x86_math.hpp), as bit patterns.  Subset sizes are
+// wave-uniform in table-order scans, so `covariance = moments - s*s*rcp(n)` reads a scalar constant instead of
+// gathering the RCPPS seed.  tests/test_gpu_math.py checks the table against the device's own ispc_rcp.
+__device__ const uint32_t RCP_OF_COUNT[17] = {
+    0xffc00000u, 0x3f7fffffu, 0x3effffffu, 0x3eaaaaaau, 0x3e7fffffu, 0x3e4cccccu, 0x3e2aaaaau, 0x3e124924u, 0x3dffffffu,
+    0x3de38e38u, 0x3dccccccu, 0x3dba2e8bu, 0x3daaaaaau, 0x3d9d89d8u, 0x3d924924u, 0x3d888888u, 0x3d7fffffu};
+__device__ __forceinline__ float rcp_of_count(int n) { return __uint_as_float(RCP_OF_COUNT[n]); }
+
+// ---- the lane's block -------------------------------------------------------------------------
+struct Tex {
+    uint32_t w[16];        // RGBA8 as loaded, texel k
+    uint32_t pl[4][4];     // planar bytes, EO order: pl[channel][dword]
+    __device__ __forceinline__ float get(int p, int k) const { return (float)((w[k] >> (8 * p)) & 255u); }
+    // (c0 | c1 << 16) and (c2 | c3 << 16) of texel k as 16-bit pairs; ALPHA=false leaves the c3 half zero
+    __device__ __forceinline__ uint32_t pair01(int k) const { return __builtin_amdgcn_perm(0u, w[k], 0x0c010c00u); }
+    template <bool ALPHA>
+    __device__ __forceinline__ uint32_t pair23(int k) const
+    {
+        return ALPHA ? __builtin_amdgcn_perm(0u, w[k], 0x0c030c02u) : ((w[k] >> 16) & 255u);
+    }
+    // 4x4 byte transposes of the loaded words into the planar form (8 v_perm per 4 texels)
+    __device__ __forceinline__ void make_planar()
+    {
+        const int grp[4][4] = {{0, 2, 4, 6}, {1, 3, 5, 7}, {8, 10, 12, 14}, {9, 11, 13, 15}};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            const uint32_t a = w[grp[d][0]], b = w[grp[d][1]], c = w[grp[d][2]], e = w[grp[d][3]];
+            const uint32_t t0 = __builtin_amdgcn_perm(b, a, 0x05010400u);   // a.r b.r a.g b.g
+            const uint32_t t1 = __builtin_amdgcn_perm(b, a, 0x07030602u);   // a.b b.b a.a b.a
+            const uint32_t u0 = __builtin_amdgcn_perm(e, c, 0x05010400u);
+            const uint32_t u1 = __builtin_amdgcn_perm(e, c, 0x07030602u);
+            pl[0][d] = __builtin_amdgcn_perm(u0, t0, 0x05040100u);
+            pl[1][d] = __builtin_amdgcn_perm(u0, t0, 0x07060302u);
+            pl[2][d] = __builtin_amdgcn_perm(u1, t1, 0x05040100u);
+            pl[3][d] = __builtin_amdgcn_perm(u1, t1, 0x07060302u);
+        }
+    }
+    // Compiler fence for candidate loops: everything derived from the texels is loop invariant and LICM would
+    // hoist hundreds of conversions / products out of the shape loop into registers or scratch.
+    __device__ __forceinline__ void fence()
+    {
+#pragma unroll
+        for (int k = 0; k < 16; k++) asm volatile("" : "+v"(w[k]));
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int d = 0; d < 4; d++) asm volatile("" : "+v"(pl[c][d]));
+    }
+};
+
+// ---- subset masks -------------------------------------------------------------------------------
+struct SubsetMask {
+    uint32_t bits;      // texel k in subset: bit k
+    uint32_t bm[4];     // the same as byte masks over the planar layout
+    int32_t n;          // texel count
+};
+
+// subset j (0..2) of table shape `shape`; wave-uniform when `shape` is (scalar loads), per lane otherwise
+__device__ __forceinline__ SubsetMask subset_of(int shape, int j)
+{
+    const uint32_t masks = BCN_SUBSET_MASKS[shape];
+    const uint32_t m0 = masks & 0xffffu, m1 = masks >> 16;
+    const uint32_t* t = BCN_BYTEMASK + shape * 8;
+    SubsetMask s;
+    if (j == 0)      { s.bits = m0; for (int d = 0; d < 4; d++) s.bm[d] = t[d]; }
+    else if (j == 1) { s.bits = m1; for (int d = 0; d < 4; d++) s.bm[d] = t[4 + d]; }
+    else             { s.bits = ~(m0 | m1) & 0xffffu; for (int d = 0; d < 4; d++) s.bm[d] = ~(t[d] | t[4 + d]); }
+    s.n = __builtin_popcount(s.bits);
+    return s;
+}
+
+__device__ __forceinline__ SubsetMask whole_block()
+{
+    return SubsetMask{0xffffu, {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, 16};
+}
+
+// ---- second moments of a subset (kernel.ispc:763-803) as integers ---------------------------------
+// Exact: a product of two texel values is <= 65025 and a sum of 16 of them <= 1 040 400 < 2^24, so the
+// reference's float accumulators hold exactly these integers whatever the summation order.
+template <int CH>
+struct IStats {
+    int32_t m[10];   // 00 01 02 03 11 12 13 22 23 33
+    int32_t s[4];
+    int32_t n;
+};
+
+template <int CH>
+__device__ __forceinline__ void stats_int(IStats<CH>& st, const uint32_t (&pl)[4][4], const SubsetMask& sm)
+{
+    uint32_t r[4], g[4], b[4], a[4];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        r[d] = pl[0][d] & sm.bm[d]; g[d] = pl[1][d] & sm.bm[d]; b[d] = pl[2][d] & sm.bm[d];
+        a[d] = (CH == 4) ? (pl[3][d] & sm.bm[d]) : 0u;
+    }
+    uint32_t m[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, s[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        m[0] = udot4(r[d], pl[0][d], m[0]); m[1] = udot4(r[d], pl[1][d], m[1]); m[2] = udot4(r[d], pl[2][d], m[2]);
+        m[4] = udot4(g[d], pl[1][d], m[4]); m[5] = udot4(g[d], pl[2][d], m[5]);
+        m[7] = udot4(b[d], pl[2][d], m[7]);
+        s[0] = udot4(r[d], 0x01010101u, s[0]); s[1] = udot4(g[d], 0x01010101u, s[1]); s[2] = udot4(b[d], 0x01010101u, s[2]);
+        if (CH == 4) {
+            m[3] = udot4(r[d], pl[3][d], m[3]); m[6] = udot4(g[d], pl[3][d], m[6]); m[8] = udot4(b[d], pl[3][d], m[8]);
+            m[9] = udot4(a[d], pl[3][d], m[9]);
+            s[3] = udot4(a[d], 0x01010101u, s[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 10; i++) st.m[i] = (int32_t)m[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) st.s[i] = (int32_t)s[i];
+    st.n = sm.n;
+}
+
+template <int CH>
+__device__ __forceinline__ void stats_sub(IStats<CH>& a, const IStats<CH>& b)      // a -= b (exact)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) a.m[i] -= b.m[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) a.s[i] -= b.s[i];
+    a.n -= b.n;
+}
+
+template <int CH>
+__device__ __forceinline__ void stats_float(Stats<CH>& f, const IStats<CH>& st)
+{
+#pragma unroll
+    for (int i = 0; i < 10; i++) f.m[i] = (float)st.m[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) f.s[i] = (float)st.s[i];
+    f.n = (float)st.n;
+}
+
+// ---- PCA line fit of a subset (kernel.ispc:825-905): fp32, pinned arithmetic --------------------------
+// `rn` = ISPC rcp(texel count).  Endpoints clamped to [0,255]; slots p >= CH are left untouched.
+template <int CH>
+__device__ __forceinline__ void fit_line(float (&ep)[2][4], const Tex& tx, uint32_t mask, const IStats<CH>& ist, float rn, const SeedTables& T)
+{
+    Stats<CH> st;
+    stats_float<CH>(st, ist);
+    float cv[10];
+    covariance_of<CH>(cv, st, rn);
+    float dc[4];
+#pragma unroll
+    for (int p = 0; p < CH; p++) dc[p] = st.s[p] * rn;
+
+    const float inv_var = 1.0f / 65536.0f;
+#pragma unroll
+    for (int i = 0; i < 10; i++) cv[i] *= inv_var;
+    const float eps = 0.001f * 0.001f;
+    cv[0] += eps; cv[4] += eps; cv[7] += eps; cv[9] += eps;
+
+    float axis[4];
+    principal_axis<CH, 8>(axis, cv, T);
+
+    float lo = __builtin_inff(), hi = -__builtin_inff();
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if ((mask >> k) & 1u) {
+            float dot = 0.f;
+#pragma unroll
+            for (int p = 0; p < CH; p++) dot += axis[p] * (tx.get(p, k) - dc[p]);
+            lo = fmin_x86(lo, dot);
+            hi = fmax_x86(hi, dot);
+        }
+    }
+    if (hi - lo < 1.0f) { lo -= 0.5f; hi += 0.5f; }
+#pragma unroll
+    for (int p = 0; p < CH; p++) {
+        ep[0][p] = fclamp_x86(lo * axis[p] + dc[p], 0.f, 255.f);
+        ep[1][p] = fclamp_x86(hi * axis[p] + dc[p], 0.f, 255.f);
+    }
+}
+
+// ---- index selection (kernel.ispc:1133-1193 block_quant) in integers ----------------------------------
+// One segment = the two dequantised endpoints of a subset, as 16-bit channel pairs.
+struct Segment {
+    uint32_t a01, a23;      // endpoint 0:  c0 | c1 << 16,  c2 | c3 << 16
+    uint32_t ba01, ba23;    // endpoint 1 - endpoint 0, per channel (signed 16-bit pairs)
+    float dn, rn;           // -|b-a|^2 and its correctly rounded reciprocal (0 when the segment is a point)
+};
+
+// d[0], d[1]: endpoints as the decoder reconstructs them, [0,255].  CH==3 drops channel 3 from the metric.
+template <int CH>
+__device__ __forceinline__ Segment make_segment(const int32_t (&d)[2][4])
+{
+    Segment s;
+    s.a01 = pack16(d[0][0], d[0][1]);
+    s.a23 = pack16(d[0][2], CH == 4 ? d[0][3] : 0);
+    const uint32_t b01 = pack16(d[1][0], d[1][1]);
+    const uint32_t b23 = pack16(d[1][2], CH == 4 ? d[1][3] : 0);
+    s.ba01 = pk_sub(b01, s.a01);
+    s.ba23 = pk_sub(b23, s.a23);
+    const int32_t dd = dot2(s.ba01, s.ba01, dot2(s.ba23, s.ba23, 0));
+    s.dn = -(float)dd;
+    s.rn = (dd == 0) ? 0.0f : 1.0f / s.dn;           // IEEE divide, once per segment
+    return s;
+}
+
+// packed interpolation weight (w | w << 16) of index q; the format's tables (kernel.ispc:675-686)
+template <int BITS>
+__device__ __forceinline__ uint32_t weight_pair(int32_t q)
+{
+    if (BITS == 2) return __builtin_amdgcn_perm(0u, 0x402b1500u, (uint32_t)q * 0x00010001u + 0x0c000c00u);           // 0 21 43 64
+    if (BITS == 3) return __builtin_amdgcn_perm(0x40372e25u, 0x1b120900u, (uint32_t)q * 0x00010001u + 0x0c000c00u);  // 0 9 18 27 37 46 55 64
+    return (((uint32_t)q * 68u + 8u) >> 4) * 0x00010001u;                                                               // 0 4 9 13 ... 60 64
+}
+
+// One texel against one segment: the reference projects the texel on the segment, rounds to an index q1 in
+// [1, LEVELS-1], decodes q1-1 and q1 and keeps the closer (ties: q1).  Returns index and squared error.
+//
+// Exactness.  With integer texel t and endpoints a, b:  N = sum (t-a)(b-a) and D = sum (b-a)^2 are integers
+// below 2^18, so the reference's float N, D are exact; it then forms RN(N/D) with a true divide (`proj /= div`,
+// kernel.ispc:1158), x = RN(RN(N/D)*LEVELS + 0.5) and truncates.  Here: q0 = RN(M*rn) with M = -N, rn = RN(1/-D);
+// rem = M - q0*(-D) is exact in fp32 (an integer multiple of ulp(q0) below 2^19 ulps); RN(q0 + rem*rn) = RN(N/D)
+// because N/D is a ratio of integers < 2^18 and therefore never within 2^-19 ulp of a rounding boundary.  The
+// multiply by LEVELS is exact, so one FMA gives x.  D == 0 (segment is a point): the reference gets 0/0 = NaN ->
+// cvttps2dq INT_MIN -> clamp 1; here rn = 0 -> x = 0.5 -> 0 -> clamp 1.
+// Decode (kernel.ispc:1172-1173): (int)(((64-w)*a + w*b + 32)/64), all exact integers, = a + ((w*(b-a)+32) >> 6)
+// with an arithmetic shift.  Errors are sums of <= 4 squares of integers in [-255,255].
+template <int BITS>
+__device__ __forceinline__ void select_texel(int32_t& q_out, int32_t& e_out, const Segment& sg, uint32_t t01, uint32_t t23)
+{
+    constexpr int LEVELS = 1 << BITS;
+    const uint32_t at01 = pk_sub(sg.a01, t01), at23 = pk_sub(sg.a23, t23);
+    const int32_t m = dot2(at01, sg.ba01, dot2(at23, sg.ba23, 0));
+    const float mf = (float)m;
+    float q = mf * sg.rn;
+    const float rem = __builtin_fmaf(-q, sg.dn, mf);
+    q = __builtin_fmaf(rem, sg.rn, q);
+    const float x = __builtin_fmaf(q, (float)LEVELS, 0.5f);
+    const int32_t q1 = imed3((int32_t)x, 1, LEVELS - 1);
+
+    const s16x2 k32 = {32, 32}, six = {6, 6};
+    const uint32_t w1 = weight_pair<BITS>(q1), w0 = weight_pair<BITS>(q1 - 1);
+    const uint32_t x0_01 = pk_add(as_u32((as_s16x2(w0) * as_s16x2(sg.ba01) + k32) >> six), at01);
+    const uint32_t x0_23 = pk_add(as_u32((as_s16x2(w0) * as_s16x2(sg.ba23) + k32) >> six), at23);
+    const uint32_t x1_01 = pk_add(as_u32((as_s16x2(w1) * as_s16x2(sg.ba01) + k32) >> six), at01);
+    const uint32_t x1_23 = pk_add(as_u32((as_s16x2(w1) * as_s16x2(sg.ba23) + k32) >> six), at23);
+    const int32_t e0 = dot2(x0_01, x0_01, dot2(x0_23, x0_23, 0));
+    const int32_t e1 = dot2(x1_01, x1_01, dot2(x1_23, x1_23, 0));
+    const bool first = e0 < e1;
+    q_out = first ? q1 - 1 : q1;
+    e_out = min(e0, e1);
+}
+
+__device__ __forceinline__ Segment pick_segment(const Segment& s0, const Segment& s1, bool one)
+{
+    Segment r;
+    r.a01 = one ? s1.a01 : s0.a01; r.a23 = one ? s1.a23 : s0.a23;
+    r.ba01 = one ? s1.ba01 : s0.ba01; r.ba23 = one ? s1.ba23 : s0.ba23;
+    r.dn = one ? s1.dn : s0.dn; r.rn = one ? s1.rn : s0.rn;
+    return r;
+}
+
+// Whole block against up to three segments chosen per texel by `pattern` (2 bits per texel).  Used where the
+// shape differs per lane (refinement of the lane's winner, ranked candidate lists) and for one-subset modes.
+// Returns the block error; indices 4 bits per texel in qb.  The error sum is exact (< 2^24), as in the reference
+// where `(int)err` per texel is summed in float.
+template <int BITS, int CH, int PAIRS>
+__device__ __forceinline__ int32_t select_block(uint32_t (&qb)[2], const Tex& tx, const Segment (&sg)[3], uint32_t pattern)
+{
+    int32_t total = 0;
+    qb[0] = qb[1] = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        Segment s = sg[0];
+        if (PAIRS >= 2) {
+            const uint32_t j = (pattern >> (2 * k)) & 3u;
+            s = pick_segment(s, sg[1], j == 1u);
+            if (PAIRS == 3) s = pick_segment(s, sg[2], j == 2u);
+        }
+        int32_t q, e;
+        select_texel<BITS>(q, e, s, tx.pair01(k), tx.template pair23<CH == 4>(k));
+        if (k < 8) qb[0] |= (uint32_t)q << (4 * k); else qb[1] |= (uint32_t)q << (4 * (k - 8));
+        total += e;
+    }
+    return total;
+}
+
+// Texels of ONE subset (wave-uniform mask: scalar branches skip the others) against its segment; accumulates.
+template <int BITS, int CH>
+__device__ __forceinline__ void select_subset(uint32_t (&qb)[2], int32_t& total, const Tex& tx, const Segment& sg, uint32_t mask)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if ((mask >> k) & 1u) {
+            int32_t q, e;
+            select_texel<BITS>(q, e, sg, tx.pair01(k), tx.template pair23<CH == 4>(k));
+            if (k < 8) qb[0] |= (uint32_t)q << (4 * k); else qb[1] |= (uint32_t)q << (4 * (k - 8));
+            total += e;
+        }
+    }
+}
+
+// ---- least-squares endpoints for fixed indices (kernel.ispc:1198-1262 opt_endpoints) -------------------
+// The sums are exact integers (sum q*t <= 16*15*255); the 2x2 solve is fp32 exactly as in the reference.
+template <int BITS, int CH>
+__device__ __forceinline__ void refit_line(float (&ep)[2][4], const uint32_t (&pl)[4][4], const uint32_t (&qb)[2], const SubsetMask& sm, const SeedTables& T)
+{
+    constexpr uint32_t LM1 = (1u << BITS) - 1u;
+    constexpr float L1 = (float)LM1;
+    const uint32_t qe[4] = {qb[0] & 0x0f0f0f0fu, (qb[0] >> 4) & 0x0f0f0f0fu, qb[1] & 0x0f0f0f0fu, (qb[1] >> 4) & 0x0f0f0f0fu};
+    uint32_t sq_ = 0, sqq = 0, ssum[4] = {0, 0, 0, 0}, satb[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        const uint32_t qm = qe[d] & sm.bm[d];
+        const uint32_t xm = (LM1 * 0x01010101u - qe[d]) & sm.bm[d];      // (L1 - q) per byte, no borrows: q <= L1
+        const uint32_t one = sm.bm[d] & 0x01010101u;
+        sq_ = udot4(qm, 0x01010101u, sq_);
+        sqq = udot4(qm, qm, sqq);
+#pragma unroll
+        for (int p = 0; p < CH; p++) {
+            ssum[p] = udot4(pl[p][d], one, ssum[p]);
+            satb[p] = udot4(pl[p][d], xm, satb[p]);
+        }
+    }
+    const float sum_q = (float)sq_, sum_qq = (float)sqq, cnt = (float)sm.n;
+    const float cxx = cnt * (L1 * L1) - (2.0f * L1) * sum_q + sum_qq;
+    const float cyy = sum_qq;
+    const float cxy = L1 * sum_q - sum_qq;
+    const float det = cxx * cyy - cxy * cxy;
+    const float scale = L1 * ispc_rcp(det, T);
+    const bool flat = fabsf(det) < 0.001f;
+    const float rcnt = ispc_rcp(cnt, T);
+#pragma unroll
+    for (int p = 0; p < CH; p++) {
+        const float sum = (float)ssum[p], atb1 = (float)satb[p];
+        const float atb2 = L1 * sum - atb1;
+        const float e0 = (atb1 * cyy - atb2 * cxy) * scale;
+        const float e1 = (atb2 * cxx - atb1 * cxy) * scale;
+        const float mean = sum * rcnt;
+        ep[0][p] = flat ? mean : e0;
+        ep[1][p] = flat ? mean : e1;
+    }
+}
+
+} // namespace itw
