@@ -400,7 +400,7 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
             ep[0][3] = 0.f; ep[1][3] = 0.f;
             refit_line<M.bits, M.ch>(ep, ln.tx.pl, w.qb, sm[j], ln.T);
             quant_mode<MODE, false>(q[j], d, ep, settings_channels);       // :1343 passes the profile's channel count
-            sg[j] = make_segment<M.ch>(d);
+            sg[j] = make_segment<M.bits, M.ch>(d);
         }
         if (M.pairs == 2) sg[2] = sg[1];
         uint32_t qb[2];
@@ -454,11 +454,11 @@ __device__ __forceinline__ void modes_02(Lane& ln, const bc7_enc_settings& S)
             int32_t q[2][4], d[2][4];
             if (do0) {
                 quant_mode<0, true>(q, d, fit, 3);
-                select_subset<3, 3>(q0, e0, ln.tx, make_segment<3>(d), sm.bits);
+                select_subset<3, 3>(q0, e0, ln.tx, make_segment<3, 3>(d), sm.bits);
             }
             if (do2) {
                 quant_mode<2, true>(q, d, fit, 3);
-                select_subset<2, 3>(q2, e2, ln.tx, make_segment<3>(d), sm.bits);
+                select_subset<2, 3>(q2, e2, ln.tx, make_segment<2, 3>(d), sm.bits);
             }
         }
         if (do0 && e0 < b0.err) take(b0, e0, q0, 64 + part, part);
@@ -513,15 +513,20 @@ __device__ __forceinline__ void two_subset_modes(Lane& ln, const bc7_enc_setting
                 int32_t q[2][4], d[2][4];
                 if (FAMILY7) {
                     quant_mode<7, true>(q, d, fit, 4);
-                    select_subset<2, 4>(qa, ea, ln.tx, make_segment<4>(d), sm.bits);
+                    select_subset<2, 4>(qa, ea, ln.tx, make_segment<2, 4>(d), sm.bits);
                 } else {
-                    if (na > 0) {
+                    if (na > 0 && nb > 0) {
                         quant_mode<1, true>(q, d, fit, 3);
-                        select_subset<3, 3>(qa, ea, ln.tx, make_segment<3>(d), sm.bits);
-                    }
-                    if (nb > 0) {
+                        const Segment s1 = make_segment<3, 3>(d);
                         quant_mode<3, true>(q, d, fit, 3);
-                        select_subset<2, 3>(qc, ec, ln.tx, make_segment<3>(d), sm.bits);
+                        const Segment s3 = make_segment<2, 3>(d);
+                        select_subset2<3, 2, 3>(qa, ea, qc, ec, ln.tx, s1, s3, sm.bits);
+                    } else if (na > 0) {
+                        quant_mode<1, true>(q, d, fit, 3);
+                        select_subset<3, 3>(qa, ea, ln.tx, make_segment<3, 3>(d), sm.bits);
+                    } else {
+                        quant_mode<3, true>(q, d, fit, 3);
+                        select_subset<2, 3>(qc, ec, ln.tx, make_segment<2, 3>(d), sm.bits);
                     }
                 }
             }
@@ -578,12 +583,12 @@ __device__ __forceinline__ void two_subset_modes(Lane& ln, const bc7_enc_setting
                 int32_t q[2][4], d[2][4];
                 if (FAMILY7) {
                     quant_mode<7, true>(q, d, fit, 4);
-                    sa[j] = make_segment<4>(d);
+                    sa[j] = make_segment<2, 4>(d);
                 } else {
                     quant_mode<1, true>(q, d, fit, 3);
-                    sa[j] = make_segment<3>(d);
+                    sa[j] = make_segment<3, 3>(d);
                     quant_mode<3, true>(q, d, fit, 3);
-                    sc[j] = make_segment<3>(d);
+                    sc[j] = make_segment<2, 3>(d);
                 }
             }
             sa[2] = sa[1]; sc[2] = sc[1];
@@ -703,7 +708,7 @@ __device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const La
     uint32_t qb[2];
     Segment sg[3];
     quant_mode<MODE, true>(q, d, fit, 3);
-    sg[0] = make_segment<3>(d); sg[1] = sg[0]; sg[2] = sg[0];
+    sg[0] = make_segment<BITS, 3>(d); sg[1] = sg[0]; sg[2] = sg[0];
     int32_t err = select_block<BITS, 3, 1>(qb, rot, sg, 0u);
     const int iters = S.refineIterations[MODE];
     for (int it = 0; it < iters; it++) {
@@ -711,7 +716,7 @@ __device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const La
         ep[0][3] = 0.f; ep[1][3] = 0.f;
         refit_line<BITS, 3>(ep, rot.pl, qb, all, ln.T);
         quant_mode<MODE, false>(q, d, ep, 3);
-        sg[0] = make_segment<3>(d);
+        sg[0] = make_segment<BITS, 3>(d);
         err = select_block<BITS, 3, 1>(qb, rot, sg, 0u);
     }
 
@@ -806,13 +811,13 @@ __device__ __forceinline__ void mode_6(Lane& ln, const bc7_enc_settings& S)
     fit_line<CH>(ep, ln.tx, 0xffffu, st, rcp_of_count(16), ln.T);
     if (CH == 3) { ep[0][3] = 255.f; ep[1][3] = 255.f; }
     quant_mode<6, true>(q, d, ep, CH);
-    sg[0] = make_segment<CH>(d); sg[1] = sg[0]; sg[2] = sg[0];
+    sg[0] = make_segment<4, CH>(d); sg[1] = sg[0]; sg[2] = sg[0];
     int32_t err = select_block<4, CH, 1>(qb, ln.tx, sg, 0u);
     const int iters = S.refineIterations[6];
     for (int it = 0; it < iters; it++) {
         refit_line<4, CH>(ep, ln.tx.pl, qb, all, ln.T);
         quant_mode<6, false>(q, d, ep, CH);
-        sg[0] = make_segment<CH>(d);
+        sg[0] = make_segment<4, CH>(d);
         err = select_block<4, CH, 1>(qb, ln.tx, sg, 0u);
     }
     if (err < ln.best_err) {

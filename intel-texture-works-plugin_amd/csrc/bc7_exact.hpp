@@ -33,6 +33,12 @@ __device__ __forceinline__ int32_t dot2(uint32_t a, uint32_t b, int32_t c)
     return __builtin_amdgcn_sdot2(as_s16x2(a), as_s16x2(b), c, false);
 }
 __device__ __forceinline__ uint32_t udot4(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_udot4(a, b, c, false); }
+// 16-bit VOP2 forms (2-cycle issue on gfx950, tools/ubench); operands are the low halves, the result is zero-extended.
+// hipcc does not select them from C++ shorts here (it widens to v_mul_lo_u32 / v_mad_u64_u32), hence the asm.
+__device__ __forceinline__ uint32_t mul_lo_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_mul_lo_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t add_u16(uint32_t a, uint32_t b) { uint32_t d; asm("v_add_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t add32_u16(uint32_t a) { uint32_t d; asm("v_add_u16 %0, 32, %1" : "=v"(d) : "v"(a)); return d; }
+__device__ __forceinline__ uint32_t ashr6_i16(uint32_t a) { uint32_t d; asm("v_ashrrev_i16 %0, 6, %1" : "=v"(d) : "v"(a)); return d; }
 __device__ __forceinline__ uint32_t pack16(int32_t lo, int32_t hi) { return (uint32_t)lo | ((uint32_t)hi << 16); }   // both in [0,65535]
 __device__ __forceinline__ int32_t imed3(int32_t v, int32_t lo, int32_t hi) { return min(max(v, lo), hi); }
 
@@ -213,72 +219,130 @@ __device__ __forceinline__ void fit_line(float (&ep)[2][4], const Tex& tx, uint3
 }
 
 // ---- index selection (kernel.ispc:1133-1193 block_quant) in integers ----------------------------------
-// One segment = the two dequantised endpoints of a subset, as 16-bit channel pairs.
+// One segment = the two dequantised endpoints of a subset.  Channels 0,1 travel as a 16-bit pair; with CH == 4
+// channels 2,3 are a second pair, with CH == 3 channel 2 is a plain int32 (its arithmetic then runs on the
+// 2-cycle 16/32-bit VOP2 forms instead of 4-cycle packed ops; measured issue costs: tools/ubench).
 struct Segment {
-    uint32_t a01, a23;      // endpoint 0:  c0 | c1 << 16,  c2 | c3 << 16
-    uint32_t ba01, ba23;    // endpoint 1 - endpoint 0, per channel (signed 16-bit pairs)
-    float dn, rn;           // -|b-a|^2 and its correctly rounded reciprocal (0 when the segment is a point)
+    uint32_t a01, ba01;     // endpoint 0: c0 | c1 << 16;  endpoint 1 - endpoint 0 per channel (signed halves)
+    uint32_t a23, ba23;     // CH == 4: the same for c2, c3.  CH == 3: c2 of endpoint 0 and (b2 - a2) as int32
+    float k0, k1;           // BITS <= 3: -LEVELS/|b-a|^2 and 0.5 + 1/(4|b-a|^2);  BITS == 4: -|b-a|^2 and its reciprocal
 };
 
 // d[0], d[1]: endpoints as the decoder reconstructs them, [0,255].  CH==3 drops channel 3 from the metric.
-template <int CH>
+template <int BITS, int CH>
 __device__ __forceinline__ Segment make_segment(const int32_t (&d)[2][4])
 {
     Segment s;
     s.a01 = pack16(d[0][0], d[0][1]);
-    s.a23 = pack16(d[0][2], CH == 4 ? d[0][3] : 0);
-    const uint32_t b01 = pack16(d[1][0], d[1][1]);
-    const uint32_t b23 = pack16(d[1][2], CH == 4 ? d[1][3] : 0);
-    s.ba01 = pk_sub(b01, s.a01);
-    s.ba23 = pk_sub(b23, s.a23);
-    const int32_t dd = dot2(s.ba01, s.ba01, dot2(s.ba23, s.ba23, 0));
-    s.dn = -(float)dd;
-    s.rn = (dd == 0) ? 0.0f : 1.0f / s.dn;           // IEEE divide, once per segment
+    s.ba01 = pk_sub(pack16(d[1][0], d[1][1]), s.a01);
+    int32_t dd;
+    if (CH == 4) {
+        s.a23 = pack16(d[0][2], d[0][3]);
+        s.ba23 = pk_sub(pack16(d[1][2], d[1][3]), s.a23);
+        dd = dot2(s.ba01, s.ba01, dot2(s.ba23, s.ba23, 0));
+    } else {
+        const int32_t ba2 = d[1][2] - d[0][2];
+        s.a23 = (uint32_t)d[0][2];
+        s.ba23 = (uint32_t)ba2;
+        dd = dot2(s.ba01, s.ba01, ba2 * ba2);
+    }
+    const float dn = -(float)dd;
+    if (BITS <= 3) {
+        s.k0 = (dd == 0) ? 0.0f : (float)(1 << BITS) / dn;                 // IEEE divides, once per segment
+        s.k1 = (dd == 0) ? 0.5f : 0.5f + (-0.25f) / dn;
+    } else {
+        s.k0 = dn;
+        s.k1 = (dd == 0) ? 0.0f : 1.0f / dn;
+    }
     return s;
 }
 
 // packed interpolation weight (w | w << 16) of index q; the format's tables (kernel.ispc:675-686)
 template <int BITS>
-__device__ __forceinline__ uint32_t weight_pair(int32_t q)
+__device__ __forceinline__ uint32_t weight_selector(int32_t q) { return (uint32_t)q * 0x00010001u + 0x0c000c00u; }
+template <int BITS>
+__device__ __forceinline__ uint32_t weight_from_selector(uint32_t sel)
 {
-    if (BITS == 2) return __builtin_amdgcn_perm(0u, 0x402b1500u, (uint32_t)q * 0x00010001u + 0x0c000c00u);           // 0 21 43 64
-    if (BITS == 3) return __builtin_amdgcn_perm(0x40372e25u, 0x1b120900u, (uint32_t)q * 0x00010001u + 0x0c000c00u);  // 0 9 18 27 37 46 55 64
-    return (((uint32_t)q * 68u + 8u) >> 4) * 0x00010001u;                                                               // 0 4 9 13 ... 60 64
+    if (BITS == 2) return __builtin_amdgcn_perm(0u, 0x402b1500u, sel);                 // 0 21 43 64
+    return __builtin_amdgcn_perm(0x40372e25u, 0x1b120900u, sel);                       // 0 9 18 27 37 46 55 64
 }
+__device__ __forceinline__ uint32_t weight_pair4(int32_t q) { return (((uint32_t)q * 68u + 8u) >> 4) * 0x00010001u; }   // 0 4 9 13 ... 60 64
 
 // One texel against one segment: the reference projects the texel on the segment, rounds to an index q1 in
 // [1, LEVELS-1], decodes q1-1 and q1 and keeps the closer (ties: q1).  Returns index and squared error.
+// t01 = c0 | c1 << 16 of the texel; t23 = c2 | c3 << 16 (CH == 4) or c2 (CH == 3).
 //
 // Exactness.  With integer texel t and endpoints a, b:  N = sum (t-a)(b-a) and D = sum (b-a)^2 are integers
-// below 2^18, so the reference's float N, D are exact; it then forms RN(N/D) with a true divide (`proj /= div`,
-// kernel.ispc:1158), x = RN(RN(N/D)*LEVELS + 0.5) and truncates.  Here: q0 = RN(M*rn) with M = -N, rn = RN(1/-D);
-// rem = M - q0*(-D) is exact in fp32 (an integer multiple of ulp(q0) below 2^19 ulps); RN(q0 + rem*rn) = RN(N/D)
-// because N/D is a ratio of integers < 2^18 and therefore never within 2^-19 ulp of a rounding boundary.  The
-// multiply by LEVELS is exact, so one FMA gives x.  D == 0 (segment is a point): the reference gets 0/0 = NaN ->
-// cvttps2dq INT_MIN -> clamp 1; here rn = 0 -> x = 0.5 -> 0 -> clamp 1.
+// below 2^18 (D <= 260100), so the reference's float N, D are exact; it forms p = RN(N/D) with a true divide
+// (`proj /= div`, kernel.ispc:1158), x = RN(p*LEVELS + 0.5) (p*LEVELS is exact) and truncates, then clamps to
+// [1, LEVELS-1].  Write y = N*LEVELS/D.
+// (1) The reference's index equals clamp(floor(y + 0.5)).  For an integer m in [2, LEVELS-1]: if y + 0.5 >= m,
+//     monotonicity of RN gives x >= m (m - 0.5 and m are representable).  Otherwise 2*N*LEVELS <= (2m-1)*D - 1, i.e.
+//     y + 0.5 <= m - 1/(2D) with 1/(2D) >= 1.92e-6, while the two roundings raise x by at most 15.5*2^-24 (divide) plus
+//     2^-21 (add, x < 16) = 1.4e-6 in total, so x < m.  Below 1 and above LEVELS-1 the clamp decides; truncation and
+//     floor only differ for x in (-1,0), which clamps to 1 either way.
+// (2) BITS <= 3: x~ = RN(M*k0 + k1) with M = -N exact, k0 = RN(-LEVELS/D), k1 = RN(0.5 + 1/(4D)).  By (1) the true value
+//     y + 0.5 + 1/(4D) is >= m + 1/(4D) or <= m - 1/(4D).  |x~ - true| <= 6.5*2^-24 (k0) + 2^-25 (k1) + 2^-22 (fma, x~ < 8)
+//     = 6.6e-7 for 3 bits -- used by 3-channel modes only, where D <= 195075 and 1/(4D) >= 1.28e-6 -- and
+//     <= 2.5*2^-24 + 2^-25 + 2^-23 = 3.0e-7 for 2 bits, where 1/(4D) >= 9.6e-7 even with 4 channels.  Hence
+//     floor(x~) = floor(y + 0.5) wherever the clamp does not decide.
+// (3) BITS == 4 (mode 6): q0 = RN(M*rn), rn = RN(1/-D); rem = M - q0*(-D) is exact in fp32 (an integer multiple of
+//     ulp(q0) below 2^19 ulps); RN(q0 + rem*rn) = RN(N/D) because a ratio of integers < 2^18 is never within 2^-19 ulp
+//     of a rounding boundary; then one FMA gives x exactly as the reference computes it.
+// D == 0 (segment is a point): the reference gets 0/0 = NaN -> cvttps2dq INT_MIN -> clamp 1; here x = 0.5 -> 0 -> 1.
 // Decode (kernel.ispc:1172-1173): (int)(((64-w)*a + w*b + 32)/64), all exact integers, = a + ((w*(b-a)+32) >> 6)
 // with an arithmetic shift.  Errors are sums of <= 4 squares of integers in [-255,255].
-template <int BITS>
+template <int BITS, int CH>
 __device__ __forceinline__ void select_texel(int32_t& q_out, int32_t& e_out, const Segment& sg, uint32_t t01, uint32_t t23)
 {
     constexpr int LEVELS = 1 << BITS;
-    const uint32_t at01 = pk_sub(sg.a01, t01), at23 = pk_sub(sg.a23, t23);
-    const int32_t m = dot2(at01, sg.ba01, dot2(at23, sg.ba23, 0));
+    const uint32_t at01 = pk_sub(sg.a01, t01);
+    uint32_t at23;
+    int32_t m;
+    if (CH == 4) {
+        at23 = pk_sub(sg.a23, t23);
+        m = dot2(at01, sg.ba01, dot2(at23, sg.ba23, 0));
+    } else {
+        at23 = sg.a23 - t23;                                   // int32, [-255,255]
+        m = dot2(at01, sg.ba01, (int32_t)at23 * (int32_t)sg.ba23);
+    }
     const float mf = (float)m;
-    float q = mf * sg.rn;
-    const float rem = __builtin_fmaf(-q, sg.dn, mf);
-    q = __builtin_fmaf(rem, sg.rn, q);
-    const float x = __builtin_fmaf(q, (float)LEVELS, 0.5f);
+    float x;
+    if (BITS <= 3) {
+        x = __builtin_fmaf(mf, sg.k0, sg.k1);
+    } else {
+        float q = mf * sg.k1;
+        const float rem = __builtin_fmaf(-q, sg.k0, mf);
+        q = __builtin_fmaf(rem, sg.k1, q);
+        x = __builtin_fmaf(q, (float)LEVELS, 0.5f);
+    }
     const int32_t q1 = imed3((int32_t)x, 1, LEVELS - 1);
 
+    uint32_t w0, w1;
+    if (BITS <= 3) {
+        const uint32_t sel = weight_selector<BITS>(q1);
+        w1 = weight_from_selector<BITS>(sel);
+        w0 = weight_from_selector<BITS>(sel - 0x00010001u);
+    } else {
+        w1 = weight_pair4(q1); w0 = weight_pair4(q1 - 1);
+    }
     const s16x2 k32 = {32, 32}, six = {6, 6};
-    const uint32_t w1 = weight_pair<BITS>(q1), w0 = weight_pair<BITS>(q1 - 1);
     const uint32_t x0_01 = pk_add(as_u32((as_s16x2(w0) * as_s16x2(sg.ba01) + k32) >> six), at01);
-    const uint32_t x0_23 = pk_add(as_u32((as_s16x2(w0) * as_s16x2(sg.ba23) + k32) >> six), at23);
     const uint32_t x1_01 = pk_add(as_u32((as_s16x2(w1) * as_s16x2(sg.ba01) + k32) >> six), at01);
-    const uint32_t x1_23 = pk_add(as_u32((as_s16x2(w1) * as_s16x2(sg.ba23) + k32) >> six), at23);
-    const int32_t e0 = dot2(x0_01, x0_01, dot2(x0_23, x0_23, 0));
-    const int32_t e1 = dot2(x1_01, x1_01, dot2(x1_23, x1_23, 0));
+    int32_t e0, e1;
+    if (CH == 4) {
+        const uint32_t x0_23 = pk_add(as_u32((as_s16x2(w0) * as_s16x2(sg.ba23) + k32) >> six), at23);
+        const uint32_t x1_23 = pk_add(as_u32((as_s16x2(w1) * as_s16x2(sg.ba23) + k32) >> six), at23);
+        e0 = dot2(x0_01, x0_01, dot2(x0_23, x0_23, 0));
+        e1 = dot2(x1_01, x1_01, dot2(x1_23, x1_23, 0));
+    } else {
+        // third channel on the 2-cycle 16-bit VOP2 forms (results in bits 15:0, upper half zero on gfx9):
+        // |w*(b-a) + 32| <= 16352 and |x| <= 255 fit int16; x*x <= 65025 fits uint16
+        const uint32_t x0 = add_u16(ashr6_i16(add32_u16(mul_lo_u16(w0, sg.ba23))), at23);
+        const uint32_t x1 = add_u16(ashr6_i16(add32_u16(mul_lo_u16(w1, sg.ba23))), at23);
+        e0 = dot2(x0_01, x0_01, (int32_t)mul_lo_u16(x0, x0));
+        e1 = dot2(x1_01, x1_01, (int32_t)mul_lo_u16(x1, x1));
+    }
     const bool first = e0 < e1;
     q_out = first ? q1 - 1 : q1;
     e_out = min(e0, e1);
@@ -289,7 +353,7 @@ __device__ __forceinline__ Segment pick_segment(const Segment& s0, const Segment
     Segment r;
     r.a01 = one ? s1.a01 : s0.a01; r.a23 = one ? s1.a23 : s0.a23;
     r.ba01 = one ? s1.ba01 : s0.ba01; r.ba23 = one ? s1.ba23 : s0.ba23;
-    r.dn = one ? s1.dn : s0.dn; r.rn = one ? s1.rn : s0.rn;
+    r.k0 = one ? s1.k0 : s0.k0; r.k1 = one ? s1.k1 : s0.k1;
     return r;
 }
 
@@ -311,7 +375,7 @@ __device__ __forceinline__ int32_t select_block(uint32_t (&qb)[2], const Tex& tx
             if (PAIRS == 3) s = pick_segment(s, sg[2], j == 2u);
         }
         int32_t q, e;
-        select_texel<BITS>(q, e, s, tx.pair01(k), tx.template pair23<CH == 4>(k));
+        select_texel<BITS, CH>(q, e, s, tx.pair01(k), tx.template pair23<CH == 4>(k));
         if (k < 8) qb[0] |= (uint32_t)q << (4 * k); else qb[1] |= (uint32_t)q << (4 * (k - 8));
         total += e;
     }
@@ -326,9 +390,28 @@ __device__ __forceinline__ void select_subset(uint32_t (&qb)[2], int32_t& total,
     for (int k = 0; k < 16; k++) {
         if ((mask >> k) & 1u) {
             int32_t q, e;
-            select_texel<BITS>(q, e, sg, tx.pair01(k), tx.template pair23<CH == 4>(k));
+            select_texel<BITS, CH>(q, e, sg, tx.pair01(k), tx.template pair23<CH == 4>(k));
             if (k < 8) qb[0] |= (uint32_t)q << (4 * k); else qb[1] |= (uint32_t)q << (4 * (k - 8));
             total += e;
+        }
+    }
+}
+
+// Two modes at once over the texels of one subset (the two dependency chains interleave).
+template <int BITSA, int BITSB, int CH>
+__device__ __forceinline__ void select_subset2(uint32_t (&qa)[2], int32_t& ta, uint32_t (&qc)[2], int32_t& tc, const Tex& tx,
+                                               const Segment& sa, const Segment& sc, uint32_t mask)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if ((mask >> k) & 1u) {
+            const uint32_t t01 = tx.pair01(k), t23 = tx.template pair23<CH == 4>(k);
+            int32_t q0, e0, q1, e1;
+            select_texel<BITSA, CH>(q0, e0, sa, t01, t23);
+            select_texel<BITSB, CH>(q1, e1, sc, t01, t23);
+            if (k < 8) { qa[0] |= (uint32_t)q0 << (4 * k); qc[0] |= (uint32_t)q1 << (4 * k); }
+            else       { qa[1] |= (uint32_t)q0 << (4 * (k - 8)); qc[1] |= (uint32_t)q1 << (4 * (k - 8)); }
+            ta += e0; tc += e1;
         }
     }
 }
