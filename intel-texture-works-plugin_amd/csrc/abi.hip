@@ -214,10 +214,20 @@ __global__ void k_test_rcp(const float* in, float* out, int64_t n)
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = itw::ispc_rcp(in[i], itw::global_seed_tables());
 }
+// Both implementations on every element: the general model on the global tables and the LDS fast path the BC7
+// kernels use.  Where they disagree the output is corrupted on purpose so the oracle comparison fails.
 __global__ void k_test_rsqrt(const float* in, float* out, int64_t n)
 {
+    __shared__ unsigned short s16[2048];
+    __shared__ uint32_t s32[2048];
+    const itw::SeedTables T = itw::stage_seed_tables_fast(s16, s32, threadIdx.x, blockDim.x);
+    __syncthreads();
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = itw::ispc_rsqrt(in[i], itw::global_seed_tables());
+    if (i >= n) return;
+    const float g = itw::ispc_rsqrt<false>(in[i], itw::global_seed_tables());
+    const float f = itw::ispc_rsqrt<true>(in[i], T);
+    const uint32_t gb = __float_as_uint(g), fb = __float_as_uint(f);
+    out[i] = (gb == fb) ? g : ((g != g) ? 0.0f : __uint_as_float(gb ^ 1u));
 }
 __global__ void k_test_f2i(const float* in, int32_t* out, int64_t n)
 {

@@ -44,6 +44,7 @@ namespace itw {
 constexpr int TPB = 256;                  // four waves share one staged seed table
 constexpr float INV255 = 1.0f / 255.0f;   // x/255f under fast-math = x*(1.f/255.f)
 constexpr int32_t ERR_MAX = 0x7fffffff;
+enum Family { F_MODES02 = 0, F_MODES13 = 1, F_MODE7 = 2, F_MODES456 = 3 };
 
 struct ModeTraits { int pairs, bits, ch; };
 __device__ __forceinline__ constexpr ModeTraits traits(int mode)
@@ -357,7 +358,7 @@ __device__ __forceinline__ int32_t rank_key(int shape, const Tex& tx, const Stat
     stats_int<RANK_CH>(s0, tx.pl, sm);
     Stats<RANK_CH> f0;
     stats_float<RANK_CH>(f0, s0);
-    return (int32_t)((uint32_t)shape + (uint32_t)split_bound_from<RANK_CH>(f0, full, T) * 64u);
+    return (int32_t)((uint32_t)shape + (uint32_t)split_bound_from<RANK_CH, true>(f0, full, T) * 64u);
 }
 
 // Least-squares refinement of a mode's winner, then the mode competes for the block.  [kernel.ispc:1329-1362]
@@ -429,9 +430,8 @@ __device__ __forceinline__ void take(Win& w, int32_t err, const uint32_t (&qb)[2
 
 // modes 0 and 2: three subsets; shapes in table order (wave-uniform), one fit per subset.  [kernel.ispc:1386-1394]
 // List order == table order, so the reference's strict `<` is reproduced by a strict `<`.
-__device__ __forceinline__ void modes_02(Lane& ln, const bc7_enc_settings& S)
+__device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, Win& b0, Win& b2)
 {
-    Win b0, b2;
     reset(b0, 64); reset(b2, 64);
     IStats<3> full;
     stats_int<3>(full, ln.tx.pl, whole_block());
@@ -444,6 +444,7 @@ __device__ __forceinline__ void modes_02(Lane& ln, const bc7_enc_settings& S)
         IStats<3> rest = full;
         #pragma unroll 1
         for (int j = 0; j < 3; j++) {
+            ln.tx.fence();                                // texel-derived values are used once per shape: do not hoist
             const SubsetMask sm = subset_of(64 + part, j);
             IStats<3> st;
             if (j < 2) stats_int<3>(st, ln.tx.pl, sm); else st = rest;
@@ -464,21 +465,19 @@ __device__ __forceinline__ void modes_02(Lane& ln, const bc7_enc_settings& S)
         if (do0 && e0 < b0.err) take(b0, e0, q0, 64 + part, part);
         if (do2 && e2 < b2.err) take(b2, e2, q2, 64 + part, part);
     }
-    refine_and_commit<0>(ln, b0, S.refineIterations[0], S.channels);
-    if (!S.skip_mode2) refine_and_commit<2>(ln, b2, S.refineIterations[2], S.channels);
 }
 
 // Two-subset modes.  FAMILY7 = false: modes 1 and 3 (3-channel fit, shared);  true: mode 7 (4-channel fit).
 // RANK_CH: channels used by the PCA ranking (3 for modes 1/3; the profile's channel count for mode 7).
-template <bool FAMILY7, int RANK_CH>
-__device__ __forceinline__ void two_subset_modes(Lane& ln, const bc7_enc_settings& S)
+// RANKED: at least one of the family's lists is a proper prefix of the PCA ranking (fast profiles).
+template <bool FAMILY7, int RANK_CH, bool RANKED>
+__device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settings& S, Win& wa, Win& wb)
 {
     constexpr int FIT_CH = FAMILY7 ? 4 : 3;
     const int na = FAMILY7 ? S.fastSkipTreshold_mode7 : S.fastSkipTreshold_mode1;   // first mode of the family
     const int nb = FAMILY7 ? 0 : S.fastSkipTreshold_mode3;                           // second mode
-    if (na <= 0 && nb <= 0) return;
-    Win wa, wb;
     reset(wa, 0); reset(wb, 0);
+    if (na <= 0 && nb <= 0) return;
 
     IStats<FIT_CH> full;
     stats_int<FIT_CH>(full, ln.tx.pl, whole_block());
@@ -493,8 +492,7 @@ __device__ __forceinline__ void two_subset_modes(Lane& ln, const bc7_enc_setting
         stats_float<RANK_CH>(rfull, t);
     }
 
-    const bool whole_table = (na <= 0 || na >= 64) && (nb <= 0 || nb >= 64);
-    if (whole_table) {
+    if (!RANKED) {
         // every shape is a candidate: table order; the rank key is only needed to order shapes of equal error
         for (int part = 0; part < 64; part++) {
             ln.tx.fence();
@@ -503,6 +501,7 @@ __device__ __forceinline__ void two_subset_modes(Lane& ln, const bc7_enc_setting
             IStats<FIT_CH> rest = full;
             #pragma unroll 1
             for (int j = 0; j < 2; j++) {
+                ln.tx.fence();                            // texel-derived values are used once per shape: do not hoist
                 const SubsetMask sm = subset_of(part, j);
                 IStats<FIT_CH> st;
                 if (j == 0) stats_int<FIT_CH>(st, ln.tx.pl, sm); else st = rest;
@@ -607,12 +606,6 @@ __device__ __forceinline__ void two_subset_modes(Lane& ln, const bc7_enc_setting
                 }
             }
         }
-    }
-    if (FAMILY7) {
-        refine_and_commit<7>(ln, wa, S.refineIterations[7], S.channels);
-    } else {
-        if (na > 0) refine_and_commit<1>(ln, wa, S.refineIterations[1], S.channels);
-        if (nb > 0) refine_and_commit<3>(ln, wb, S.refineIterations[3], S.channels);
     }
 }
 
@@ -827,39 +820,91 @@ __device__ __forceinline__ void mode_6(Lane& ln, const bc7_enc_settings& S)
     }
 }
 
-// ---- kernels: one per mode family ------------------------------------------------------------------
-enum Family { F_MODES02 = 0, F_MODES13 = 1, F_MODE7 = 2, F_MODES456 = 3 };
-
-template <int FAMILY, bool VEC16>
-__global__ void __launch_bounds__(TPB)
-bc7_family_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
-                  uint8_t* __restrict__ dst, int32_t* __restrict__ err_ws, const bc7_enc_settings S, const int first)
+// ---- kernels ----------------------------------------------------------------------------------------
+// Per multi-subset family two kernels: SEARCH (scan of the shapes; low register pressure, runs at 3-4 waves per SIMD)
+// leaves each mode's winner {indices, error, shape} in the workspace, FINISH refines the winners and lets them compete
+// for the block.  Modes 4/5/6 are one kernel.  Splitting keeps the register allocation of the scan independent of the
+// (per-lane shape, fully unrolled) refinement code.
+template <bool VEC16>
+__device__ __forceinline__ void load_block(Tex& tx, const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t b)
 {
-    __shared__ unsigned short s_seed[4096];
-    extern __shared__ int32_t s_keys[];            // 64 * TPB keys, only allocated for ranked lists
-    Lane ln;
-    ln.T = stage_seed_tables(s_seed, threadIdx.x, TPB);
-    __syncthreads();
-
-    const int32_t gid = blockIdx.x * TPB + threadIdx.x;
-    const bool live = gid < nblocks;
-    const int32_t b = live ? gid : nblocks - 1;    // idle lanes of the last workgroup redo its last block, store nothing
     const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
-
-    ln.keys = s_keys + threadIdx.x;
     const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 16;
 #pragma unroll
     for (int y = 0; y < 4; y++) {
         if (VEC16) {
             const uint4 v = *reinterpret_cast<const uint4*>(p + y * stride);
-            ln.tx.w[y * 4 + 0] = v.x; ln.tx.w[y * 4 + 1] = v.y; ln.tx.w[y * 4 + 2] = v.z; ln.tx.w[y * 4 + 3] = v.w;
+            tx.w[y * 4 + 0] = v.x; tx.w[y * 4 + 1] = v.y; tx.w[y * 4 + 2] = v.z; tx.w[y * 4 + 3] = v.w;
         } else {
             const uint32_t* q = reinterpret_cast<const uint32_t*>(p + y * stride);
             #pragma unroll
-            for (int x = 0; x < 4; x++) ln.tx.w[y * 4 + x] = q[x];
+            for (int x = 0; x < 4; x++) tx.w[y * 4 + x] = q[x];
         }
     }
-    ln.tx.make_planar();
+    tx.make_planar();
+}
+
+// winners of a family's two modes: [slot][block] x {qb0, qb1, err, shape}
+__device__ __forceinline__ void store_win(uint4* __restrict__ wins, int32_t nblocks, int slot, int32_t b, const Win& w)
+{
+    wins[(int64_t)slot * nblocks + b] = make_uint4(w.qb[0], w.qb[1], (uint32_t)w.err, (uint32_t)w.shape);
+}
+__device__ __forceinline__ void load_win(Win& w, const uint4* __restrict__ wins, int32_t nblocks, int slot, int32_t b)
+{
+    const uint4 v = wins[(int64_t)slot * nblocks + b];
+    w.qb[0] = v.x; w.qb[1] = v.y; w.err = (int32_t)v.z; w.shape = (int32_t)v.w; w.key = -1;
+}
+
+// Register budgets (waves per SIMD) were picked by measurement on MI355X: the scans are bound by dependent-issue
+// and LDS latency at 2 waves, and tolerate a few spilled cold values to reach 3-4.
+__host__ __device__ constexpr int search_waves(int family, bool ranked) { return ranked ? 2 : (family == F_MODE7 ? 3 : 4); }
+__host__ __device__ constexpr int finish_waves(int family) { return family == F_MODES456 ? 3 : 3; }
+
+template <int FAMILY, bool RANKED, bool VEC16>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(search_waves(FAMILY, RANKED), search_waves(FAMILY, RANKED))))
+bc7_search_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
+                  uint4* __restrict__ wins, const bc7_enc_settings S)
+{
+    __shared__ unsigned short s_seed16[2048];
+    __shared__ uint32_t s_seed32[2048];
+    extern __shared__ int32_t s_keys[];            // 64 * TPB keys, only allocated for ranked lists
+    Lane ln;
+    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
+    __syncthreads();
+    const int32_t gid = blockIdx.x * TPB + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;    // idle lanes of the last workgroup redo its last block, store nothing
+    ln.keys = s_keys + threadIdx.x;
+    load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
+
+    Win wa, wb;
+    if (FAMILY == F_MODES02) search_02(ln, S, wa, wb);
+    if (FAMILY == F_MODES13) search_two_subset<false, 3, RANKED>(ln, S, wa, wb);
+    if (FAMILY == F_MODE7) {
+        if (S.channels == 4) search_two_subset<true, 4, RANKED>(ln, S, wa, wb); else search_two_subset<true, 3, RANKED>(ln, S, wa, wb);
+    }
+    if (live) {
+        store_win(wins, nblocks, 0, b, wa);
+        if (FAMILY != F_MODE7) store_win(wins, nblocks, 1, b, wb);
+    }
+}
+
+template <int FAMILY, bool VEC16>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(finish_waves(FAMILY), finish_waves(FAMILY))))
+bc7_finish_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
+                  uint8_t* __restrict__ dst, int32_t* __restrict__ err_ws, const uint4* __restrict__ wins,
+                  const bc7_enc_settings S, const int first)
+{
+    __shared__ unsigned short s_seed16[2048];
+    __shared__ uint32_t s_seed32[2048];
+    Lane ln;
+    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
+    __syncthreads();
+    const int32_t gid = blockIdx.x * TPB + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;
+    ln.keys = nullptr;
+    load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
 
     ln.best_err = first ? ERR_MAX : err_ws[b];
     ln.best[0] = ln.best[1] = ln.best[2] = ln.best[3] = 0u;
@@ -872,9 +917,22 @@ bc7_family_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
         ln.opaque_err = (int32_t)e;
     }
 
-    if (FAMILY == F_MODES02) modes_02(ln, S);
-    if (FAMILY == F_MODES13) two_subset_modes<false, 3>(ln, S);
-    if (FAMILY == F_MODE7) { if (S.channels == 4) two_subset_modes<true, 4>(ln, S); else two_subset_modes<true, 3>(ln, S); }
+    if (FAMILY == F_MODES02) {
+        Win w;
+        load_win(w, wins, nblocks, 0, b);
+        refine_and_commit<0>(ln, w, S.refineIterations[0], S.channels);
+        if (!S.skip_mode2) { load_win(w, wins, nblocks, 1, b); refine_and_commit<2>(ln, w, S.refineIterations[2], S.channels); }
+    }
+    if (FAMILY == F_MODES13) {
+        Win w;
+        if (S.fastSkipTreshold_mode1 > 0) { load_win(w, wins, nblocks, 0, b); refine_and_commit<1>(ln, w, S.refineIterations[1], S.channels); }
+        if (S.fastSkipTreshold_mode3 > 0) { load_win(w, wins, nblocks, 1, b); refine_and_commit<3>(ln, w, S.refineIterations[3], S.channels); }
+    }
+    if (FAMILY == F_MODE7) {
+        Win w;
+        load_win(w, wins, nblocks, 0, b);
+        refine_and_commit<7>(ln, w, S.refineIterations[7], S.channels);
+    }
     if (FAMILY == F_MODES456) {
         if (S.mode_selection[2]) modes_45(ln, S);
         if (S.mode_selection[3]) { if (S.channels == 4) mode_6<4>(ln, S); else mode_6<3>(ln, S); }
@@ -888,47 +946,62 @@ bc7_family_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
     }
 }
 
-template <int FAMILY>
-static void launch_family(bool vec, dim3 grid, size_t lds, hipStream_t st, const uint8_t* src, int64_t stride, int bx, int32_t n,
-                          uint8_t* dst, int32_t* ws, const bc7_enc_settings& S, int first)
+struct Bc7Launch {
+    bool vec; dim3 grid; hipStream_t st; const uint8_t* src; int64_t stride; int bx; int32_t n;
+    uint8_t* dst; int32_t* err; uint4* wins; bc7_enc_settings S; int first;
+};
+
+template <int FAMILY, bool RANKED>
+static void launch_search(const Bc7Launch& L)
 {
-    if (vec) hipLaunchKernelGGL((bc7_family_kernel<FAMILY, true>),  grid, dim3(TPB), lds, st, src, stride, bx, n, dst, ws, S, first);
-    else     hipLaunchKernelGGL((bc7_family_kernel<FAMILY, false>), grid, dim3(TPB), lds, st, src, stride, bx, n, dst, ws, S, first);
+    const size_t lds = RANKED ? (size_t)64 * TPB * sizeof(int32_t) : 0;
+    if (L.vec) hipLaunchKernelGGL((bc7_search_kernel<FAMILY, RANKED, true>),  L.grid, dim3(TPB), lds, L.st, L.src, L.stride, L.bx, L.n, L.wins, L.S);
+    else       hipLaunchKernelGGL((bc7_search_kernel<FAMILY, RANKED, false>), L.grid, dim3(TPB), lds, L.st, L.src, L.stride, L.bx, L.n, L.wins, L.S);
+}
+template <int FAMILY>
+static void launch_finish(Bc7Launch& L)
+{
+    if (L.vec) hipLaunchKernelGGL((bc7_finish_kernel<FAMILY, true>),  L.grid, dim3(TPB), 0, L.st, L.src, L.stride, L.bx, L.n, L.dst, L.err, L.wins, L.S, L.first);
+    else       hipLaunchKernelGGL((bc7_finish_kernel<FAMILY, false>), L.grid, dim3(TPB), 0, L.st, L.src, L.stride, L.bx, L.n, L.dst, L.err, L.wins, L.S, L.first);
+    L.first = 0;
 }
 
+// workspace: best error so far (4 B/block) + the winners of one family's two modes (2 x 16 B/block)
 size_t bc7_workspace_bytes(int width, int height)
 {
-    return (size_t)(width / 4) * (size_t)(height / 4) * sizeof(int32_t);
+    const size_t n = (size_t)(width / 4) * (size_t)(height / 4);
+    return ((n * sizeof(int32_t) + 15) & ~(size_t)15) + 2 * n * sizeof(uint4);
 }
 
 // Families run in the reference's order (kernel.ispc:1970-1977): {0,2} -> {1,3} -> {7} -> {4,5} -> {6}.
 void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
-                const bc7_enc_settings& s, float* err_ws, hipStream_t st)
+                const bc7_enc_settings& s, float* workspace, hipStream_t st)
 {
     const int bx = width / 4, by = height / 4;
     const int64_t n = (int64_t)bx * by;
     if (n <= 0) return;
-    bc7_enc_settings S = s;
-    S.channels = (s.channels == 4) ? 4 : 3;
-    int32_t* ws = reinterpret_cast<int32_t*>(err_ws);
-    const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
-    const dim3 grid((unsigned)((n + TPB - 1) / TPB));
-    const size_t key_bytes = (size_t)64 * TPB * sizeof(int32_t);
+    Bc7Launch L;
+    L.S = s;
+    L.S.channels = (s.channels == 4) ? 4 : 3;
+    L.err = reinterpret_cast<int32_t*>(workspace);
+    L.wins = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(workspace) + (((size_t)n * sizeof(int32_t) + 15) & ~(size_t)15));
+    L.vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    L.grid = dim3((unsigned)((n + TPB - 1) / TPB));
+    L.st = st; L.src = src; L.stride = stride; L.bx = bx; L.n = (int32_t)n; L.dst = dst; L.first = 1;
+    const bc7_enc_settings& S = L.S;
     auto ranked = [](int t) { return t > 0 && t < 64; };
-    int first = 1;
-    if (S.mode_selection[0]) { launch_family<F_MODES02>(vec, grid, 0, st, src, stride, bx, (int32_t)n, dst, ws, S, first); first = 0; }
+    if (S.mode_selection[0]) { launch_search<F_MODES02, false>(L); launch_finish<F_MODES02>(L); }
     if (S.mode_selection[1] && (S.fastSkipTreshold_mode1 > 0 || S.fastSkipTreshold_mode3 > 0)) {
-        const size_t lds = (ranked(S.fastSkipTreshold_mode1) || ranked(S.fastSkipTreshold_mode3)) ? key_bytes : 0;
-        launch_family<F_MODES13>(vec, grid, lds, st, src, stride, bx, (int32_t)n, dst, ws, S, first); first = 0;
+        if (ranked(S.fastSkipTreshold_mode1) || ranked(S.fastSkipTreshold_mode3)) launch_search<F_MODES13, true>(L);
+        else launch_search<F_MODES13, false>(L);
+        launch_finish<F_MODES13>(L);
     }
     if (S.mode_selection[1] && S.fastSkipTreshold_mode7 > 0) {
-        const size_t lds = ranked(S.fastSkipTreshold_mode7) ? key_bytes : 0;
-        launch_family<F_MODE7>(vec, grid, lds, st, src, stride, bx, (int32_t)n, dst, ws, S, first); first = 0;
+        if (ranked(S.fastSkipTreshold_mode7)) launch_search<F_MODE7, true>(L); else launch_search<F_MODE7, false>(L);
+        launch_finish<F_MODE7>(L);
     }
-    if (S.mode_selection[2] || S.mode_selection[3]) {
-        launch_family<F_MODES456>(vec, grid, 0, st, src, stride, bx, (int32_t)n, dst, ws, S, first); first = 0;
-    }
-    if (first) (void)hipMemsetAsync(dst, 0, (size_t)n * 16, st);   // no mode enabled: defined (zero) output
+    if (S.mode_selection[2] || S.mode_selection[3]) launch_finish<F_MODES456>(L);
+    if (L.first) (void)hipMemsetAsync(dst, 0, (size_t)n * 16, st);   // no mode enabled: defined (zero) output
 }
 
 } // namespace itw

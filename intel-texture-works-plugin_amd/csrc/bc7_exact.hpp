@@ -197,7 +197,7 @@ __device__ __forceinline__ void fit_line(float (&ep)[2][4], const Tex& tx, uint3
     cv[0] += eps; cv[4] += eps; cv[7] += eps; cv[9] += eps;
 
     float axis[4];
-    principal_axis<CH, 8>(axis, cv, T);
+    principal_axis<CH, 8, true>(axis, cv, T);
 
     float lo = __builtin_inff(), hi = -__builtin_inff();
 #pragma unroll

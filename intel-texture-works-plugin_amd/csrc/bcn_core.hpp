@@ -123,7 +123,7 @@ __device__ __forceinline__ void covariance_of(float (&cv)[10], const Stats<CH>& 
 }
 
 // Power iteration from (1,..,1), renormalised (rsqrt) after every second step.  (kernel.ispc:207-229)
-template <int CH, int ITERS>
+template <int CH, int ITERS, bool FAST = false>
 __device__ __forceinline__ void principal_axis(float (&v)[4], const float (&cv)[10], const SeedTables& T)
 {
     v[0] = v[1] = v[2] = v[3] = 1.f;
@@ -147,7 +147,7 @@ __device__ __forceinline__ void principal_axis(float (&v)[4], const float (&cv)[
             float nsq = 0.f;
             #pragma unroll
             for (int p = 0; p < CH; p++) nsq += a[p] * a[p];
-            const float rn = ispc_rsqrt(nsq, T);
+            const float rn = ispc_rsqrt<FAST>(nsq, T);
             #pragma unroll
             for (int p = 0; p < CH; p++) v[p] *= rn;
         }
@@ -205,7 +205,7 @@ __device__ __forceinline__ void fit_subset(float (&ep)[2][4], const TX& px, uint
 }
 
 // trace - largest eigenvalue (4 power iterations) of a scaled covariance.   (kernel.ispc:907-939)
-template <int CH>
+template <int CH, bool FAST = false>
 __device__ __forceinline__ float pca_residual(float (&cv)[10], const SeedTables& T)
 {
     const float inv_var = 1.0f / 65536.0f;
@@ -214,7 +214,7 @@ __device__ __forceinline__ float pca_residual(float (&cv)[10], const SeedTables&
     const float eps = 0.001f * 0.001f;
     cv[0] += eps; cv[4] += eps; cv[7] += eps;           // not cv[9]: reference quirk
     float axis[4];
-    principal_axis<CH, 4>(axis, cv, T);
+    principal_axis<CH, 4, FAST>(axis, cv, T);
     float w[4];
     if (CH == 3) {
         w[0] = cv[0] * axis[0] + cv[1] * axis[1] + cv[2] * axis[2];
@@ -238,7 +238,7 @@ __device__ __forceinline__ float pca_residual(float (&cv)[10], const SeedTables&
 
 // Lower bound on the two-subset error of a shape, as an integer sort key component:
 // (int)(sqrt(res(subset0) + res(rest)) * 256), rest = full - subset0.   (kernel.ispc:952-971, 1404-1409)
-template <int CH>
+template <int CH, bool FAST = false>
 __device__ __forceinline__ int32_t split_bound_from(const Stats<CH>& a, const Stats<CH>& full, const SeedTables& T)
 {
     float cv1[10], cv2[10];
@@ -251,8 +251,8 @@ __device__ __forceinline__ int32_t split_bound_from(const Stats<CH>& a, const St
     b.n = full.n - a.n;
     covariance_of<CH>(cv2, b, ispc_rcp(b.n, T));
     float bound = 0.f;
-    bound += pca_residual<CH>(cv1, T);
-    bound += pca_residual<CH>(cv2, T);
+    bound += pca_residual<CH, FAST>(cv1, T);
+    bound += pca_residual<CH, FAST>(cv2, T);
     return f2i_x86(sqrtf(bound) * 256.0f);
 }
 

@@ -10,11 +10,12 @@ namespace itw {
 // output tightly packed in raster block order; asynchronous on `st`.
 void launch_bc1 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
 void launch_bc3 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
-// BC7 runs as up to four kernels (one per mode family) that hand "best error so far" to each other through
-// `err_ws`: device memory, bc7_workspace_bytes(width, height) bytes, contents irrelevant on entry.
+// BC7 runs as up to seven kernels (search + finish per multi-subset mode family, one for modes 4/5/6) that hand
+// "best error so far" and the search winners to each other through
+// `workspace`: device memory, bc7_workspace_bytes(width, height) bytes, 16 B aligned, contents irrelevant on entry.
 size_t bc7_workspace_bytes(int width, int height);
 void launch_bc7 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
-                 const bc7_enc_settings& s, float* err_ws, hipStream_t st);
+                 const bc7_enc_settings& s, float* workspace, hipStream_t st);
 void launch_bc6h(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                  const bc6h_enc_settings& s, hipStream_t st);
 

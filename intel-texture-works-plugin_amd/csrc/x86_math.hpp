@@ -25,11 +25,12 @@ namespace itw {
 struct SeedTables {
     const unsigned short* rcp;     // [2048] indexed by mantissa[22:12]
     const unsigned short* rsqrt;   // [2048] indexed by {exponent parity, mantissa[22:13]}
+    const uint32_t* rsqrt32;       // [2048] LDS, fast path (see x86_rsqrtps_fast); null when not staged
 };
 
 __device__ __forceinline__ SeedTables global_seed_tables()
 {
-    return SeedTables{X86_RCP_SEED16, X86_RSQRT_SEED16};
+    return SeedTables{X86_RCP_SEED16, X86_RSQRT_SEED16, nullptr};
 }
 
 // Cooperative copy of both tables (8 KiB) into LDS; `lds` must hold 4096 ushorts.
@@ -39,7 +40,21 @@ __device__ __forceinline__ SeedTables stage_seed_tables(unsigned short* lds, int
     const uint32_t* s1 = reinterpret_cast<const uint32_t*>(X86_RSQRT_SEED16);
     uint32_t* d = reinterpret_cast<uint32_t*>(lds);
     for (int i = tid; i < 1024; i += nthreads) { d[i] = s0[i]; d[1024 + i] = s1[i]; }
-    return SeedTables{lds, lds + 2048};
+    return SeedTables{lds, lds + 2048, nullptr};
+}
+
+// LDS staging for kernels that normalise a lot (BC7): the RCPPS table as is (4 KiB at lds16) and the RSQRTPS table
+// expanded to ready-to-use words (8 KiB at lds32): entry i, indexed by bits [23:13] of the operand (exponent LSB,
+// top 10 mantissa bits), holds seed mantissa | 0.5's exponent, plus 64 << 23 so that the result's exponent is one
+// subtraction away.  `lds16` must hold 2048 ushorts, `lds32` 2048 words.
+__device__ __forceinline__ SeedTables stage_seed_tables_fast(unsigned short* lds16, uint32_t* lds32, int tid, int nthreads)
+{
+    const uint32_t* s0 = reinterpret_cast<const uint32_t*>(X86_RCP_SEED16);
+    uint32_t* d = reinterpret_cast<uint32_t*>(lds16);
+    for (int i = tid; i < 1024; i += nthreads) d[i] = s0[i];
+    for (int i = tid; i < 2048; i += nthreads)
+        lds32[i] = (0x3f000000u | ((uint32_t)X86_RSQRT_SEED16[i ^ 0x400] << 11)) + 0x20000000u;
+    return SeedTables{lds16, X86_RSQRT_SEED16, lds32};
 }
 
 // RCPPS.  Model proven equal to the instruction for all 2^32 inputs.
@@ -72,6 +87,18 @@ __device__ __forceinline__ float x86_rsqrtps(float v, const unsigned short* lut)
     return __uint_as_float(r);
 }
 
+// RSQRTPS of a positive normal operand in 6 VALU operations + one LDS read; everything else (zero, denormal,
+// negative, inf, NaN: never produced by well-formed blocks) takes the general model above in a divergent branch.
+// With e the exponent field and h = ((e + 1) >> 1) - 64:  result = seed_word(i) - (h << 23)  (same as x86_rsqrtps:
+// odd = ~e & 1, k = (e - 127 - odd) >> 1 = h), and ((x + 0x00800000) >> 1) & 0x7f800000 = ((e + 1) >> 1) << 23.
+__device__ __forceinline__ float x86_rsqrtps_fast(float v, const SeedTables& T)
+{
+    const uint32_t x = __float_as_uint(v);
+    if (__builtin_expect((x - 0x00800000u) >= 0x7f000000u, 0)) return x86_rsqrtps(v, T.rsqrt);
+    const uint32_t t = T.rsqrt32[(x >> 13) & 0x7ffu];
+    return __uint_as_float(t - (((x + 0x00800000u) >> 1) & 0x7f800000u));
+}
+
 // ISPC stdlib rcp(): r*(2 - v*r), three separately rounded operations.
 __device__ __forceinline__ float ispc_rcp(float v, const SeedTables& T)
 {
@@ -82,9 +109,10 @@ __device__ __forceinline__ float ispc_rcp(float v, const SeedTables& T)
 }
 
 // ISPC stdlib rsqrt(): 0.5*(is*(3 - (v*is)*is)).
+template <bool FAST = false>
 __device__ __forceinline__ float ispc_rsqrt(float v, const SeedTables& T)
 {
-    const float is = x86_rsqrtps(v, T.rsqrt);
+    const float is = FAST ? x86_rsqrtps_fast(v, T) : x86_rsqrtps(v, T.rsqrt);
     float a = v * is;
     a = a * is;
     a = 3.0f - a;
