@@ -857,8 +857,26 @@ __device__ __forceinline__ void load_win(Win& w, const uint4* __restrict__ wins,
 
 // Register budgets (waves per SIMD) were picked by measurement on MI355X: the scans are bound by dependent-issue
 // and LDS latency at 2 waves, and tolerate a few spilled cold values to reach 3-4.
-__host__ __device__ constexpr int search_waves(int family, bool ranked) { return ranked ? 2 : (family == F_MODE7 ? 3 : 4); }
-__host__ __device__ constexpr int finish_waves(int family) { return family == F_MODES456 ? 3 : 3; }
+#ifndef SW02
+#define SW02 4
+#endif
+#ifndef SW13
+#define SW13 4
+#endif
+#ifndef SW7
+#define SW7 3
+#endif
+#ifndef SWR
+#define SWR 2
+#endif
+#ifndef FW
+#define FW 3
+#endif
+#ifndef FW456
+#define FW456 3
+#endif
+__host__ __device__ constexpr int search_waves(int family, bool ranked) { return ranked ? SWR : (family == F_MODE7 ? SW7 : (family == F_MODES02 ? SW02 : SW13)); }
+__host__ __device__ constexpr int finish_waves(int family) { return family == F_MODES456 ? FW456 : FW; }
 
 template <int FAMILY, bool RANKED, bool VEC16>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(search_waves(FAMILY, RANKED), search_waves(FAMILY, RANKED))))

@@ -1,18 +1,20 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): rocprofv3 kernel-trace stats of the default bench command, then separate PMC
-# passes (FETCH_SIZE / WRITE_SIZE need separate passes: TCC has 4 slots, FETCH_SIZE takes 3, WRITE_SIZE 2).
-# Usage: tools/profile_gpu.sh <tag>      -> gpurun_out/prof_<tag>/...
+# passes (FETCH_SIZE / WRITE_SIZE need separate passes: TCC has 4 slots, FETCH_SIZE takes 3, WRITE_SIZE 2), then SQ
+# counters of the BC7 kernels.  Usage: tools/profile_gpu.sh <tag>   -> gpurun_out/prof_<tag>/...
+# Afterwards (in the build container): python tools/summarize_profiles.py <tag>  copies the summaries into profiles/.
 set -u
 TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+KERNELS='bc7_search_kernel|bc7_finish_kernel|bc13_kernel|bc6h_'
 
 # 1. kernel trace + stats of the same command the driver runs
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 find $OUT/trace -name '*kernel_stats*.csv' -exec cp {} $OUT/kernel_stats.csv \;
-find $OUT/trace -name '*kernel_trace*.csv' | head -1 | xargs -I{} sh -c "head -1 {} > $OUT/kernel_trace_head.csv; grep -m3 bc7_kernel {} >> $OUT/kernel_trace_head.csv; grep -m3 bc13_kernel {} >> $OUT/kernel_trace_head.csv; grep -m3 bc6h_kernel {} >> $OUT/kernel_trace_head.csv"
+find $OUT/trace -name '*kernel_trace*.csv' | head -1 | xargs -I{} sh -c "head -1 {} > $OUT/kernel_trace_head.csv; grep -m8 bc7_ {} >> $OUT/kernel_trace_head.csv; grep -m3 bc13_kernel {} >> $OUT/kernel_trace_head.csv; grep -m3 bc6h_ {} >> $OUT/kernel_trace_head.csv"
 rm -rf $OUT/trace
 
 # 2. PMC passes, one counter group per run, short workloads
@@ -21,13 +23,13 @@ for wl in bc1 bc3 bc7_slow bc6h_slow; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${wl}_$ctr -o pmc -- python $ROOT/bench.py --workload $wl --no-formats --no-cpu --steps $steps --warmup 1 > /dev/null 2> $OUT/pmc_${wl}_$ctr.log
     f=$(find $OUT/pmc_${wl}_$ctr -name '*counter_collection*.csv' | head -1)
-    if [ -n "$f" ]; then head -1 $f > $OUT/pmc_${wl}_$ctr.csv; grep -E 'bc7_kernel|bc13_kernel|bc6h_kernel' $f | head -40 >> $OUT/pmc_${wl}_$ctr.csv; fi
+    if [ -n "$f" ]; then head -1 $f > $OUT/pmc_${wl}_$ctr.csv; grep -E "$KERNELS" $f | head -100 >> $OUT/pmc_${wl}_$ctr.csv; fi
     rm -rf $OUT/pmc_${wl}_$ctr
   done
 done
-# 3. SQ counters for the BC7 kernel (VALU utilisation, wave cycles)
+# 3. SQ counters for the BC7 kernels (VALU instruction counts, wave cycles)
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- python $ROOT/bench.py --workload bc7_slow --no-formats --no-cpu --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_sq.log
 f=$(find $OUT/pmc_sq -name '*counter_collection*.csv' | head -1)
-if [ -n "$f" ]; then head -1 $f > $OUT/pmc_sq_bc7.csv; grep -E 'bc7_kernel' $f | head -40 >> $OUT/pmc_sq_bc7.csv; fi
+if [ -n "$f" ]; then head -1 $f > $OUT/pmc_sq_bc7.csv; grep -E 'bc7_' $f | head -400 >> $OUT/pmc_sq_bc7.csv; fi
 rm -rf $OUT/pmc_sq
 ls -la $OUT

@@ -1,0 +1,72 @@
+"""Copies the rocprofv3 summaries of tools/profile_gpu.sh <tag> from gpurun_out/prof_<tag>/ into profiles/<tag>_* and
+rebuilds profiles/pmc_traffic.json (HBM bytes per C-ABI call from the FETCH_SIZE / WRITE_SIZE passes, with the gfx950
+corrections of MI355X_MICROARCH.md: FETCH_SIZE counts 32 B units reported in KiB at half scale -> x2; WRITE_SIZE as is)
+and profiles/<tag>_valu.json (VALU wave-instructions per call from the SQ pass).
+
+Usage: python tools/summarize_profiles.py <tag>
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_call(path, counter):
+    """Sum of `counter` over all kernels of one C-ABI call = total over the trace / number of calls, where the number
+    of calls is the dispatch count of the most frequent kernel name."""
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    if not rows:
+        return None, 0
+    by_kernel = collections.Counter(r["Kernel_Name"] for r in rows)
+    calls = max(by_kernel.values())
+    total = sum(float(r["Counter_Value"]) for r in rows)
+    return total / calls, calls
+
+
+def main():
+    tag = sys.argv[1]
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    os.makedirs(dst, exist_ok=True)
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".csv", ".json")):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
+    traffic = {}
+    for wl in ("bc1", "bc3", "bc7_slow", "bc6h_slow"):
+        f = os.path.join(src, f"pmc_{wl}_FETCH_SIZE.csv")
+        w = os.path.join(src, f"pmc_{wl}_WRITE_SIZE.csv")
+        if not (os.path.exists(f) and os.path.exists(w)):
+            continue
+        fetch_kib, n = per_call(f, "FETCH_SIZE")
+        write_kib, _ = per_call(w, "WRITE_SIZE")
+        if fetch_kib is None or write_kib is None:
+            continue
+        fetch = fetch_kib * 1024 * 2
+        write = write_kib * 1024
+        traffic[wl] = {"hbm_bytes_per_launch": int(fetch + write), "fetch_bytes_corrected_x2": int(fetch),
+                       "write_bytes": int(write), "raw_FETCH_SIZE_KiB": fetch_kib, "raw_WRITE_SIZE_KiB": write_kib,
+                       "calls_sampled": n, "source": f"profiles/{tag}_pmc_{wl}_FETCH_SIZE.csv, profiles/{tag}_pmc_{wl}_WRITE_SIZE.csv"}
+    traffic["_note"] = ("rocprofv3 --pmc, one counter per pass (TCC slots); per C-ABI call = all kernels of the call; gfx950 x2 "
+                        "correction applied to FETCH_SIZE per MI355X_MICROARCH.md section HBM; calibrated on BC1: 2*FETCH = "
+                        "texels read, WRITE = blocks written.")
+    with open(os.path.join(dst, "pmc_traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
+    sq = os.path.join(src, "pmc_sq_bc7.csv")
+    if os.path.exists(sq):
+        out = {}
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVES"):
+            v, n = per_call(sq, c)
+            if v is not None:
+                out[c] = v
+        out["_note"] = "per C-ABI call of bc7_slow at 4096x4096 (all kernels of the call); SQ cycle counters are in quad-cycles"
+        with open(os.path.join(dst, f"{tag}_valu.json"), "w") as fh:
+            json.dump(out, fh, indent=1)
+    print(json.dumps(traffic, indent=1)[:1500])
+
+
+if __name__ == "__main__":
+    main()
