@@ -11,6 +11,14 @@
 //   * the PCA ranking of the 32 shapes depends only on the block, not on the mode
 //     being tried, so it is computed once per block (the reference recomputes it for
 //     each of the up to seven two-region modes) and kept in LDS;
+//   * neither do the line fits of a shape: the scan visits the ranked shapes once and
+//     tries every two-region mode of the profile on each fit (slow profiles: 6 modes),
+//     keeping one winner per mode in LDS; the winners are then refined and committed in
+//     the reference's mode order.  Likewise the one-region fit serves modes 10..13;
+//   * index selection: decoded palette values are integers <= 65535, so
+//     (int)(((64-w)*a + w*b + 32)/64) = a + floor((w*(b-a) + 32)/64) exactly in fp32; the
+//     true divide of the projection is formed from one reciprocal per region and two
+//     FMAs (exactly rounded, see select_hdr);
 //   * headers are packed from the format's bit-layout table (bc6h_layout.hpp, derived
 //     from the decoder's mode descriptors), one compile-time specialisation per mode,
 //     instead of the reference's per-mode arithmetic scatter (kernel.ispc:2392-2980).
@@ -21,7 +29,7 @@
 
 namespace itw {
 
-constexpr int TPB6 = 64;
+constexpr int TPB6 = 256;
 constexpr float INV65535 = 1.0f / 65535.0f;     // ep/(256*256f-1) under fast-math
 constexpr float INV31 = 1.0f / 31.0f;
 
@@ -35,8 +43,8 @@ struct HLane {
     int32_t mode, epb;
     int32_t qlo[3], qhi[3];   // endpoint clamp window in code space
     SeedTables T;
-    int32_t* keys;            // LDS column, 32 entries
-    bool ranked;
+    int32_t* keys;            // LDS column, 32 entries: keys[i * TPB6]
+    uint32_t* wins;           // LDS column, 6 winners x {err bits, shape, qb0, qb1}: wins[(4 * m + f) * TPB6]
 };
 
 // ---- format data (kernel.ispc:2080-2125) -----------------------------------
@@ -194,18 +202,104 @@ __device__ __forceinline__ void emit_one_region(uint32_t (&out)[4], int32_t (&q)
     store_bits(out, bb);
 }
 
+// ---- index selection for uf16-domain texels (kernel.ispc:1133-1193 with 16-bit endpoints) ---------
+// One region's endpoints as the decoder reconstructs them (integers in [0,65535], held as floats).
+struct HSeg {
+    float a[3], ba[3];        // endpoint 0; endpoint 1 - endpoint 0 (exact)
+    float div, rdiv;          // sum (b-a)^2 accumulated in the reference's order; its IEEE reciprocal
+};
+
+__device__ __forceinline__ HSeg make_hseg(const float (&e)[2][4])
+{
+    HSeg s;
+    s.div = 0.f;
+#pragma unroll
+    for (int p = 0; p < 3; p++) { s.a[p] = e[0][p]; s.ba[p] = e[1][p] - e[0][p]; s.div += sq(s.ba[p]); }
+    s.rdiv = 1.0f / s.div;
+    return s;
+}
+
+// Returns the block error (sum of per-texel errors, each truncated with cvttps2dq semantics); indices in qb.
+//  * `proj /= div` of the reference is a true divide.  Here q0 = RN(proj * r), r = RN(1/div); rem = proj - q0*div
+//    (exact, one FMA); q = RN(q0 + rem*r) = RN(proj/div) (Markstein's correction step with a correctly rounded
+//    reciprocal; additionally checked against the divide instruction for all 2^23 divisor significands x 400
+//    numerators, 3.4e9 pairs, 0 mismatches).  div == 0: 0*inf = NaN on both routes -> index 1.
+//  * decode: (64-w)*a, w*b <= 64*65535 and their sum + 32 are exact in fp32, /64 is exact, truncation of a
+//    non-negative value is floor: d = a + floor((w*(b-a) + 32) / 64), every step exact (|w*(b-a)| < 2^23).
+//  * float -> int of the index: cvttps2dq gives INT_MIN (-> clamp 1) for NaN and for x >= 2^31, where
+//    v_cvt_i32_f32 would saturate upwards; x < -2^31 ends at 1 on both.
+template <int BITS, int PAIRS>
+__device__ __forceinline__ float select_hdr(uint32_t (&qb)[2], const TexF& px, const HSeg (&sg)[2], uint32_t pattern)
+{
+    constexpr int LEVELS = 1 << BITS;
+    float total = 0.f;
+    qb[0] = qb[1] = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        HSeg s = sg[0];
+        if (PAIRS == 2) {
+            const bool one = ((pattern >> (2 * k)) & 3u) == 1u;
+#pragma unroll
+            for (int p = 0; p < 3; p++) { s.a[p] = one ? sg[1].a[p] : s.a[p]; s.ba[p] = one ? sg[1].ba[p] : s.ba[p]; }
+            s.div = one ? sg[1].div : s.div; s.rdiv = one ? sg[1].rdiv : s.rdiv;
+        }
+        float t[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) t[p] = px.get(p, k);
+        float proj = 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; p++) proj += (t[p] - s.a[p]) * s.ba[p];
+        float q = proj * s.rdiv;
+        const float rem = __builtin_fmaf(-q, s.div, proj);
+        q = __builtin_fmaf(rem, s.rdiv, q);
+        const float x = q * (float)LEVELS + 0.5f;
+        int32_t q1 = iclamp((int32_t)x, 1, LEVELS - 1);
+        q1 = (x < 2147483648.0f) ? q1 : 1;
+        const float w0 = (float)weight_of<BITS>(q1 - 1), w1 = (float)weight_of<BITS>(q1);
+        float err0 = 0.f, err1 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const float d0 = s.a[p] + __builtin_floorf((w0 * s.ba[p] + 32.0f) * 0.015625f);
+            const float d1 = s.a[p] + __builtin_floorf((w1 * s.ba[p] + 32.0f) * 0.015625f);
+            err0 += sq(d0 - t[p]);
+            err1 += sq(d1 - t[p]);
+        }
+        const bool first = err0 < err1;
+        const float e = first ? err0 : err1;
+        const uint32_t qi = (uint32_t)(first ? q1 - 1 : q1);
+        if (k < 8) qb[0] += qi << (4 * k); else qb[1] += qi << (4 * (k - 8));
+        total += (float)f2i_x86(e);
+    }
+    return total;
+}
+
+// ---- mode descriptors ------------------------------------------------------------------------------
+// gate a mode on the block's widest channel span and make it the lane's current mode          [2332-2365]
+__device__ __forceinline__ bool enter_mode(HLane& ln, int mode, float margin)
+{
+    const float span = span_of(mode);
+    if (ln.max_span * margin > span) return false;
+    ln.epb = bits_of(mode);
+    if (mode >= 10 || mode <= 1 || mode == 5 || mode == 9) {
+        ln.mode = mode;
+        set_window(ln, span, -1);
+    } else {
+        ln.mode = mode + ln.max_span_idx;           // 2 -> 2/3/4, 6 -> 6/7/8 by the widest channel
+        set_window(ln, span, ln.max_span_idx);
+    }
+    return true;
+}
+
 // ---- searches ----------------------------------------------------------------------------------
 __device__ __forceinline__ void rank_shapes32(HLane& ln)                                  // [2259-2269]
 {
-    if (ln.ranked) return;                          // depends on the block only: once per block
     Stats<3> full;
     stats_of<3>(full, ln.tex, 0xffffu);
     for (int part = 0; part < 32; part++) {
         const uint32_t m0 = BCN_SUBSET_MASKS[part] & 0xffffu;
-        const int32_t bound = split_bound<3>(ln.tex, m0, full, ln.T);
+        const int32_t bound = split_bound<3, true>(ln.tex, m0, full, ln.T);
         ln.keys[part * TPB6] = (int32_t)((uint32_t)part + (uint32_t)bound * 64u);
     }
-    ln.ranked = true;
 }
 
 __device__ __forceinline__ int32_t next_key32(const HLane& ln, int32_t prev, bool first)
@@ -218,101 +312,130 @@ __device__ __forceinline__ int32_t next_key32(const HLane& ln, int32_t prev, boo
     return cur;
 }
 
-// two-region search at the lane's current (mode, epb, window)                             [2174-2273]
-__device__ __forceinline__ void encode_two_region(HLane& ln, int count, int refine)
+// The two-region modes a profile encodes, in the reference's order.  Slow profiles: 0,1,2,5,6,9 (never gated out:
+// margin 0).  Other profiles: the mode the gate sequence left in the lane (`gated`), then mode 1 unless fast_mode.
+__device__ __forceinline__ int two_region_mode(bool slow, int m, int gated)
 {
-    rank_shapes32(ln);
-    if (count <= 0) return;
-    count = min(count, 32);
+    if (!slow) return (m == 0) ? gated : 1;
+    return (m == 0) ? 0 : (m == 1) ? 1 : (m == 2) ? 2 : (m == 3) ? 5 : (m == 4) ? 6 : 9;
+}
 
-    int32_t bq[2][2][4];
-    uint32_t bqb[2] = {0u, 0u};
-    int32_t bshape = 0;
-    float berr = __builtin_inff();
-    for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = 0;
-
+// Scan of the `count` best ranked shapes: one pair of line fits per shape serves all `nmodes` modes. [2174-2273]
+__device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes, int gated, int count)
+{
+    for (int m = 0; m < nmodes; m++) {
+        ln.wins[(4 * m + 0) * TPB6] = 0x7f800000u;      // +inf
+        ln.wins[(4 * m + 1) * TPB6] = 0u;
+        ln.wins[(4 * m + 2) * TPB6] = 0u;
+        ln.wins[(4 * m + 3) * TPB6] = 0u;
+    }
     int32_t prev = 0;
     for (int c = 0; c < count; c++) {
         prev = next_key32(ln, prev, c == 0);
         const int shape = prev & 31;
         const Shape sh = load_shape(shape);
-        float ep[3][2][4];
-        int32_t q[2][2][4];
-        for (int j = 0; j < 2; j++) {
-            fit_subset<3, false>(ep[j], ln.tex, subset_mask(sh, j), ln.T);
-            quant_pair(q[j], ep[j], ln);
+        float fit[2][2][4];
+#pragma unroll
+        for (int j = 0; j < 2; j++) fit_subset<3, false, true>(fit[j], ln.tex, subset_mask(sh, j), ln.T);
+#pragma unroll 1
+        for (int m = 0; m < nmodes; m++) {
+            enter_mode(ln, two_region_mode(slow, m, gated), 0.f);
+            HSeg sg[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                float ep[2][4];
+                int32_t q[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; i++) for (int p = 0; p < 3; p++) ep[i][p] = fit[j][i][p];
+                quant_pair(q, ep, ln);
+                sg[j] = make_hseg(ep);
+            }
+            uint32_t qb[2];
+            const float err = select_hdr<3, 2>(qb, ln.tex, sg, sh.pattern);
+            if (err < __uint_as_float(ln.wins[(4 * m + 0) * TPB6])) {
+                ln.wins[(4 * m + 0) * TPB6] = __float_as_uint(err);
+                ln.wins[(4 * m + 1) * TPB6] = (uint32_t)shape;
+                ln.wins[(4 * m + 2) * TPB6] = qb[0];
+                ln.wins[(4 * m + 3) * TPB6] = qb[1];
+            }
         }
-        uint32_t qb[2];
-        const float err = select_indices<3, 3, true>(qb, ln.tex, ep, sh.pattern);
-        if (err < berr) {
-            for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = q[j][i][p];
-            bqb[0] = qb[0]; bqb[1] = qb[1];
-            bshape = shape;
-            berr = err;
-        }
-    }
-
-    const Shape sh = load_shape(bshape);
-    for (int it = 0; it < refine; it++) {
-        float ep[3][2][4];
-        int32_t q[2][2][4];
-        for (int j = 0; j < 2; j++) {
-            refit_subset<3, 3>(ep[j], ln.tex, bqb, subset_mask(sh, j), ln.T);
-            quant_pair(q[j], ep[j], ln);
-        }
-        uint32_t qb[2];
-        const float err = select_indices<3, 3, true>(qb, ln.tex, ep, sh.pattern);
-        if (err < berr) {
-            for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = q[j][i][p];
-            bqb[0] = qb[0]; bqb[1] = qb[1];
-            berr = err;
-        }
-    }
-
-    if (berr < ln.best_err) {
-        ln.best_err = berr;
-        emit_two_region(ln.best, bq, bqb, bshape, ln.mode);
     }
 }
 
-// one-region search                                                                        [2275-2300]
-__device__ __forceinline__ void encode_one_region(HLane& ln, int refine)
+// Refinement of each mode's winner, then the mode competes for the block, in mode order.
+__device__ __forceinline__ void finish_two_region(HLane& ln, bool slow, int nmodes, int gated, int refine)
 {
-    float ep[3][2][4];
-    int32_t q[2][4];
-    uint32_t qb[2];
-    fit_subset<3, false>(ep[0], ln.tex, 0xffffu, ln.T);
-    quant_pair(q, ep[0], ln);
-    float err = select_indices<4, 3, true>(qb, ln.tex, ep, 0u);
-    for (int it = 0; it < refine; it++) {
-        refit_subset<4, 3>(ep[0], ln.tex, qb, 0xffffu, ln.T);
-        quant_pair(q, ep[0], ln);
-        err = select_indices<4, 3, true>(qb, ln.tex, ep, 0u);
-    }
-    if (err < ln.best_err) {
-        ln.best_err = err;
-        emit_one_region(ln.best, q, qb, ln.mode);
+#pragma unroll 1
+    for (int m = 0; m < nmodes; m++) {
+        enter_mode(ln, two_region_mode(slow, m, gated), 0.f);
+        float berr = __uint_as_float(ln.wins[(4 * m + 0) * TPB6]);
+        const int bshape = (int)ln.wins[(4 * m + 1) * TPB6];
+        uint32_t bqb[2] = {ln.wins[(4 * m + 2) * TPB6], ln.wins[(4 * m + 3) * TPB6]};
+        const Shape sh = load_shape(bshape);
+        // endpoint codes of the scan's winner: same fit, same quantiser, same bits
+        int32_t bq[2][2][4];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float ep[2][4];
+            fit_subset<3, false, true>(ep, ln.tex, subset_mask(sh, j), ln.T);
+            quant_pair(bq[j], ep, ln);
+        }
+        if (berr == __builtin_inff())               // no candidate beat +inf (cannot happen: errors are finite); keep zeros
+            for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = 0;
+        for (int it = 0; it < refine; it++) {
+            HSeg sg[2];
+            int32_t q[2][2][4];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                float ep[2][4];
+                refit_subset<3, 3>(ep, ln.tex, bqb, subset_mask(sh, j), ln.T);
+                quant_pair(q[j], ep, ln);
+                sg[j] = make_hseg(ep);
+            }
+            uint32_t qb[2];
+            const float err = select_hdr<3, 2>(qb, ln.tex, sg, sh.pattern);
+            if (err < berr) {
+                for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = q[j][i][p];
+                bqb[0] = qb[0]; bqb[1] = qb[1];
+                berr = err;
+            }
+        }
+        if (berr < ln.best_err) {
+            ln.best_err = berr;
+            emit_two_region(ln.best, bq, bqb, bshape, ln.mode);
+        }
     }
 }
 
-// gate a mode on the block's widest channel span; optionally encode with it               [2332-2365]
-__device__ __forceinline__ void test_mode(HLane& ln, const bc6h_enc_settings& S, int mode, bool enc, float margin)
+// one-region modes: the fit is the block's, whatever the mode                                   [2275-2300]
+// slow: modes 10..13 in turn; otherwise the one mode the gates left in the lane.
+__device__ __forceinline__ void encode_one_region(HLane& ln, bool slow, int refine)
 {
-    const float span = span_of(mode);
-    if (ln.max_span * margin > span) return;
-    ln.epb = bits_of(mode);
-    if (mode >= 10) {
-        ln.mode = mode;
-        set_window(ln, span, -1);
-        if (enc) encode_one_region(ln, S.refineIterations_1p);
-    } else if (mode <= 1 || mode == 5 || mode == 9) {
-        ln.mode = mode;
-        set_window(ln, span, -1);
-        if (enc) encode_two_region(ln, S.fastSkipTreshold, S.refineIterations_2p);
-    } else {
-        ln.mode = mode + ln.max_span_idx;           // 2 -> 2/3/4, 6 -> 6/7/8 by the widest channel
-        set_window(ln, span, ln.max_span_idx);
-        if (enc) encode_two_region(ln, S.fastSkipTreshold, S.refineIterations_2p);
+    float fit[2][4];
+    fit_subset<3, false, true>(fit, ln.tex, 0xffffu, ln.T);
+    const int n = slow ? 4 : 1;
+#pragma unroll 1
+    for (int m = 0; m < n; m++) {
+        if (slow) enter_mode(ln, 10 + m, 0.f);
+        float ep[2][4];
+        int32_t q[2][4];
+        uint32_t qb[2];
+        HSeg sg[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) for (int p = 0; p < 3; p++) ep[i][p] = fit[i][p];
+        quant_pair(q, ep, ln);
+        sg[0] = make_hseg(ep); sg[1] = sg[0];
+        float err = select_hdr<4, 1>(qb, ln.tex, sg, 0u);
+        for (int it = 0; it < refine; it++) {
+            refit_subset<4, 3>(ep, ln.tex, qb, 0xffffu, ln.T);
+            quant_pair(q, ep, ln);
+            sg[0] = make_hseg(ep);
+            err = select_hdr<4, 1>(qb, ln.tex, sg, 0u);
+        }
+        if (err < ln.best_err) {
+            ln.best_err = err;
+            emit_one_region(ln.best, q, qb, ln.mode);
+        }
     }
 }
 
@@ -321,15 +444,19 @@ __global__ void __launch_bounds__(TPB6)
 bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
             uint8_t* __restrict__ dst, const bc6h_enc_settings S)
 {
+    __shared__ unsigned short s_seed16[2048];
+    __shared__ uint32_t s_seed32[2048];
     __shared__ int32_t s_keys[32 * TPB6];
-    const int32_t b = blockIdx.x * TPB6 + threadIdx.x;
-    if (b >= nblocks) return;
-    const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
-
+    __shared__ uint32_t s_wins[24 * TPB6];
     HLane ln;
-    ln.T = global_seed_tables();
+    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB6);
+    __syncthreads();
+    const int32_t gid = blockIdx.x * TPB6 + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;    // idle lanes of the last workgroup redo its last block, store nothing
+    const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
     ln.keys = s_keys + threadIdx.x;
-    ln.ranked = false;
+    ln.wins = s_wins + threadIdx.x;
 
     // load: 4 texels x 8 bytes per row; keep R,G,B half bit patterns as integers    [kernel.ispc:134-151]
     const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 32;
@@ -376,38 +503,43 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
     for (int c = 0; c < 3; c++) { ln.qlo[c] = 0; ln.qhi[c] = 0; }
 
     if (S.slow_mode) {                                                                  // [kernel.ispc:3073-3085]
-        test_mode(ln, S, 0, true, 0.f);
-        test_mode(ln, S, 1, true, 0.f);
-        test_mode(ln, S, 2, true, 0.f);
-        test_mode(ln, S, 5, true, 0.f);
-        test_mode(ln, S, 6, true, 0.f);
-        test_mode(ln, S, 9, true, 0.f);
-        test_mode(ln, S, 10, true, 0.f);
-        test_mode(ln, S, 11, true, 0.f);
-        test_mode(ln, S, 12, true, 0.f);
-        test_mode(ln, S, 13, true, 0.f);
+        // every mode is encoded (margin 0 never gates); the ranking runs even when no shape is tried
+        rank_shapes32(ln);
+        const int count = min(max(S.fastSkipTreshold, 0), 32);
+        if (count > 0) {
+            scan_two_region(ln, true, 6, 0, count);
+            finish_two_region(ln, true, 6, 0, S.refineIterations_2p);
+        }
+        encode_one_region(ln, true, S.refineIterations_1p);
     } else {                                                                            // [kernel.ispc:3086-3106]
         const float inv1_2 = 1.0f / 1.2f;
         if (S.fastSkipTreshold > 0) {
-            test_mode(ln, S, 9, false, 0.f);
-            if (S.fast_mode) test_mode(ln, S, 1, false, 1.f);
-            test_mode(ln, S, 6, false, inv1_2);
-            test_mode(ln, S, 5, false, inv1_2);
-            test_mode(ln, S, 0, false, inv1_2);
-            test_mode(ln, S, 2, false, 1.f);
-            encode_two_region(ln, S.fastSkipTreshold, S.refineIterations_2p);
-            if (!S.fast_mode) test_mode(ln, S, 1, true, 0.f);
+            enter_mode(ln, 9, 0.f);
+            if (S.fast_mode) enter_mode(ln, 1, 1.f);
+            enter_mode(ln, 6, inv1_2);
+            enter_mode(ln, 5, inv1_2);
+            enter_mode(ln, 0, inv1_2);
+            enter_mode(ln, 2, 1.f);
+            // the gates leave one of 9,1,6,5,0,2 in the lane; recover the base mode (6/7/8 -> 6, 2/3/4 -> 2)
+            const int gated = (ln.mode >= 6 && ln.mode <= 8) ? 6 : ((ln.mode >= 2 && ln.mode <= 4) ? 2 : ln.mode);
+            rank_shapes32(ln);
+            const int count = min(S.fastSkipTreshold, 32);
+            const int nmodes = S.fast_mode ? 1 : 2;
+            scan_two_region(ln, false, nmodes, gated, count);
+            finish_two_region(ln, false, nmodes, gated, S.refineIterations_2p);
         }
-        test_mode(ln, S, 10, false, 0.f);
-        test_mode(ln, S, 11, false, 1.f);
-        test_mode(ln, S, 12, false, 1.f);
-        test_mode(ln, S, 13, false, 1.f);
-        encode_one_region(ln, S.refineIterations_1p);
+        enter_mode(ln, 10, 0.f);
+        enter_mode(ln, 11, 1.f);
+        enter_mode(ln, 12, 1.f);
+        enter_mode(ln, 13, 1.f);
+        encode_one_region(ln, false, S.refineIterations_1p);
     }
 
-    uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
-    if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(ln.best[0], ln.best[1], ln.best[2], ln.best[3]);
-    else { d[0] = ln.best[0]; d[1] = ln.best[1]; d[2] = ln.best[2]; d[3] = ln.best[3]; }
+    if (live) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
+        if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(ln.best[0], ln.best[1], ln.best[2], ln.best[3]);
+        else { d[0] = ln.best[0]; d[1] = ln.best[1]; d[2] = ln.best[2]; d[3] = ln.best[3]; }
+    }
 }
 
 void launch_bc6h(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,

@@ -157,7 +157,7 @@ __device__ __forceinline__ void principal_axis(float (&v)[4], const float (&cv)[
 // PCA line fit of one subset: endpoints = mean + extreme projections * axis.
 // CLAMP255: BC7 clamps to [0,255] (kernel.ispc:896-905); BC6H keeps the raw fit (857-894).
 // ep[0][p] / ep[1][p]: low / high endpoint.  Slots p >= CH are left untouched.
-template <int CH, bool CLAMP255, class TX>
+template <int CH, bool CLAMP255, bool FAST = false, class TX>
 __device__ __forceinline__ void fit_from_stats(float (&ep)[2][4], const TX& px, uint32_t mask, const Stats<CH>& st, const SeedTables& T)
 {
     const float rn = ispc_rcp(st.n, T);
@@ -174,7 +174,7 @@ __device__ __forceinline__ void fit_from_stats(float (&ep)[2][4], const TX& px, 
     cv[0] += eps; cv[4] += eps; cv[7] += eps; cv[9] += eps;
 
     float axis[4];
-    principal_axis<CH, 8>(axis, cv, T);
+    principal_axis<CH, 8, FAST>(axis, cv, T);
 
     float lo = __builtin_inff(), hi = -__builtin_inff();
 #pragma unroll
@@ -196,12 +196,12 @@ __device__ __forceinline__ void fit_from_stats(float (&ep)[2][4], const TX& px, 
     }
 }
 
-template <int CH, bool CLAMP255, class TX>
+template <int CH, bool CLAMP255, bool FAST = false, class TX>
 __device__ __forceinline__ void fit_subset(float (&ep)[2][4], const TX& px, uint32_t mask, const SeedTables& T)
 {
     Stats<CH> st;
     stats_of<CH>(st, px, mask);
-    fit_from_stats<CH, CLAMP255>(ep, px, mask, st, T);
+    fit_from_stats<CH, CLAMP255, FAST>(ep, px, mask, st, T);
 }
 
 // trace - largest eigenvalue (4 power iterations) of a scaled covariance.   (kernel.ispc:907-939)
@@ -256,12 +256,12 @@ __device__ __forceinline__ int32_t split_bound_from(const Stats<CH>& a, const St
     return f2i_x86(sqrtf(bound) * 256.0f);
 }
 
-template <int CH, class TX>
+template <int CH, bool FAST = false, class TX>
 __device__ __forceinline__ int32_t split_bound(const TX& px, uint32_t mask0, const Stats<CH>& full, const SeedTables& T)
 {
     Stats<CH> a;
     stats_of<CH>(a, px, mask0);
-    return split_bound_from<CH>(a, full, T);
+    return split_bound_from<CH, FAST>(a, full, T);
 }
 
 // ---- index selection (kernel.ispc:1133-1193) -------------------------------
