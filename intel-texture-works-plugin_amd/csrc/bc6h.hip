@@ -36,7 +36,10 @@ constexpr float INV31 = 1.0f / 31.0f;
 struct HLane {
     TexF tex;                 // uf16-domain texels (plane 3 unused)
     float best_err;
-    uint32_t best[4];
+    // best encoding so far, turned into bits once at the end of the kernel
+    int32_t best_q[2][2][4];  // endpoint codes [region][endpoint][channel]
+    uint32_t best_qb[2];
+    int32_t best_shape, best_mode;   // best_shape < 0: one-region block
     float lo[3], hi[3];       // per-channel bounds
     float max_span;
     int32_t max_span_idx;
@@ -296,6 +299,7 @@ __device__ __forceinline__ void rank_shapes32(HLane& ln)                        
     Stats<3> full;
     stats_of<3>(full, ln.tex, 0xffffu);
     for (int part = 0; part < 32; part++) {
+        ln.tex.fence();                             // texel products are loop invariant: do not hoist 100+ values
         const uint32_t m0 = BCN_SUBSET_MASKS[part] & 0xffffu;
         const int32_t bound = split_bound<3, true>(ln.tex, m0, full, ln.T);
         ln.keys[part * TPB6] = (int32_t)((uint32_t)part + (uint32_t)bound * 64u);
@@ -332,6 +336,7 @@ __device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes
     int32_t prev = 0;
     for (int c = 0; c < count; c++) {
         prev = next_key32(ln, prev, c == 0);
+        ln.tex.fence();
         const int shape = prev & 31;
         const Shape sh = load_shape(shape);
         float fit[2][2][4];
@@ -339,6 +344,7 @@ __device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes
         for (int j = 0; j < 2; j++) fit_subset<3, false, true>(fit[j], ln.tex, subset_mask(sh, j), ln.T);
 #pragma unroll 1
         for (int m = 0; m < nmodes; m++) {
+            ln.tex.fence();
             enter_mode(ln, two_region_mode(slow, m, gated), 0.f);
             HSeg sg[2];
 #pragma unroll
@@ -367,6 +373,7 @@ __device__ __forceinline__ void finish_two_region(HLane& ln, bool slow, int nmod
 {
 #pragma unroll 1
     for (int m = 0; m < nmodes; m++) {
+        ln.tex.fence();
         enter_mode(ln, two_region_mode(slow, m, gated), 0.f);
         float berr = __uint_as_float(ln.wins[(4 * m + 0) * TPB6]);
         const int bshape = (int)ln.wins[(4 * m + 1) * TPB6];
@@ -383,6 +390,7 @@ __device__ __forceinline__ void finish_two_region(HLane& ln, bool slow, int nmod
         if (berr == __builtin_inff())               // no candidate beat +inf (cannot happen: errors are finite); keep zeros
             for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = 0;
         for (int it = 0; it < refine; it++) {
+            ln.tex.fence();
             HSeg sg[2];
             int32_t q[2][2][4];
 #pragma unroll
@@ -402,7 +410,9 @@ __device__ __forceinline__ void finish_two_region(HLane& ln, bool slow, int nmod
         }
         if (berr < ln.best_err) {
             ln.best_err = berr;
-            emit_two_region(ln.best, bq, bqb, bshape, ln.mode);
+            for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) ln.best_q[j][i][p] = bq[j][i][p];
+            ln.best_qb[0] = bqb[0]; ln.best_qb[1] = bqb[1];
+            ln.best_shape = bshape; ln.best_mode = ln.mode;
         }
     }
 }
@@ -416,6 +426,7 @@ __device__ __forceinline__ void encode_one_region(HLane& ln, bool slow, int refi
     const int n = slow ? 4 : 1;
 #pragma unroll 1
     for (int m = 0; m < n; m++) {
+        ln.tex.fence();
         if (slow) enter_mode(ln, 10 + m, 0.f);
         float ep[2][4];
         int32_t q[2][4];
@@ -434,13 +445,15 @@ __device__ __forceinline__ void encode_one_region(HLane& ln, bool slow, int refi
         }
         if (err < ln.best_err) {
             ln.best_err = err;
-            emit_one_region(ln.best, q, qb, ln.mode);
+            for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) { ln.best_q[0][i][p] = q[i][p]; ln.best_q[1][i][p] = 0; }
+            ln.best_qb[0] = qb[0]; ln.best_qb[1] = qb[1];
+            ln.best_shape = -1; ln.best_mode = ln.mode;
         }
     }
 }
 
-template <bool VEC16>
-__global__ void __launch_bounds__(TPB6)
+template <bool SLOW, bool VEC16>
+__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(2, 2)))   // measured: 2 waves with a little scratch beat 1 wave with AGPR spills by 35 %
 bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
             uint8_t* __restrict__ dst, const bc6h_enc_settings S)
 {
@@ -498,11 +511,13 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
     }
 
     ln.best_err = __builtin_inff();
-    ln.best[0] = ln.best[1] = ln.best[2] = ln.best[3] = 0u;
+    for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) ln.best_q[j][i][p] = 0;
+    ln.best_qb[0] = ln.best_qb[1] = 0u;
+    ln.best_shape = -1; ln.best_mode = 10;
     ln.mode = 0; ln.epb = 0;
     for (int c = 0; c < 3; c++) { ln.qlo[c] = 0; ln.qhi[c] = 0; }
 
-    if (S.slow_mode) {                                                                  // [kernel.ispc:3073-3085]
+    if (SLOW) {                                                                         // [kernel.ispc:3073-3085]
         // every mode is encoded (margin 0 never gates); the ranking runs even when no shape is tried
         rank_shapes32(ln);
         const int count = min(max(S.fastSkipTreshold, 0), 32);
@@ -535,10 +550,13 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
         encode_one_region(ln, false, S.refineIterations_1p);
     }
 
+    uint32_t out[4];
+    if (ln.best_shape >= 0) emit_two_region(out, ln.best_q, ln.best_qb, ln.best_shape, ln.best_mode);
+    else                    emit_one_region(out, ln.best_q[0], ln.best_qb, ln.best_mode);
     if (live) {
         uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
-        if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(ln.best[0], ln.best[1], ln.best[2], ln.best[3]);
-        else { d[0] = ln.best[0]; d[1] = ln.best[1]; d[2] = ln.best[2]; d[3] = ln.best[3]; }
+        if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(out[0], out[1], out[2], out[3]);
+        else { d[0] = out[0]; d[1] = out[1]; d[2] = out[2]; d[3] = out[3]; }
     }
 }
 
@@ -550,8 +568,13 @@ void launch_bc6h(const uint8_t* src, int64_t stride, int width, int height, uint
     if (n <= 0) return;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const dim3 grid((unsigned)((n + TPB6 - 1) / TPB6)), blk(TPB6);
-    if (vec) hipLaunchKernelGGL((bc6h_kernel<true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
-    else     hipLaunchKernelGGL((bc6h_kernel<false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
+    if (s.slow_mode) {
+        if (vec) hipLaunchKernelGGL((bc6h_kernel<true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
+        else     hipLaunchKernelGGL((bc6h_kernel<true, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
+    } else {
+        if (vec) hipLaunchKernelGGL((bc6h_kernel<false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
+        else     hipLaunchKernelGGL((bc6h_kernel<false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
+    }
 }
 
 } // namespace itw
