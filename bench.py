@@ -105,6 +105,21 @@ def cpu_baseline(fmt, prof, img, budget_s=15.0):
                       f"{os.cpu_count()}, affinity, cgroup quota), reference band rule; cpu: {model}"}
 
 
+def pmc_valu(workload):
+    """VALU wave-instructions per C-ABI call from a committed rocprofv3 SQ pass (profiles/*_valu.json), if present."""
+    if workload != "bc7_slow":
+        return None
+    best = None
+    try:
+        for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+            if name.endswith("_valu.json"):
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    best = json.load(f).get("SQ_INSTS_VALU")
+    except (OSError, ValueError):
+        return None
+    return best
+
+
 def pmc_traffic(workload):
     """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), if present."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -210,9 +225,18 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.workload),
                          "kernel_ms_avg": round(k_avg_ms, 4), "kernel_ms_min": round(k_min_ms, 4),
                          "algorithmic_bytes_per_launch": alg,
-                         "note": "BC7/BC6H are fp32-VALU bound (no MFMA-shaped work); HBM fraction is reported "
-                                 "because the contract asks for it, see DESIGN.md for the VALU ceiling"},
+                         "note": "BC7/BC6H are VALU-issue bound (no MFMA-shaped work); the HBM fraction is reported "
+                                 "because the contract asks for it; `valu` is the roofline that binds (DESIGN.md 3)"},
         }
+        insts = pmc_valu(args.workload)
+        if insts and world == 1 and size == 4096:
+            lane_ops = insts * 64 / (k_avg_ms * 1e-3) / 1e12
+            result["roofline"]["valu"] = {
+                "achieved": round(lane_ops, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": round(lane_ops / VALU_PEAK_TOPS, 4),
+                "wave_instructions_per_call": int(insts),
+                "note": "SQ_INSTS_VALU of one call (committed rocprofv3 pass) x 64 lanes / live kernel time; peak = 256 CU x 4 SIMD "
+                        "x 32 lanes x 2.4 GHz, reached only by the 2-cycle VOP2 forms (v_mul/add_f32, v_add_u32, logic, shifts right); "
+                        "cvt / cmp / fma / packed / dot forms issue at half that rate (tools/ubench)"}
 
     if rank == 0 and world == 1 and not args.no_formats:
         side = {}

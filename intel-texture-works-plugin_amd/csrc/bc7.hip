@@ -873,10 +873,10 @@ __device__ __forceinline__ void load_win(Win& w, const uint4* __restrict__ wins,
 #define FW 3
 #endif
 #ifndef FW456
-#define FW456 3
+#define FW456 2
 #endif
 __host__ __device__ constexpr int search_waves(int family, bool ranked) { return ranked ? SWR : (family == F_MODE7 ? SW7 : (family == F_MODES02 ? SW02 : SW13)); }
-__host__ __device__ constexpr int finish_waves(int family) { return family == F_MODES456 ? FW456 : FW; }
+__host__ __device__ constexpr int finish_waves(int family) { return family == F_MODES13 ? FW : FW456; }
 
 template <int FAMILY, bool RANKED, bool VEC16>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(search_waves(FAMILY, RANKED), search_waves(FAMILY, RANKED))))
