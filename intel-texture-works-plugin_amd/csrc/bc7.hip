@@ -70,6 +70,11 @@ __device__ __forceinline__ int32_t f2i(float f) { return SAFE ? (int32_t)f : f2i
 //      d[i][p]  what a decoder reconstructs from it (the reference overwrites e with this; kernel.ispc:1100-1128)
 
 // modes 0,3,6,7: one p-bit per endpoint, chosen by squared error over `err_ch` channels.  [kernel.ispc:983-1022]
+// SAFE (fitted endpoints, clamped to [0,255]): u = (e/255*L2 - b)/2 + 0.5 is in [0, 2^BITS + 1), so the code
+// 2*floor(u) + b stays an integer-valued float end to end (floor, *2, +b are exact) and only the chosen hypothesis is
+// converted; of the reference's clamp [b, L2-1+b] only the upper bound of b = 0 can fire (u >= 2^BITS needs
+// e/255*L2 >= L2, i.e. e = 255; for b = 1, u < 2^BITS always).  Modes 3, 6, 7 compare the code itself (kernel.ispc:
+// 1003-1017: mode 7 compares raw 6-bit codes against 8-bit targets, a reference quirk), mode 0 its 5-bit expansion.
 template <int MODE, bool SAFE>
 __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4], const float (&e)[2][4], int err_ch)
 {
@@ -77,6 +82,27 @@ __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4
     constexpr int L2 = (1 << BITS) * 2 - 1;
     #pragma unroll
     for (int i = 0; i < 2; i++) {
+        if (SAFE && MODE != 0) {
+            float db[2][4];
+            #pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const float t = e[i][p] * INV255 * (float)L2;
+                const float v0 = __builtin_floorf(t * 0.5f + 0.5f) * 2.0f;
+                db[0][p] = (v0 < (float)(L2 - 1)) ? v0 : (float)(L2 - 1);
+                db[1][p] = __builtin_floorf((t - 1.0f) * 0.5f + 0.5f) * 2.0f + 1.0f;
+            }
+            float err0 = 0.f, err1 = 0.f;
+            #pragma unroll
+            for (int p = 0; p < 4; p++)
+                if (p < err_ch) { err0 += sq(e[i][p] - db[0][p]); err1 += sq(e[i][p] - db[1][p]); }
+            const bool first = err0 < err1;
+            #pragma unroll
+            for (int p = 0; p < 4; p++) {
+                q[i][p] = (int32_t)(first ? db[0][p] : db[1][p]);
+                d[i][p] = (MODE == 7) ? expand_to_byte(q[i][p], 6) : q[i][p];
+            }
+            continue;
+        }
         int32_t qb[2][4];
         float db[2][4];
         #pragma unroll
@@ -84,7 +110,7 @@ __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4
             #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const uint32_t v = (uint32_t)f2i<SAFE>((e[i][p] * INV255 * (float)L2 - (float)b) * 0.5f + 0.5f) * 2u + (uint32_t)b;
-                qb[b][p] = iclamp((int32_t)v, b, L2 - 1 + b);
+                qb[b][p] = SAFE ? ((b == 0) ? min((int32_t)v, L2 - 1) : (int32_t)v) : iclamp((int32_t)v, b, L2 - 1 + b);
                 // mode 0 compares in 8-bit space; modes 3/6 codes are 8-bit; mode 7 compares raw 6-bit codes
                 // against 8-bit targets (reference quirk, kernel.ispc:1003-1017)
                 db[b][p] = (float)((MODE == 0) ? expand_to_byte(qb[b][p], 5) : qb[b][p]);
@@ -115,7 +141,7 @@ __device__ __forceinline__ void quant_shared_pbit(int32_t (&q)[2][4], int32_t (&
             #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const uint32_t v = (uint32_t)f2i<SAFE>((e[i][p] * INV255 * 127.0f - (float)b) * 0.5f + 0.5f) * 2u + (uint32_t)b;
-                qb[b][i][p] = iclamp((int32_t)v, b, 126 + b);
+                qb[b][i][p] = SAFE ? ((b == 0) ? min((int32_t)v, 126) : (int32_t)v) : iclamp((int32_t)v, b, 126 + b);
                 db[b][i][p] = (float)expand_to_byte(qb[b][i][p], 7);
             }
     float err0 = 0.f, err1 = 0.f;
@@ -142,7 +168,8 @@ __device__ __forceinline__ void quant_plain(int32_t (&q)[2][4], int32_t (&d)[2][
     for (int i = 0; i < 2; i++)
         #pragma unroll
         for (int p = 0; p < 4; p++) {
-            q[i][p] = iclamp(f2i<SAFE>(e[i][p] * INV255 * (float)(L - 1) + 0.5f), 0, L - 1);
+            const int32_t v = f2i<SAFE>(e[i][p] * INV255 * (float)(L - 1) + 0.5f);
+            q[i][p] = SAFE ? v : iclamp(v, 0, L - 1);          // e in [0,255]: e/255*(L-1) + 0.5 < L, never negative
             d[i][p] = expand_to_byte(q[i][p], BITS);
         }
 }

@@ -247,12 +247,13 @@ __device__ __forceinline__ Segment make_segment(const int32_t (&d)[2][4])
         dd = dot2(s.ba01, s.ba01, ba2 * ba2);
     }
     const float dn = -(float)dd;
+    const float r = (dd == 0) ? 0.0f : 1.0f / dn;                          // one IEEE divide per segment
     if (BITS <= 3) {
-        s.k0 = (dd == 0) ? 0.0f : (float)(1 << BITS) / dn;                 // IEEE divides, once per segment
-        s.k1 = (dd == 0) ? 0.5f : 0.5f + (-0.25f) / dn;
+        s.k0 = (float)(1 << BITS) * r;                                      // = RN(LEVELS/dn): scaling by 2^k commutes with RN
+        s.k1 = 0.5f - 0.25f * r;                                            // = RN(0.5 + RN(-0.25/dn))
     } else {
         s.k0 = dn;
-        s.k1 = (dd == 0) ? 0.0f : 1.0f / dn;
+        s.k1 = r;
     }
     return s;
 }
