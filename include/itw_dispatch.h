@@ -1,0 +1,89 @@
+/*
+ * itw_dispatch.h -- portable restatement of the reference's threading / dispatch layer
+ * (3rdParty/Intel/Source/win32Threads.h:24-80, win32Threads.cpp:98-329): the immediate caller of the
+ * CompressBlocks* C ABI.  Same entry points, same argument meaning; Win32 types replaced by portable ones
+ * (BYTE -> uint8_t, DXGI_FORMAT -> int carrying the DXGI_FORMAT_* value) and C linkage, so any host language can
+ * bind it.
+ *
+ * What changes underneath: the reference keeps a pool of up to 64 Win32 threads and hands each a 4-row-aligned band
+ * of the surface (win32Threads.cpp:211-249).  Here a "worker" is a GPU: CompressImageMT cuts the surface with the
+ * same band rule over GetProcessorCount() = number of visible MI355X devices and runs one band per device from a
+ * persistent pool of host threads (one per device), so a single-GPU box makes ONE whole-surface call instead of
+ * dozens of few-thousand-pixel calls, and an 8-GPU node encodes 8 bands concurrently in one process.
+ */
+#ifndef ITW_DISPATCH_H
+#define ITW_DISPATCH_H
+
+#include "ispc_texcomp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* win32Threads.h:24 */
+typedef void (CompressionFunc)(const rgba_surface* input, uint8_t* output);
+
+/* the DXGI_FORMAT values the dispatch layer understands (dxgiformat.h; win32Threads.cpp:192-209) */
+enum {
+    ITW_DXGI_FORMAT_BC1_UNORM = 71, ITW_DXGI_FORMAT_BC1_UNORM_SRGB = 72,
+    ITW_DXGI_FORMAT_BC3_UNORM = 77, ITW_DXGI_FORMAT_BC3_UNORM_SRGB = 78,
+    ITW_DXGI_FORMAT_BC6H_UF16 = 95, ITW_DXGI_FORMAT_BC6H_SF16 = 96,
+    ITW_DXGI_FORMAT_BC7_UNORM = 98, ITW_DXGI_FORMAT_BC7_UNORM_SRGB = 99
+};
+
+/* win32Threads.h:52-55 / win32Threads.cpp:98-190.  GetProcessorCount(): number of workers = visible GPUs (>= 1).
+ * InitWin32Threads() starts the pool (idempotent); DestroyThreads() joins it.  CompressImageMT initialises lazily. */
+int  GetProcessorCount(void);
+void InitWin32Threads(void);
+void DestroyThreads(void);
+
+/* win32Threads.cpp:192-209: 8 for BC1 (and anything unknown), 16 for BC3 / BC7 / BC6H */
+int  GetBytesPerBlock(int dxgi_format);
+
+/* win32Threads.cpp:211-249, 277-282.  `input`/`output` are host or device pointers exactly as CompressBlocks* accepts
+ * them (device pointers must be reachable from every GPU that takes a band, i.e. single-GPU or managed memory).
+ * Blocks until the whole surface is encoded; returns true like the reference. */
+bool CompressImageMT(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format);
+bool CompressImageST(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format);
+
+/* win32Threads.h:58-80 / win32Threads.cpp:289-329: profile trampolines */
+void CompressImageBC1(const rgba_surface* input, uint8_t* output);
+void CompressImageBC3(const rgba_surface* input, uint8_t* output);
+void CompressImageBC7_ultrafast(const rgba_surface* input, uint8_t* output);
+void CompressImageBC7_veryfast(const rgba_surface* input, uint8_t* output);
+void CompressImageBC7_fast(const rgba_surface* input, uint8_t* output);
+void CompressImageBC7_basic(const rgba_surface* input, uint8_t* output);
+void CompressImageBC7_slow(const rgba_surface* input, uint8_t* output);
+void CompressImageBC7_alpha_ultrafast(const rgba_surface* input, uint8_t* output);
+void CompressImageBC7_alpha_veryfast(const rgba_surface* input, uint8_t* output);
+void CompressImageBC7_alpha_fast(const rgba_surface* input, uint8_t* output);
+void CompressImageBC7_alpha_basic(const rgba_surface* input, uint8_t* output);
+void CompressImageBC7_alpha_slow(const rgba_surface* input, uint8_t* output);
+void CompressImageBC6H_veryfast(const rgba_surface* input, uint8_t* output);
+void CompressImageBC6H_fast(const rgba_surface* input, uint8_t* output);
+void CompressImageBC6H_basic(const rgba_surface* input, uint8_t* output);
+void CompressImageBC6H_slow(const rgba_surface* input, uint8_t* output);
+void CompressImageBC6H_veryslow(const rgba_surface* input, uint8_t* output);
+
+/* The plugin's slice loop with progress / early out (IntelPlugin.cpp:851-879): the surface is cut into
+ * `slices = width*height / slice_pixels` (>= 1) runs of block rows, `progress(i, slices, user)` is polled before every
+ * slice but the first and aborts the job when it returns false (the call then returns false; slices already written
+ * stay written).  `target` is the block array with `block_row_pitch` bytes between block rows (the reference passes
+ * the DDS image's rowPitch).  slice_pixels <= 0 selects the reference's 0x40000; a GPU caller wants it much larger. */
+typedef bool (ItwProgressFunc)(int done, int total, void* user);
+bool itwCompressImageSliced(const rgba_surface* source, uint8_t* target, int64_t block_row_pitch, CompressionFunc* cmpFunc,
+                            int dxgi_format, bool multithreaded, int64_t slice_pixels, ItwProgressFunc* progress, void* user);
+
+/* Pad to multiples of 4 by edge replication (IntelPlugin.cpp:893-928): the step immediately before the ABI.
+ * pixel_size = 4 (RGBA8) or 8 (RGBA16F).  Host version: returns a surface whose ptr was allocated with malloc()
+ * (free with itwFreeSurface); the reference allocates with new[] and leaves ownership to the caller likewise.
+ * Device version: `out_ptr` is a caller-allocated device buffer of ((w+3)&~3)*pixel_size x ((h+3)&~3) bytes, tight
+ * pitch; asynchronous on the calling thread's stream (itwSetStream). */
+rgba_surface itwPadToMultipleOf4(const rgba_surface* input, int pixel_size);
+void itwFreeSurface(rgba_surface* s);
+void itwPadToMultipleOf4Device(const rgba_surface* input, int pixel_size, uint8_t* out_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,269 @@
+// dispatch.hip -- portable, GPU-aware restatement of the reference's dispatch layer (include/itw_dispatch.h):
+// CompressImageMT/ST and the profile trampolines (win32Threads.cpp:192-329), the plugin's slice loop with progress /
+// early out (IntelPlugin.cpp:851-879) and the pad-to-multiple-of-4 pre-pass (IntelPlugin.cpp:893-928), the latter
+// also as a device kernel so a GPU-resident pipeline never leaves HBM.
+//
+// Workers are GPUs, not CPU cores: one persistent host thread per visible device, each bound to its device once.
+// A band is handed to a worker exactly like win32Threads.cpp:217-231 cuts them, so with host pointers every GPU
+// stages and encodes its own band concurrently (H2D/D2H of different devices overlap on their own PCIe links);
+// a device-resident surface is encoded by the device that owns it, in one call.
+#include <hip/hip_runtime.h>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include "../../include/itw_dispatch.h"
+#include "../../include/itw_amd.h"
+
+namespace {
+
+struct Job {
+    rgba_surface input;
+    uint8_t* output = nullptr;
+    CompressionFunc* fn = nullptr;
+    bool pending = false;
+};
+
+struct Pool {
+    std::mutex m;
+    std::condition_variable work, done;
+    std::vector<std::thread> threads;
+    std::vector<Job> jobs;
+    int outstanding = 0;
+    bool quit = false;
+    std::mutex submit;          // one CompressImageMT at a time, like the reference's single global pool
+
+    void run(int idx)
+    {
+        (void)hipSetDevice(idx);
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            work.wait(lk, [&] { return quit || jobs[idx].pending; });
+            if (quit) return;
+            Job j = jobs[idx];
+            lk.unlock();
+            if (j.input.height >= 4) j.fn(&j.input, j.output);     // win32Threads.cpp:263
+            lk.lock();
+            jobs[idx].pending = false;
+            if (--outstanding == 0) done.notify_all();
+        }
+    }
+};
+
+Pool* g_pool = nullptr;
+std::mutex g_pool_mutex;
+
+int device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) n = 1;
+    return n > 64 ? 64 : n;     // kMaxWinThreads
+}
+
+Pool* pool()
+{
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    if (!g_pool) {
+        Pool* p = new Pool;
+        const int n = device_count();
+        p->jobs.resize(n);
+        for (int i = 0; i < n; i++) p->threads.emplace_back([p, i] { p->run(i); });
+        g_pool = p;
+    }
+    return g_pool;
+}
+
+bool is_device_pointer(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice;
+}
+
+template <int PIXEL_WORDS>
+__global__ void pad_kernel(const uint32_t* __restrict__ src, int64_t src_stride_words, int w, int h,
+                           uint32_t* __restrict__ dst, int ow, int oh)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= ow || y >= oh) return;
+    const int sx = min(x, w - 1), sy = min(y, h - 1);          // edge replication
+    const uint32_t* s = src + (int64_t)sy * src_stride_words + (int64_t)sx * PIXEL_WORDS;
+    uint32_t* d = dst + ((int64_t)y * ow + x) * PIXEL_WORDS;
+#pragma unroll
+    for (int i = 0; i < PIXEL_WORDS; i++) d[i] = s[i];
+}
+
+} // namespace
+
+extern "C" {
+
+int GetProcessorCount(void) { return device_count(); }
+
+void InitWin32Threads(void) { (void)pool(); }
+
+void DestroyThreads(void)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mutex);
+    if (!g_pool) return;
+    {
+        std::lock_guard<std::mutex> l2(g_pool->m);
+        g_pool->quit = true;
+    }
+    g_pool->work.notify_all();
+    for (auto& t : g_pool->threads) t.join();
+    delete g_pool;
+    g_pool = nullptr;
+}
+
+int GetBytesPerBlock(int f)
+{
+    switch (f) {
+    case ITW_DXGI_FORMAT_BC3_UNORM_SRGB: case ITW_DXGI_FORMAT_BC3_UNORM:
+    case ITW_DXGI_FORMAT_BC7_UNORM_SRGB: case ITW_DXGI_FORMAT_BC7_UNORM:
+    case ITW_DXGI_FORMAT_BC6H_UF16: case ITW_DXGI_FORMAT_BC6H_SF16:
+        return 16;
+    default:
+        return 8;
+    }
+}
+
+bool CompressImageST(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int)
+{
+    (*cmpFunc)(input, output);
+    return true;
+}
+
+bool CompressImageMT(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format)
+{
+    Pool* p = pool();
+    const int n = (int)p->threads.size();
+    // a surface that already lives on one GPU is encoded there, in one call
+    if (n == 1 || is_device_pointer(input->ptr) || is_device_pointer(output)) return CompressImageST(input, output, cmpFunc, dxgi_format);
+
+    const int bpb = GetBytesPerBlock(dxgi_format);
+    const int lines = (input->height + n - 1) / n;               // win32Threads.cpp:217
+    std::lock_guard<std::mutex> one(p->submit);
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        for (int i = 0; i < n; i++) {
+            int y0 = (lines * i) / 4 * 4, y1 = (lines * (i + 1)) / 4 * 4;
+            if (y1 > input->height) y1 = input->height;
+            Job& j = p->jobs[i];
+            j.input = *input;
+            j.input.ptr = input->ptr + (int64_t)y0 * input->stride;
+            j.input.height = y1 - y0;
+            j.output = output + (int64_t)(y0 / 4) * (input->width / 4) * bpb;
+            j.fn = cmpFunc;
+            j.pending = true;
+        }
+        p->outstanding = n;
+    }
+    p->work.notify_all();
+    std::unique_lock<std::mutex> lk(p->m);
+    p->done.wait(lk, [&] { return p->outstanding == 0; });
+    return true;
+}
+
+void CompressImageBC1(const rgba_surface* input, uint8_t* output) { CompressBlocksBC1(input, output); }
+void CompressImageBC3(const rgba_surface* input, uint8_t* output) { CompressBlocksBC3(input, output); }
+
+#define ITW_BC7_TRAMPOLINE(profile)                                                    \
+    void CompressImageBC7_##profile(const rgba_surface* input, uint8_t* output)        \
+    {                                                                                  \
+        bc7_enc_settings settings;                                                     \
+        std::memset(&settings, 0, sizeof settings);                                    \
+        GetProfile_##profile(&settings);                                               \
+        CompressBlocksBC7(input, output, &settings);                                   \
+    }
+#define ITW_BC6H_TRAMPOLINE(profile)                                                   \
+    void CompressImageBC6H_##profile(const rgba_surface* input, uint8_t* output)       \
+    {                                                                                  \
+        bc6h_enc_settings settings;                                                    \
+        std::memset(&settings, 0, sizeof settings);                                    \
+        GetProfile_bc6h_##profile(&settings);                                          \
+        CompressBlocksBC6H(input, output, &settings);                                  \
+    }
+ITW_BC7_TRAMPOLINE(ultrafast) ITW_BC7_TRAMPOLINE(veryfast) ITW_BC7_TRAMPOLINE(fast) ITW_BC7_TRAMPOLINE(basic) ITW_BC7_TRAMPOLINE(slow)
+ITW_BC7_TRAMPOLINE(alpha_ultrafast) ITW_BC7_TRAMPOLINE(alpha_veryfast) ITW_BC7_TRAMPOLINE(alpha_fast)
+ITW_BC7_TRAMPOLINE(alpha_basic) ITW_BC7_TRAMPOLINE(alpha_slow)
+ITW_BC6H_TRAMPOLINE(veryfast) ITW_BC6H_TRAMPOLINE(fast) ITW_BC6H_TRAMPOLINE(basic) ITW_BC6H_TRAMPOLINE(slow) ITW_BC6H_TRAMPOLINE(veryslow)
+
+bool itwCompressImageSliced(const rgba_surface* source, uint8_t* target, int64_t block_row_pitch, CompressionFunc* cmpFunc,
+                            int dxgi_format, bool multithreaded, int64_t slice_pixels, ItwProgressFunc* progress, void* user)
+{
+    if (!cmpFunc) return false;
+    if (slice_pixels <= 0) slice_pixels = 0x40000;                                   // IntelPlugin.cpp:851
+    int slices = (int)(((int64_t)source->width * source->height) / slice_pixels);
+    if (slices < 1) slices = 1;
+    // the ABI packs block rows tightly; a wider pitch would need one call per block row
+    const int64_t tight = (int64_t)(source->width / 4) * GetBytesPerBlock(dxgi_format);
+    if (block_row_pitch != tight) {
+        std::fprintf(stderr, "itwCompressImageSliced: block_row_pitch %lld != %lld (tight)\n", (long long)block_row_pitch, (long long)tight);
+        return false;
+    }
+    for (int i = 0; i < slices; i++) {
+        if (i > 0 && progress && !progress(i, slices, user)) return false;          // allow an early out
+        int ylo = (int)((int64_t)i * source->height / slices) & ~0x3;
+        int yhi = (int)((int64_t)(i + 1) * source->height / slices) & ~0x3;
+        if (yhi > source->height) yhi = source->height;
+        if (yhi > ylo) {
+            rgba_surface input = *source;
+            input.ptr += (int64_t)input.stride * ylo;
+            input.height = yhi - ylo;
+            uint8_t* dst = target + block_row_pitch * (ylo >> 2);
+            if (multithreaded) CompressImageMT(&input, dst, cmpFunc, dxgi_format);
+            else               CompressImageST(&input, dst, cmpFunc, dxgi_format);
+        }
+    }
+    return true;
+}
+
+rgba_surface itwPadToMultipleOf4(const rgba_surface* input, int pixel_size)
+{
+    rgba_surface out;
+    out.width = (input->width + 3) & ~3;
+    out.height = (input->height + 3) & ~3;
+    out.stride = out.width * pixel_size;
+    out.ptr = (uint8_t*)std::malloc((size_t)out.height * out.stride);
+    if (!out.ptr) { std::fprintf(stderr, "itwPadToMultipleOf4: out of memory\n"); std::abort(); }
+    for (int y = 0; y < input->height; y++) {
+        const uint8_t* rs = input->ptr + (int64_t)y * input->stride;
+        uint8_t* rd = out.ptr + (int64_t)y * out.stride;
+        std::memcpy(rd, rs, (size_t)input->width * pixel_size);
+        for (int x = input->width; x < out.width; x++)                               // trailing pixels
+            std::memcpy(rd + (int64_t)x * pixel_size, rs + (int64_t)(input->width - 1) * pixel_size, pixel_size);
+    }
+    for (int y = input->height; y < out.height; y++) {                              // extra rows
+        uint8_t* rd = out.ptr + (int64_t)y * out.stride;
+        std::memcpy(rd, rd - out.stride, out.stride);
+    }
+    return out;
+}
+
+void itwFreeSurface(rgba_surface* s)
+{
+    if (s && s->ptr) { std::free(s->ptr); s->ptr = nullptr; }
+}
+
+void itwPadToMultipleOf4Device(const rgba_surface* input, int pixel_size, uint8_t* out_ptr)
+{
+    const int w = input->width, h = input->height;
+    if (w <= 0 || h <= 0) return;
+    if ((pixel_size != 4 && pixel_size != 8) || (input->stride & 3) || ((uintptr_t)input->ptr & 3) || ((uintptr_t)out_ptr & 3)) {
+        std::fprintf(stderr, "itwPadToMultipleOf4Device: pixel_size must be 4 or 8, pointers and stride 4-byte aligned\n");
+        std::abort();
+    }
+    const int ow = (w + 3) & ~3, oh = (h + 3) & ~3;
+    hipStream_t st = (hipStream_t)itwGetStream();
+    const dim3 blk(256), grid((unsigned)((ow + 255) / 256), (unsigned)oh);
+    if (pixel_size == 4)
+        hipLaunchKernelGGL((pad_kernel<1>), grid, blk, 0, st, (const uint32_t*)input->ptr, (int64_t)(input->stride / 4), w, h, (uint32_t*)out_ptr, ow, oh);
+    else
+        hipLaunchKernelGGL((pad_kernel<2>), grid, blk, 0, st, (const uint32_t*)input->ptr, (int64_t)(input->stride / 4), w, h, (uint32_t*)out_ptr, ow, oh);
+    if (hipGetLastError() != hipSuccess) { std::fprintf(stderr, "itwPadToMultipleOf4Device: launch failed\n"); std::abort(); }
+}
+
+} // extern "C"

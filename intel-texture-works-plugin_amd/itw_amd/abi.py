@@ -15,7 +15,16 @@ EXPORTED_SYMBOLS = tuple(
     ["CompressBlocksBC1", "CompressBlocksBC3", "CompressBlocksBC6H", "CompressBlocksBC7"]
     + ["GetProfile_" + p for p in BC7_PROFILES] + ["GetProfile_bc6h_" + p for p in BC6H_PROFILES]
     + ["itwSetStream", "itwGetStream", "itwDeviceInfo", "itwVersion", "itwBandForPart",
-       "itwTestRcp", "itwTestRsqrt", "itwTestF2I"])
+       "itwTestRcp", "itwTestRsqrt", "itwTestF2I"]
+    # include/itw_dispatch.h: the reference's dispatch layer (win32Threads.h), slice loop, pad pre-pass
+    + ["GetProcessorCount", "InitWin32Threads", "DestroyThreads", "GetBytesPerBlock", "CompressImageMT", "CompressImageST",
+       "CompressImageBC1", "CompressImageBC3"]
+    + ["CompressImageBC7_" + p for p in BC7_PROFILES] + ["CompressImageBC6H_" + p for p in BC6H_PROFILES]
+    + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device"]
+    # include/itw_dds.h: DDS container
+    + ["itwDdsLevelBytes", "itwDdsHeaderBytes", "itwDdsFileBytes", "itwDdsWriteHeader", "itwDdsReadHeader", "itwDdsWriteFile"])
+
+
 
 
 class RgbaSurface(C.Structure):
@@ -39,6 +48,18 @@ class Bc6hSettings(C.Structure):
 
 
 assert C.sizeof(RgbaSurface) == 24 and C.sizeof(Bc7Settings) == 64 and C.sizeof(Bc6hSettings) == 16
+
+DXGI_FORMAT = {"bc1": 71, "bc1_srgb": 72, "bc3": 77, "bc3_srgb": 78, "bc6h": 95, "bc6h_sf16": 96, "bc7": 98, "bc7_srgb": 99}
+
+
+class DdsDesc(C.Structure):
+    """struct ItwDdsDesc (itw_dds.h)."""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("mip_levels", C.c_uint32), ("dxgi_format", C.c_uint32),
+                ("is_cubemap", C.c_uint32), ("array_size", C.c_uint32)]
+
+
+COMPRESSION_FUNC = C.CFUNCTYPE(None, C.POINTER(RgbaSurface), C.c_void_p)
+PROGRESS_FUNC = C.CFUNCTYPE(C.c_bool, C.c_int, C.c_int, C.c_void_p)
 
 _lib = None
 
@@ -72,6 +93,38 @@ def lib():
         for n in ("itwTestRcp", "itwTestRsqrt", "itwTestF2I"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
             getattr(L, n).restype = None
+        # dispatch layer (itw_dispatch.h)
+        L.GetProcessorCount.restype = C.c_int
+        L.GetBytesPerBlock.argtypes = [C.c_int]
+        L.GetBytesPerBlock.restype = C.c_int
+        for n in ("CompressImageMT", "CompressImageST"):
+            getattr(L, n).argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_void_p, C.c_int]
+            getattr(L, n).restype = C.c_bool
+        for n in ["CompressImageBC1", "CompressImageBC3"] + ["CompressImageBC7_" + p for p in BC7_PROFILES] \
+                + ["CompressImageBC6H_" + p for p in BC6H_PROFILES]:
+            getattr(L, n).argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
+            getattr(L, n).restype = None
+        L.itwCompressImageSliced.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_bool,
+                                             C.c_int64, C.c_void_p, C.c_void_p]
+        L.itwCompressImageSliced.restype = C.c_bool
+        L.itwPadToMultipleOf4.argtypes = [C.POINTER(RgbaSurface), C.c_int]
+        L.itwPadToMultipleOf4.restype = RgbaSurface
+        L.itwFreeSurface.argtypes = [C.POINTER(RgbaSurface)]
+        L.itwFreeSurface.restype = None
+        L.itwPadToMultipleOf4Device.argtypes = [C.POINTER(RgbaSurface), C.c_int, C.c_void_p]
+        L.itwPadToMultipleOf4Device.restype = None
+        # DDS container (itw_dds.h)
+        L.itwDdsLevelBytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.itwDdsLevelBytes.restype = C.c_size_t
+        for n in ("itwDdsHeaderBytes", "itwDdsFileBytes"):
+            getattr(L, n).argtypes = [C.POINTER(DdsDesc)]
+            getattr(L, n).restype = C.c_size_t
+        L.itwDdsWriteHeader.argtypes = [C.POINTER(DdsDesc), C.c_void_p, C.c_size_t]
+        L.itwDdsWriteHeader.restype = C.c_size_t
+        L.itwDdsReadHeader.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(DdsDesc)]
+        L.itwDdsReadHeader.restype = C.c_size_t
+        L.itwDdsWriteFile.argtypes = [C.POINTER(DdsDesc), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_size_t]
+        L.itwDdsWriteFile.restype = C.c_size_t
         _lib = L
     return _lib
 
@@ -158,4 +211,53 @@ def compress(fmt, img, settings=None, out=None):
         L.itwSetStream(torch.cuda.current_stream(img.device).cuda_stream)
         surf = RgbaSurface(img.data_ptr(), w, h, img.stride(0) * es)
         _call(fmt, surf, out.data_ptr(), settings)
+    return out
+
+
+def image_func(fmt, profile=None):
+    """Address of the CompressImage* trampoline (win32Threads.h:58-80) for a format / profile, as a void*."""
+    name = {"bc1": "CompressImageBC1", "bc3": "CompressImageBC3"}.get(fmt) or \
+        ("CompressImageBC7_" if fmt == "bc7" else "CompressImageBC6H_") + (profile or "slow")
+    return C.cast(getattr(lib(), name), C.c_void_p)
+
+
+def compress_image(fmt, img, profile=None, multithreaded=True, slice_pixels=0, progress=None):
+    """The plugin's save path below the pixel conversion (IntelPlugin.cpp:816-884): slice loop -> CompressImageMT/ST ->
+    trampoline -> CompressBlocks*.  img: host numpy (H, W, 4) uint8 / uint16 half bits.  Returns (ok, blocks)."""
+    import numpy as np
+    h, w = img.shape[:2]
+    out = np.zeros((h // 4) * (w // 4) * BYTES_PER_BLOCK[fmt], dtype=np.uint8)
+    surf = RgbaSurface(img.ctypes.data, w, h, img.strides[0])
+    cb = PROGRESS_FUNC(progress) if progress else None
+    ok = lib().itwCompressImageSliced(C.byref(surf), out.ctypes.data, (w // 4) * BYTES_PER_BLOCK[fmt], image_func(fmt, profile),
+                                      DXGI_FORMAT[fmt], multithreaded, slice_pixels, C.cast(cb, C.c_void_p) if cb else None, None)
+    return bool(ok), out
+
+
+def pad_to_multiple_of_4(img):
+    """Host pre-pass (IntelPlugin.cpp:893-928) through the library; returns a new numpy array."""
+    import numpy as np
+    h, w = img.shape[:2]
+    ps = 4 * img.itemsize
+    surf = RgbaSurface(img.ctypes.data, w, h, img.strides[0])
+    out = lib().itwPadToMultipleOf4(C.byref(surf), ps)
+    n = out.height * out.stride
+    arr = np.ctypeslib.as_array(C.cast(out.ptr, C.POINTER(C.c_uint8)), shape=(n,)).copy()
+    lib().itwFreeSurface(C.byref(out))
+    return arr.view(img.dtype).reshape(out.height, out.width, 4)
+
+
+def dds_file(fmt_key, width, height, levels, mip_levels=1, cubemap=False, array_size=1):
+    """DDS file bytes for block arrays `levels` (file order).  fmt_key: a key of DXGI_FORMAT."""
+    import numpy as np
+    d = DdsDesc(width, height, mip_levels, DXGI_FORMAT[fmt_key], 1 if cubemap else 0, array_size)
+    total = lib().itwDdsFileBytes(C.byref(d))
+    if not total:
+        raise ValueError("unsupported DDS description")
+    out = np.empty(total, dtype=np.uint8)
+    keep = [np.ascontiguousarray(np.asarray(l, dtype=np.uint8)) for l in levels]
+    ptrs = (C.c_void_p * len(keep))(*[k.ctypes.data for k in keep])
+    n = lib().itwDdsWriteFile(C.byref(d), ptrs, len(keep), out.ctypes.data, out.size)
+    if n != total:
+        raise ValueError("itwDdsWriteFile failed (level count / sizes)")
     return out

@@ -1,0 +1,104 @@
+"""The dispatch layer above the ABI (include/itw_dispatch.h = win32Threads.h:24-80 restated portably): band rule,
+bytes per block, host pad pre-pass (CPU); on the GPU: every trampoline and CompressImageMT/ST byte-equal to the direct
+CompressBlocks* call and to the oracle, the slice loop's progress / early-out contract, and the device pad kernel."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+def test_bytes_per_block_and_worker_count(itw):
+    L = itw.lib()
+    assert [L.GetBytesPerBlock(f) for f in (71, 72, 77, 78, 95, 96, 98, 99, 0, 28)] == [8, 8, 16, 16, 16, 16, 16, 16, 8, 8]
+    assert L.GetProcessorCount() >= 1                        # "1 or more" (win32Threads.h:51)
+
+
+@pytest.mark.parametrize("shape,dtype", [((7, 5), np.uint8), ((4, 4), np.uint8), ((1, 1), np.uint16), ((10, 13), np.uint16),
+                                         ((339, 127), np.uint8)])
+def test_host_pad_replicates_edges(itw, shape, dtype):
+    """IntelPlugin.cpp:893-928: new texels copy the last texel of the row, new rows copy the last row."""
+    rng = np.random.default_rng(5)
+    h, w = shape
+    img = rng.integers(0, np.iinfo(dtype).max, size=(h, w, 4), dtype=dtype)
+    got = itw.pad_to_multiple_of_4(img)
+    H, W = (h + 3) & ~3, (w + 3) & ~3
+    want = np.pad(img, ((0, H - h), (0, W - w), (0, 0)), mode="edge")
+    assert got.shape == (H, W, 4) and np.array_equal(got, want)
+
+
+def test_host_pad_respects_stride(itw):
+    rng = np.random.default_rng(6)
+    big = rng.integers(0, 255, size=(9, 16, 4), dtype=np.uint8)
+    view = big[:, 2:9]                                        # 7 wide, row stride of 16 texels
+    assert np.array_equal(itw.pad_to_multiple_of_4(view), np.pad(view, ((0, 3), (0, 1), (0, 0)), mode="edge"))
+
+
+# ---- GPU ------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_trampolines_equal_direct_calls_and_oracle(itw, gpu, oracle):
+    from itw_amd import surfaces
+    ldr = surfaces.ldr_smooth(64, 96)
+    hdr = surfaces.hdr_smooth(32, 64)
+    cases = [("bc1", ldr, None), ("bc3", ldr, None)] + [("bc7", ldr, p) for p in itw.BC7_PROFILES] \
+        + [("bc6h", hdr, p) for p in itw.BC6H_PROFILES]
+    for fmt, img, prof in cases:
+        h, w = img.shape[:2]
+        out = np.zeros((h // 4) * (w // 4) * itw.BYTES_PER_BLOCK[fmt], dtype=np.uint8)
+        surf = itw.RgbaSurface(img.ctypes.data, w, h, img.strides[0])
+        fn = itw.image_func(fmt, prof)
+        for entry in ("CompressImageMT", "CompressImageST"):
+            out[:] = 0
+            assert getattr(itw.lib(), entry)(C.byref(surf), out.ctypes.data, fn, itw.DXGI_FORMAT[fmt])
+            assert np.array_equal(out, itw.compress_numpy(fmt, img, prof)), (entry, fmt, prof)
+        assert np.array_equal(out, oracle.encode(fmt, img, prof).reshape(-1)), (fmt, prof)
+
+
+@pytest.mark.gpu
+def test_slice_loop_progress_and_abort(itw, gpu, oracle):
+    """IntelPlugin.cpp:851-879: `slices = w*h / slice_pixels`, progress polled before every slice but the first, a false
+    return stops the job and leaves the slices already written."""
+    from itw_amd import surfaces
+    img = surfaces.ldr_smooth(128, 64)                        # 8192 px
+    want = oracle.encode("bc7", img, "veryfast").reshape(-1)
+    calls = []
+    ok, out = itw.compress_image("bc7", img, "veryfast", slice_pixels=2048, progress=lambda i, n, u: calls.append((i, n)) or True)
+    assert ok and calls == [(1, 4), (2, 4), (3, 4)] and np.array_equal(out, want)
+    ok, out = itw.compress_image("bc7", img, "veryfast", multithreaded=False, slice_pixels=2048, progress=lambda i, n, u: i < 2)
+    assert not ok
+    rows = 128 // 4                                           # 32 block rows, 8 per slice, 16 blocks of 16 B per row
+    done = 2 * 8 * 16 * 16
+    assert np.array_equal(out[:done], want[:done]) and not out[done:].any()
+    ok, out = itw.compress_image("bc1", img)                  # default slice size: one slice, no callback needed
+    assert ok and np.array_equal(out, oracle.encode("bc1", img).reshape(-1))
+
+
+@pytest.mark.gpu
+def test_device_pad_kernel(itw, gpu):
+    import torch
+    rng = np.random.default_rng(8)
+    for (h, w), dtype in (((7, 5), np.uint8), ((339, 127), np.uint8), ((10, 13), np.int16), ((4, 8), np.uint8)):
+        img = rng.integers(0, 127, size=(h, w, 4)).astype(dtype)
+        d_in = torch.from_numpy(img).to(gpu)
+        H, W = (h + 3) & ~3, (w + 3) & ~3
+        d_out = torch.zeros((H, W, 4), dtype=d_in.dtype, device=gpu)
+        itw.lib().itwSetStream(torch.cuda.current_stream().cuda_stream)
+        surf = itw.RgbaSurface(d_in.data_ptr(), w, h, d_in.stride(0) * d_in.element_size())
+        itw.lib().itwPadToMultipleOf4Device(C.byref(surf), 4 * d_in.element_size(), d_out.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(d_out.cpu().numpy(), np.pad(img, ((0, H - h), (0, W - w), (0, 0)), mode="edge"))
+
+
+@pytest.mark.gpu
+def test_pad_then_encode_device_resident(itw, gpu, oracle):
+    """The pre-pass feeding the ABI without leaving HBM: a 127 x 339 surface (landscape-detail.jpg's size)."""
+    import torch
+    from itw_amd import surfaces
+    img = surfaces.ldr_smooth(340, 128)[:339, :127].copy()
+    d_in = torch.from_numpy(img).to(gpu)
+    d_pad = torch.empty((340, 128, 4), dtype=torch.uint8, device=gpu)
+    itw.lib().itwSetStream(torch.cuda.current_stream().cuda_stream)
+    surf = itw.RgbaSurface(d_in.data_ptr(), 127, 339, 127 * 4)
+    itw.lib().itwPadToMultipleOf4Device(C.byref(surf), 4, d_pad.data_ptr())
+    got = itw.compress("bc3", d_pad).cpu().numpy()
+    want = oracle.encode("bc3", itw.pad_to_multiple_of_4(img)).reshape(-1)
+    assert np.array_equal(got, want)
