@@ -31,7 +31,8 @@ enum {
     ITW_DXGI_FORMAT_BC7_UNORM = 98, ITW_DXGI_FORMAT_BC7_UNORM_SRGB = 99
 };
 
-/* win32Threads.h:52-55 / win32Threads.cpp:98-190.  GetProcessorCount(): number of workers = visible GPUs (>= 1).
+/* win32Threads.h:52-55 / win32Threads.cpp:98-190.  GetProcessorCount(): number of workers = visible GPUs (>= 1), or the
+ * value of the environment variable ITW_WORKERS when set (extra workers share the devices round-robin).
  * InitWin32Threads() starts the pool (idempotent); DestroyThreads() joins it.  CompressImageMT initialises lazily. */
 int  GetProcessorCount(void);
 void InitWin32Threads(void);

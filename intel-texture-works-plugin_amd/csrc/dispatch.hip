@@ -36,9 +36,11 @@ struct Pool {
     bool quit = false;
     std::mutex submit;          // one CompressImageMT at a time, like the reference's single global pool
 
+    int devices = 1;
+
     void run(int idx)
     {
-        (void)hipSetDevice(idx);
+        (void)hipSetDevice(idx % devices);
         std::unique_lock<std::mutex> lk(m);
         for (;;) {
             work.wait(lk, [&] { return quit || jobs[idx].pending; });
@@ -63,12 +65,25 @@ int device_count()
     return n > 64 ? 64 : n;     // kMaxWinThreads
 }
 
+// Workers = devices, unless ITW_WORKERS=<n> asks for more: the extra workers share the devices round-robin.  That is how
+// the 8-band path is exercised on a single-GPU box (tests), and it lets a host overlap staging of one band with the
+// encode of another on one device.
+int worker_count()
+{
+    const int dev = device_count();
+    const char* e = std::getenv("ITW_WORKERS");
+    int n = e ? std::atoi(e) : 0;
+    if (n < 1) n = dev;
+    return n > 64 ? 64 : n;
+}
+
 Pool* pool()
 {
     std::lock_guard<std::mutex> lk(g_pool_mutex);
     if (!g_pool) {
         Pool* p = new Pool;
-        const int n = device_count();
+        const int n = worker_count();
+        p->devices = device_count();
         p->jobs.resize(n);
         for (int i = 0; i < n; i++) p->threads.emplace_back([p, i] { p->run(i); });
         g_pool = p;
@@ -100,7 +115,7 @@ __global__ void pad_kernel(const uint32_t* __restrict__ src, int64_t src_stride_
 
 extern "C" {
 
-int GetProcessorCount(void) { return device_count(); }
+int GetProcessorCount(void) { return worker_count(); }
 
 void InitWin32Threads(void) { (void)pool(); }
 

@@ -102,3 +102,36 @@ def test_pad_then_encode_device_resident(itw, gpu, oracle):
     got = itw.compress("bc3", d_pad).cpu().numpy()
     want = oracle.encode("bc3", itw.pad_to_multiple_of_4(img)).reshape(-1)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_eight_workers_on_one_device(gpu, oracle):
+    """The 8-band path of CompressImageMT (win32Threads.cpp:217-231) on a one-GPU box: ITW_WORKERS=8 starts eight host
+    workers that share device 0; unequal and empty bands included (heights that do not divide by 32)."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import itw_amd
+from itw_amd import surfaces
+from oracle import pyoracle
+L = itw_amd.lib()
+assert L.GetProcessorCount() == 8
+for h, w, fmt, prof in ((100, 64, "bc1", None), (36, 32, "bc3", None), (256, 64, "bc7", "veryfast"), (8, 16, "bc7", "alpha_basic"), (64, 32, "bc6h", "fast")):
+    img = surfaces.hdr_smooth(h, w) if fmt == "bc6h" else surfaces.ldr_smooth(h, w)
+    out = np.zeros((h // 4) * (w // 4) * itw_amd.BYTES_PER_BLOCK[fmt], dtype=np.uint8)
+    surf = itw_amd.RgbaSurface(img.ctypes.data, w, h, img.strides[0])
+    for rep in range(3):
+        out[:] = 0
+        assert L.CompressImageMT(C.byref(surf), out.ctypes.data, itw_amd.image_func(fmt, prof), itw_amd.DXGI_FORMAT[fmt])
+        assert np.array_equal(out, pyoracle.encode(fmt, img, prof).reshape(-1)), (h, w, fmt, prof, rep)
+L.DestroyThreads()
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ITW_WORKERS="8")
+    r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "intel-texture-works-plugin_amd"))],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
