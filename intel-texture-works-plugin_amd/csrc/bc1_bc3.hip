@@ -25,9 +25,10 @@ __device__ __forceinline__ int32_t scale8(int32_t a, int32_t b)
     return (t + (t >> 8)) >> 8;
 }
 
+// inputs are clamped to [0,255] by the callers (fclamp_x86 maps NaN to 0), so the plain conversion is cvttps2dq
 __device__ __forceinline__ int32_t pack565(float cr, float cg, float cb)
 {
-    return ((scale8(f2i_x86(cr), 31) << 11) + (scale8(f2i_x86(cg), 63) << 5) + scale8(f2i_x86(cb), 31)) & 0xffff;
+    return ((scale8(cvt_i32_sat(cr), 31) << 11) + (scale8(cvt_i32_sat(cg), 63) << 5) + scale8(cvt_i32_sat(cb), 31)) & 0xffff;
 }
 
 __device__ __forceinline__ void unpack565(int32_t p, float c[3])        // [kernel.ispc:250-259]
@@ -60,7 +61,8 @@ __device__ __forceinline__ uint32_t project_indices(const float (&px)[3][16], in
     for (int k = 0; k < 16; k++) {
         float dot = 0.f;
         for (int p = 0; p < 3; p++) dot += px[p][k] * dir[p];
-        const int32_t q = iclamp(f2i_x86(dot + bias), 0, 3);
+        // finite and small (|dir| <= 3*255, texels <= 255) or NaN when p0 == p1 (rcp(0)): NaN -> 0 on both routes after the clamp
+        const int32_t q = iclamp(cvt_i32_sat(dot + bias), 0, 3);
         bits += (uint32_t)q << (2 * k);           // q*4^k, no carries: q < 4
     }
     return bits;
@@ -186,12 +188,12 @@ __device__ __forceinline__ void encode_alpha(const float (&a)[16], uint32_t out[
     uint32_t q0 = 0, q1 = 0;      // 8 x 3 bits each
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        int32_t q = 7 - iclamp(f2i_x86((a[k] - lo) * scale + 0.5f), 0, 7);
+        int32_t q = 7 - iclamp(cvt_i32_sat((a[k] - lo) * scale + 0.5f), 0, 7);      // hi - lo >= 0.1: finite, in [0.5, 7.6]
         q = (q > 0) ? q + 1 : q;   // DXT5 order: 0 = alpha0(max), 1 = alpha1(min), 2.. ramp
         q = (q == 8) ? 1 : q;
         if (k < 8) q0 |= (uint32_t)q << (k * 3); else q1 |= (uint32_t)q << ((k - 8) * 3);
     }
-    out[0] = (uint32_t)(iclamp(f2i_x86(lo), 0, 255) * 256 + iclamp(f2i_x86(hi), 0, 255)) | (q0 << 16);
+    out[0] = (uint32_t)(iclamp(cvt_i32_sat(lo), 0, 255) * 256 + iclamp(cvt_i32_sat(hi), 0, 255)) | (q0 << 16);
     out[1] = (q0 >> 16) | (q1 << 8);
 }
 

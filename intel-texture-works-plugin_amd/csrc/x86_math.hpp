@@ -128,6 +128,16 @@ __device__ __forceinline__ int32_t f2i_x86(float f)
     return ok ? (int32_t)f : (int32_t)0x80000000;
 }
 
+// v_cvt_i32_f32: truncation, saturating, NaN -> 0.  Equals cvttps2dq wherever the value is finite and inside the int
+// range; the two also agree after a clamp to [0, n] for NaN and for values below -2^31 (INT_MIN and 0 / INT_MIN both
+// clamp to 0).  They differ for +inf and values >= 2^31 (INT_MIN vs INT_MAX): callers state why those cannot occur.
+__device__ __forceinline__ int32_t cvt_i32_sat(float f)
+{
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+}
+
 // minps / maxps: second operand wins when unordered.
 __device__ __forceinline__ float fmin_x86(float a, float b) { return (a < b) ? a : b; }
 __device__ __forceinline__ float fmax_x86(float a, float b) { return (a > b) ? a : b; }
