@@ -75,6 +75,8 @@ __device__ __forceinline__ int32_t f2i(float f) { return SAFE ? (int32_t)f : f2i
 // converted; of the reference's clamp [b, L2-1+b] only the upper bound of b = 0 can fire (u >= 2^BITS needs
 // e/255*L2 >= L2, i.e. e = 255; for b = 1, u < 2^BITS always).  Modes 3, 6, 7 compare the code itself (kernel.ispc:
 // 1003-1017: mode 7 compares raw 6-bit codes against 8-bit targets, a reference quirk), mode 0 its 5-bit expansion.
+// For b = 1 the reference's u = (t - 1)*0.5 + 0.5 equals t*0.5 exactly when t >= 0.5 (t - 1 is then exact, the rest
+// is scaling and an exactly representable sum); for t < 0.5 both floors are 0.  SAFE paths use floor(t*0.5) directly.
 template <int MODE, bool SAFE>
 __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4], const float (&e)[2][4], int err_ch)
 {
@@ -89,7 +91,7 @@ __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4
                 const float t = e[i][p] * INV255 * (float)L2;
                 const float v0 = __builtin_floorf(t * 0.5f + 0.5f) * 2.0f;
                 db[0][p] = (v0 < (float)(L2 - 1)) ? v0 : (float)(L2 - 1);
-                db[1][p] = __builtin_floorf((t - 1.0f) * 0.5f + 0.5f) * 2.0f + 1.0f;
+                db[1][p] = __builtin_floorf(t * 0.5f) * 2.0f + 1.0f;       // (t-1)/2 + 1/2 = t/2 exactly for t >= 0.5, floor 0 below
             }
             float err0 = 0.f, err1 = 0.f;
             #pragma unroll
@@ -109,7 +111,9 @@ __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4
         for (int b = 0; b < 2; b++)
             #pragma unroll
             for (int p = 0; p < 4; p++) {
-                const uint32_t v = (uint32_t)f2i<SAFE>((e[i][p] * INV255 * (float)L2 - (float)b) * 0.5f + 0.5f) * 2u + (uint32_t)b;
+                const float t = e[i][p] * INV255 * (float)L2;
+                const float u = (SAFE && b == 1) ? t * 0.5f : (t - (float)b) * 0.5f + 0.5f;
+                const uint32_t v = (uint32_t)f2i<SAFE>(u) * 2u + (uint32_t)b;
                 qb[b][p] = SAFE ? ((b == 0) ? min((int32_t)v, L2 - 1) : (int32_t)v) : iclamp((int32_t)v, b, L2 - 1 + b);
                 // mode 0 compares in 8-bit space; modes 3/6 codes are 8-bit; mode 7 compares raw 6-bit codes
                 // against 8-bit targets (reference quirk, kernel.ispc:1003-1017)
@@ -140,7 +144,9 @@ __device__ __forceinline__ void quant_shared_pbit(int32_t (&q)[2][4], int32_t (&
         for (int i = 0; i < 2; i++)
             #pragma unroll
             for (int p = 0; p < 4; p++) {
-                const uint32_t v = (uint32_t)f2i<SAFE>((e[i][p] * INV255 * 127.0f - (float)b) * 0.5f + 0.5f) * 2u + (uint32_t)b;
+                const float t = e[i][p] * INV255 * 127.0f;
+                const float u = (SAFE && b == 1) ? t * 0.5f : (t - (float)b) * 0.5f + 0.5f;      // see quant_pbit
+                const uint32_t v = (uint32_t)f2i<SAFE>(u) * 2u + (uint32_t)b;
                 qb[b][i][p] = SAFE ? ((b == 0) ? min((int32_t)v, 126) : (int32_t)v) : iclamp((int32_t)v, b, 126 + b);
                 db[b][i][p] = (float)expand_to_byte(qb[b][i][p], 7);
             }

@@ -199,15 +199,35 @@ __device__ __forceinline__ void fit_line(float (&ep)[2][4], const Tex& tx, uint3
     float axis[4];
     principal_axis<CH, 8, true>(axis, cv, T);
 
+    // Extreme projections.  minps/maxps differ from v_min/max_f32 only when a NaN is involved (and in the sign of a
+    // zero result, which the clamp below erases: (+-0)*axis + dc is dc, or +-0 -> max(.,0) = +0).  Texels and dc are
+    // finite, so a NaN can only come from a non-finite axis (degenerate normalisation): those lanes take the
+    // compare-and-select form, everyone else two 4-cycle instructions per texel instead of four plus wait states.
     float lo = __builtin_inff(), hi = -__builtin_inff();
+    float probe = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        if ((mask >> k) & 1u) {
-            float dot = 0.f;
+    for (int p = 0; p < CH; p++) probe += axis[p] * 0.0f;                       // NaN iff some axis component is NaN or inf
+    if (__builtin_expect(probe != probe, 0)) {
 #pragma unroll
-            for (int p = 0; p < CH; p++) dot += axis[p] * (tx.get(p, k) - dc[p]);
-            lo = fmin_x86(lo, dot);
-            hi = fmax_x86(hi, dot);
+        for (int k = 0; k < 16; k++) {
+            if ((mask >> k) & 1u) {
+                float dot = 0.f;
+#pragma unroll
+                for (int p = 0; p < CH; p++) dot += axis[p] * (tx.get(p, k) - dc[p]);
+                lo = fmin_x86(lo, dot);
+                hi = fmax_x86(hi, dot);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if ((mask >> k) & 1u) {
+                float dot = 0.f;
+#pragma unroll
+                for (int p = 0; p < CH; p++) dot += axis[p] * (tx.get(p, k) - dc[p]);
+                lo = __builtin_fminf(lo, dot);
+                hi = __builtin_fmaxf(hi, dot);
+            }
         }
     }
     if (hi - lo < 1.0f) { lo -= 0.5f; hi += 0.5f; }
