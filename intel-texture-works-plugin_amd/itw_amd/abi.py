@@ -21,6 +21,8 @@ EXPORTED_SYMBOLS = tuple(
        "CompressImageBC1", "CompressImageBC3"]
     + ["CompressImageBC7_" + p for p in BC7_PROFILES] + ["CompressImageBC6H_" + p for p in BC6H_PROFILES]
     + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device"]
+    # include/itw_decode.h: device decoders
+    + ["itwDecodeBlocks"]
     # include/itw_dds.h: DDS container
     + ["itwDdsLevelBytes", "itwDdsHeaderBytes", "itwDdsFileBytes", "itwDdsWriteHeader", "itwDdsReadHeader", "itwDdsWriteFile"])
 
@@ -113,6 +115,8 @@ def lib():
         L.itwFreeSurface.restype = None
         L.itwPadToMultipleOf4Device.argtypes = [C.POINTER(RgbaSurface), C.c_int, C.c_void_p]
         L.itwPadToMultipleOf4Device.restype = None
+        L.itwDecodeBlocks.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+        L.itwDecodeBlocks.restype = C.c_int
         # DDS container (itw_dds.h)
         L.itwDdsLevelBytes.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         L.itwDdsLevelBytes.restype = C.c_size_t
@@ -261,3 +265,31 @@ def dds_file(fmt_key, width, height, levels, mip_levels=1, cubemap=False, array_
     if n != total:
         raise ValueError("itwDdsWriteFile failed (level count / sizes)")
     return out
+
+
+def decode(fmt, blocks, width, height, want_modes=False):
+    """GPU decode (itwDecodeBlocks).  blocks: uint8 numpy array or CUDA torch tensor of packed blocks.  Returns texels as
+    (H, W, 4) uint8 -- uint16 half bit patterns for bc6h -- in the same kind of container, plus the per-block modes
+    (int32) when asked."""
+    import numpy as np
+    key = {"bc1": 71, "bc3": 77, "bc7": 98, "bc6h": 95}[fmt]
+    nb = (width // 4) * (height // 4)
+    es = 2 if fmt == "bc6h" else 1
+    if isinstance(blocks, np.ndarray):
+        blk = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1)
+        out = np.empty((height, width, 4), dtype=np.uint16 if fmt == "bc6h" else np.uint8)
+        modes = np.empty(nb, dtype=np.int32) if want_modes else None
+        rc = lib().itwDecodeBlocks(key, blk.ctypes.data, width, height, out.ctypes.data, width * 4 * es,
+                                   modes.ctypes.data if want_modes else None)
+    else:
+        import torch
+        assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
+        out = torch.empty((height, width, 4), dtype=torch.int16 if fmt == "bc6h" else torch.uint8, device=blocks.device)
+        modes = torch.empty(nb, dtype=torch.int32, device=blocks.device) if want_modes else None
+        with torch.cuda.device(blocks.device):
+            lib().itwSetStream(torch.cuda.current_stream(blocks.device).cuda_stream)
+            rc = lib().itwDecodeBlocks(key, blocks.data_ptr(), width, height, out.data_ptr(), width * 4 * es,
+                                       modes.data_ptr() if want_modes else None)
+    if rc != 0:
+        raise ValueError("itwDecodeBlocks: unsupported format or size")
+    return (out, modes) if want_modes else out
