@@ -69,6 +69,51 @@ def test_custom_settings_struct(itw, gpu, oracle):
         assert first_mismatch(got, want, 16) is None, (tweak, first_mismatch(got, want, 16))
 
 
+def _posterised(h, w, levels, seed=5):
+    """Few distinct colours per block: many shapes reach the same error, so the rank-key tie-break decides."""
+    from itw_amd import surfaces
+    img = surfaces.ldr_smooth(h, w, seed=surfaces.SEED + seed)
+    step = 256 // levels
+    out = (img // step) * step + step // 2
+    rng = np.random.default_rng(seed)
+    flat = rng.random((h // 4, w // 4)) < 0.2                      # a fifth of the blocks completely flat
+    blocks = out.reshape(h // 4, 4, w // 4, 4, 4).transpose(0, 2, 1, 3, 4).copy()      # [by][bx][y][x][c]
+    blocks[flat] = blocks[flat][:, :1, :1, :]
+    return np.ascontiguousarray(blocks.transpose(0, 2, 1, 3, 4).reshape(h, w, 4)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("prof", ["slow", "alpha_slow"])
+@pytest.mark.parametrize("levels", [2, 4, 8])
+def test_ties_between_shapes_follow_the_rank_order(itw, gpu, oracle, prof, levels):
+    """Whole-table scans evaluate the PCA rank key only when two shapes tie (csrc/bc7.hip); the reference's ranked,
+    strict-`<` scan must still be reproduced on content where ties are the rule."""
+    img = _posterised(96, 128, levels)
+    got = gpu_encode(itw, gpu, img, prof)
+    want = oracle.encode_mt("bc7", img, prof)
+    assert first_mismatch(got, want, 16) is None, first_mismatch(got, want, 16)
+
+
+def test_mixed_whole_table_and_ranked_lists(itw, gpu, oracle):
+    """Thresholds on either side of 64 select different kernels (table-order scan vs ranked list): every mix agrees."""
+    from itw_amd import surfaces
+    img = np.concatenate([surfaces.ldr_smooth(32, 96), _posterised(32, 96, 4)], axis=0)
+    for base, tweak in (("slow", {"fastSkipTreshold_mode3": 8}), ("slow", {"fastSkipTreshold_mode1": 0}),
+                        ("slow", {"fastSkipTreshold_mode3": 0}), ("slow", {"fastSkipTreshold_mode1": 63, "fastSkipTreshold_mode3": 65}),
+                        ("slow", {"fastSkipTreshold_mode7": 64}), ("alpha_slow", {"fastSkipTreshold_mode7": 1}),
+                        ("alpha_slow", {"fastSkipTreshold_mode1": 1, "fastSkipTreshold_mode3": 64}), ("slow", {"skip_mode2": True}),
+                        ("alpha_slow", {"channels": 3}), ("slow", {"channels": 4, "fastSkipTreshold_mode7": 64})):
+        s = itw.bc7_profile(base)
+        so = oracle.bc7_profile(base)
+        for k, v in tweak.items():
+            setattr(s, k, v)
+            setattr(so, k, v)
+        s.refineIterations[7] = 2
+        so.refineIterations[7] = 2
+        got = gpu_encode(itw, gpu, img, s)
+        want = oracle.encode("bc7", img, so)
+        assert first_mismatch(got, want, 16) is None, (base, tweak, first_mismatch(got, want, 16))
+
+
 def test_full_size_4096_slow_properties(itw, gpu, oracle):
     """BASELINE configs[2] at full size.  The scalar oracle needs minutes for 4096^2 'slow', so: (1) bands sampled
     across the surface are compared bit-exactly, (2) size-independent properties cover the rest -- blocks are
