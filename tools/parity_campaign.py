@@ -1,0 +1,55 @@
+"""Large GPU-vs-oracle parity campaign (run on the GPU box): every format / profile on several megapixels of mixed
+content -- smooth + noise, uniform random bytes, posterised (tie-heavy), real alpha, adversarial half bits -- compared
+bit for bit with the multi-threaded scalar oracle.  Prints one line per case and a summary; exit code 1 on any mismatch.
+Usage: python tools/parity_campaign.py [megapixels_per_case]   (default 2; the oracle needs ~1 s per Mpix of BC7 slow
+on 16 cores)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "intel-texture-works-plugin_amd"))
+import numpy as np, torch
+import itw_amd
+from itw_amd import surfaces
+from oracle import pyoracle          # checker
+
+mp = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+W = 2048
+H = max(4, int(mp * 1e6 / W) // 4 * 4)
+rng = np.random.default_rng(2026)
+
+def posterised(h, w, levels):
+    img = surfaces.ldr_smooth(h, w, seed=surfaces.SEED + 17)
+    step = 256 // levels
+    return ((img // step) * step + step // 2).astype(np.uint8)
+
+def mixed_ldr(h, w):
+    q = h // 4 // 4 * 4
+    parts = [surfaces.ldr_smooth(q, w, seed=surfaces.SEED + 31), rng.integers(0, 256, size=(q, w, 4), dtype=np.uint8),
+             posterised(q, w, 4), posterised(h - 3 * q, w, 2)]
+    return np.ascontiguousarray(np.concatenate(parts, axis=0))
+
+def mixed_hdr(h, w):
+    q = h // 2 // 4 * 4
+    a = surfaces.hdr_smooth(q, w, seed=surfaces.SEED + 41)
+    b = rng.integers(0, 65536, size=(h - q, w, 4), dtype=np.uint16)     # NaN / inf / negative halves included
+    return np.ascontiguousarray(np.concatenate([a, b], axis=0))
+
+cases = [("bc1", None), ("bc3", None)] + [("bc7", p) for p in itw_amd.BC7_PROFILES] + [("bc6h", p) for p in itw_amd.BC6H_PROFILES]
+torch.cuda.set_device(0)
+bad_total, blocks_total = 0, 0
+ldr, hdr = mixed_ldr(H, W), mixed_hdr(H, W)
+for fmt, prof in cases:
+    img = hdr if fmt == "bc6h" else ldr
+    t0 = time.perf_counter()
+    got = itw_amd.compress(fmt, torch.from_numpy(img.view(np.int16) if fmt == "bc6h" else img).cuda(), prof)
+    torch.cuda.synchronize()
+    got = got.cpu().numpy()
+    t1 = time.perf_counter()
+    want = pyoracle.encode_mt(fmt, img, prof).reshape(-1)
+    t2 = time.perf_counter()
+    bpb = itw_amd.BYTES_PER_BLOCK[fmt]
+    bad = int((got.reshape(-1, bpb) != want.reshape(-1, bpb)).any(axis=1).sum())
+    n = got.size // bpb
+    bad_total += bad; blocks_total += n
+    print(f"{fmt:5s} {prof or '-':16s} {n:8d} blocks  mismatches {bad:6d}   gpu {1e3*(t1-t0):8.1f} ms  oracle {t2-t1:6.1f} s", flush=True)
+print(f"TOTAL {blocks_total} blocks, {bad_total} mismatches")
+sys.exit(1 if bad_total else 0)
