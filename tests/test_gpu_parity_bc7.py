@@ -114,6 +114,23 @@ def test_mixed_whole_table_and_ranked_lists(itw, gpu, oracle):
         assert first_mismatch(got, want, 16) is None, (base, tweak, first_mismatch(got, want, 16))
 
 
+def test_every_subset_of_mode_families(itw, gpu, oracle):
+    """mode_selection[4] switches the families {0,2} {1,3,7} {4,5} {6}; the families are separate kernels that hand the
+    best error to each other, so every one of the 16 combinations must still equal the reference's single pass."""
+    from itw_amd import surfaces
+    img = np.concatenate([surfaces.ldr_smooth(16, 64), _posterised(16, 64, 4)], axis=0)
+    for base in ("slow", "alpha_basic"):
+        for bits in range(16):
+            s = itw.bc7_profile(base)
+            so = oracle.bc7_profile(base)
+            for i in range(4):
+                s.mode_selection[i] = bool(bits >> i & 1)
+                so.mode_selection[i] = bool(bits >> i & 1)
+            got = gpu_encode(itw, gpu, img, s)
+            want = oracle.encode("bc7", img, so)
+            assert first_mismatch(got, want, 16) is None, (base, bits, first_mismatch(got, want, 16))
+
+
 def test_full_size_4096_slow_properties(itw, gpu, oracle):
     """BASELINE configs[2] at full size.  The scalar oracle needs minutes for 4096^2 'slow', so: (1) bands sampled
     across the surface are compared bit-exactly, (2) size-independent properties cover the rest -- blocks are
