@@ -200,6 +200,7 @@ struct Lane {
     bool improved;
     SeedTables T;
     int32_t* keys;            // LDS column (ranked-list path only): keys[i * TPB]
+    uint2* pal;               // LDS column of palettes (table-order scans): 12 levels, pal[level * TPB]
 };
 
 struct Win {                  // winner of one multi-subset mode during the search
@@ -468,6 +469,7 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
     reset(b0, 64); reset(b2, 64);
     IStats<3> full;
     stats_int<3>(full, ln.tx.pl, whole_block());
+    const int32_t tt = full.m[0] + full.m[4] + full.m[7];          // sum over the block of |texel|^2
     const int count = S.skip_mode2 ? 16 : 64;
     for (int part = 0; part < count; part++) {
         ln.tx.fence();
@@ -488,13 +490,16 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
             int32_t q[2][4], d[2][4];
             if (do0) {
                 quant_mode<0, true>(q, d, fit, 3);
-                select_subset<3, 3>(q0, e0, ln.tx, make_segment<3, 3>(d), sm.bits);
+                const PalSegment ps = build_palette<3, 3, TPB>(ln.pal, d);
+                select_subset_pal<3, 3, TPB>(q0, e0, ln.tx, ps, ln.pal, sm.bits);
             }
             if (do2) {
                 quant_mode<2, true>(q, d, fit, 3);
-                select_subset<2, 3>(q2, e2, ln.tx, make_segment<2, 3>(d), sm.bits);
+                const PalSegment ps = build_palette<2, 3, TPB>(ln.pal + 8 * TPB, d);
+                select_subset_pal<2, 3, TPB>(q2, e2, ln.tx, ps, ln.pal + 8 * TPB, sm.bits);
             }
         }
+        e0 += tt; e2 += tt;                              // the |t|^2 terms the palette path leaves out
         if (do0 && e0 < b0.err) take(b0, e0, q0, 64 + part, part);
         if (do2 && e2 < b2.err) take(b2, e2, q2, 64 + part, part);
     }
@@ -514,6 +519,7 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
 
     IStats<FIT_CH> full;
     stats_int<FIT_CH>(full, ln.tx.pl, whole_block());
+    const int32_t tt = full.m[0] + full.m[4] + full.m[7] + (FIT_CH == 4 ? full.m[9] : 0);     // sum over the block of |texel|^2
     Stats<RANK_CH> rfull;                                 // the ranking's view of the block (first RANK_CH channels)
     {
         IStats<RANK_CH> t;
@@ -545,23 +551,27 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
                 int32_t q[2][4], d[2][4];
                 if (FAMILY7) {
                     quant_mode<7, true>(q, d, fit, 4);
-                    select_subset<2, 4>(qa, ea, ln.tx, make_segment<2, 4>(d), sm.bits);
+                    const PalSegment ps = build_palette<2, 4, TPB>(ln.pal, d);
+                    select_subset_pal<2, 4, TPB>(qa, ea, ln.tx, ps, ln.pal, sm.bits);
                 } else {
                     if (na > 0 && nb > 0) {
                         quant_mode<1, true>(q, d, fit, 3);
-                        const Segment s1 = make_segment<3, 3>(d);
+                        const PalSegment s1 = build_palette<3, 3, TPB>(ln.pal, d);
                         quant_mode<3, true>(q, d, fit, 3);
-                        const Segment s3 = make_segment<2, 3>(d);
-                        select_subset2<3, 2, 3>(qa, ea, qc, ec, ln.tx, s1, s3, sm.bits);
+                        const PalSegment s3 = build_palette<2, 3, TPB>(ln.pal + 8 * TPB, d);
+                        select_subset2_pal<3, 2, 3, TPB>(qa, ea, qc, ec, ln.tx, s1, ln.pal, s3, ln.pal + 8 * TPB, sm.bits);
                     } else if (na > 0) {
                         quant_mode<1, true>(q, d, fit, 3);
-                        select_subset<3, 3>(qa, ea, ln.tx, make_segment<3, 3>(d), sm.bits);
+                        const PalSegment ps = build_palette<3, 3, TPB>(ln.pal, d);
+                        select_subset_pal<3, 3, TPB>(qa, ea, ln.tx, ps, ln.pal, sm.bits);
                     } else {
                         quant_mode<3, true>(q, d, fit, 3);
-                        select_subset<2, 3>(qc, ec, ln.tx, make_segment<2, 3>(d), sm.bits);
+                        const PalSegment ps = build_palette<2, 3, TPB>(ln.pal + 8 * TPB, d);
+                        select_subset_pal<2, 3, TPB>(qc, ec, ln.tx, ps, ln.pal + 8 * TPB, sm.bits);
                     }
                 }
             }
+            ea += tt; ec += tt;                          // the |t|^2 terms the palette path leaves out
             const bool on_a = na > 0, on_b = !FAMILY7 && nb > 0;
             const bool tie_a = on_a && ea == wa.err, tie_b = on_b && ec == wb.err;
             if (on_a && ea < wa.err) take(wa, ea, qa, part, -1);
@@ -919,6 +929,7 @@ bc7_search_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
     extern __shared__ int32_t s_keys[];            // 64 * TPB keys, only allocated for ranked lists
+    __shared__ uint2 s_pal[RANKED ? 1 : 12 * TPB]; // per-lane palettes of the table-order scans: 8 + 4 levels (24 KiB)
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
@@ -926,6 +937,7 @@ bc7_search_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
     const bool live = gid < nblocks;
     const int32_t b = live ? gid : nblocks - 1;    // idle lanes of the last workgroup redo its last block, store nothing
     ln.keys = s_keys + threadIdx.x;
+    ln.pal = s_pal + (RANKED ? 0 : threadIdx.x);
     load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
 
     Win wa, wb;
@@ -955,6 +967,7 @@ bc7_finish_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
     const bool live = gid < nblocks;
     const int32_t b = live ? gid : nblocks - 1;
     ln.keys = nullptr;
+    ln.pal = nullptr;
     load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
 
     ln.best_err = first ? ERR_MAX : err_ws[b];

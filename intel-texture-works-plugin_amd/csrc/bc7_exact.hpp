@@ -437,6 +437,122 @@ __device__ __forceinline__ void select_subset2(uint32_t (&qa)[2], int32_t& ta, u
     }
 }
 
+// ---- index selection through a per-segment palette in LDS ---------------------------------------------------
+// The decoded colour of index q on a segment does not depend on the texel, so a table-order scan decodes every level
+// ONCE per (subset, mode) -- LEVELS x ~30 cycles -- into LDS and each texel then needs: the projection (2 dot ops, one
+// FMA), one 16-byte LDS read of the two neighbouring levels, and per candidate one v_dot4_u32_u8 against the texel as
+// loaded:  |P - t|^2 = |P|^2 - 2 P.t + |t|^2.  |t|^2 is the same for both candidates and sums to a per-block constant
+// over the texels (each texel belongs to exactly one subset), which the caller adds once per shape: the block error is
+// still the reference's exact integer.  Entry layout: {P0 | P1 << 8 | P2 << 16 | P3 << 24, |P|^2}, level-major,
+// lane-minor (`pal[level * PAL_STRIDE]`): any mix of levels across a wave is bank-conflict free.
+struct PalSegment {
+    uint32_t ba01, ba23;    // endpoint 1 - endpoint 0 (as in Segment; CH == 3: ba23 = int32 of channel 2)
+    int32_t c;              // sum a*(b-a): N = sum t*(b-a) - c
+    float k0, k1;           // the biased quotient constants of Segment (BITS <= 3)
+};
+
+template <int BITS, int CH, int PAL_STRIDE>
+__device__ __forceinline__ PalSegment build_palette(uint2* pal, const int32_t (&d)[2][4])
+{
+    static_assert(BITS <= 3, "4-bit indices keep the direct path");
+    constexpr int LEVELS = 1 << BITS;
+    PalSegment s;
+    const uint32_t a01 = pack16(d[0][0], d[0][1]);
+    s.ba01 = pk_sub(pack16(d[1][0], d[1][1]), a01);
+    uint32_t a23;
+    int32_t dd;
+    if (CH == 4) {
+        a23 = pack16(d[0][2], d[0][3]);
+        s.ba23 = pk_sub(pack16(d[1][2], d[1][3]), a23);
+        dd = dot2(s.ba01, s.ba01, dot2(s.ba23, s.ba23, 0));
+        s.c = dot2(a01, s.ba01, dot2(a23, s.ba23, 0));
+    } else {
+        const int32_t ba2 = d[1][2] - d[0][2];
+        a23 = (uint32_t)d[0][2];
+        s.ba23 = (uint32_t)ba2;
+        dd = dot2(s.ba01, s.ba01, ba2 * ba2);
+        s.c = dot2(a01, s.ba01, d[0][2] * ba2);
+    }
+    const float dn = -(float)dd;
+    const float r = (dd == 0) ? 0.0f : 1.0f / dn;
+    s.k0 = (float)LEVELS * r;
+    s.k1 = 0.5f - 0.25f * r;
+    const s16x2 k32 = {32, 32}, six = {6, 6};
+#pragma unroll
+    for (int q = 0; q < LEVELS; q++) {
+        constexpr int D = LEVELS - 1;
+        const uint32_t w = (uint32_t)((q * 128 + D) / (2 * D)) * 0x00010001u;           // the format's weight, both halves
+        const uint32_t x01 = pk_add(as_u32((as_s16x2(w) * as_s16x2(s.ba01) + k32) >> six), a01);      // decoded c0 | c1 << 16
+        uint32_t bytes, pp;
+        if (CH == 4) {
+            const uint32_t x23 = pk_add(as_u32((as_s16x2(w) * as_s16x2(s.ba23) + k32) >> six), a23);
+            bytes = __builtin_amdgcn_perm(x23, x01, 0x06040200u);                         // low byte of each half
+            pp = (uint32_t)dot2(x01, x01, dot2(x23, x23, 0));
+        } else {
+            const uint32_t x2 = add_u16(ashr6_i16(add32_u16(mul_lo_u16(w, s.ba23))), a23);
+            bytes = __builtin_amdgcn_perm(x2, x01, 0x0c040200u);
+            pp = (uint32_t)dot2(x01, x01, (int32_t)mul_lo_u16(x2, x2));
+        }
+        pal[q * PAL_STRIDE] = make_uint2(bytes, pp);
+    }
+    return s;
+}
+
+// One texel against a palette.  `w` = the texel as loaded (RGBA8; the palette's alpha byte is 0 when CH == 3), t01/t23 as
+// in select_texel.  e_out excludes |t|^2 (see above).
+template <int BITS, int CH, int PAL_STRIDE>
+__device__ __forceinline__ void select_texel_pal(int32_t& q_out, int32_t& e_out, const PalSegment& sg, const uint2* pal,
+                                                 uint32_t w, uint32_t t01, uint32_t t23)
+{
+    constexpr int LEVELS = 1 << BITS;
+    int32_t n;                                                              // sum t*(b-a)
+    if (CH == 4) n = dot2(t01, sg.ba01, dot2(t23, sg.ba23, 0));
+    else         n = dot2(t01, sg.ba01, (int32_t)t23 * (int32_t)sg.ba23);
+    const float mf = (float)(sg.c - n);                                     // M = -N, as in select_texel
+    const float x = __builtin_fmaf(mf, sg.k0, sg.k1);
+    const int32_t q1 = imed3((int32_t)x, 1, LEVELS - 1);
+    const uint2 lo = pal[(q1 - 1) * PAL_STRIDE], hi = pal[q1 * PAL_STRIDE];
+    const uint32_t c0 = udot4(lo.x, w, 0u), c1 = udot4(hi.x, w, 0u);
+    const int32_t e0 = (int32_t)(lo.y - (c0 + c0)), e1 = (int32_t)(hi.y - (c1 + c1));
+    const bool first = e0 < e1;
+    q_out = first ? q1 - 1 : q1;
+    e_out = min(e0, e1);
+}
+
+// Texels of one subset (wave-uniform mask) against one or two palettes; accumulates errors WITHOUT the |t|^2 terms.
+template <int BITS, int CH, int PAL_STRIDE>
+__device__ __forceinline__ void select_subset_pal(uint32_t (&qb)[2], int32_t& total, const Tex& tx, const PalSegment& sg,
+                                                  const uint2* pal, uint32_t mask)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if ((mask >> k) & 1u) {
+            int32_t q, e;
+            select_texel_pal<BITS, CH, PAL_STRIDE>(q, e, sg, pal, tx.w[k], tx.pair01(k), tx.template pair23<CH == 4>(k));
+            if (k < 8) qb[0] |= (uint32_t)q << (4 * k); else qb[1] |= (uint32_t)q << (4 * (k - 8));
+            total += e;
+        }
+    }
+}
+
+template <int BITSA, int BITSB, int CH, int PAL_STRIDE>
+__device__ __forceinline__ void select_subset2_pal(uint32_t (&qa)[2], int32_t& ta, uint32_t (&qc)[2], int32_t& tc, const Tex& tx,
+                                                   const PalSegment& sa, const uint2* pa, const PalSegment& sc, const uint2* pc, uint32_t mask)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if ((mask >> k) & 1u) {
+            const uint32_t t01 = tx.pair01(k), t23 = tx.template pair23<CH == 4>(k);
+            int32_t q0, e0, q1, e1;
+            select_texel_pal<BITSA, CH, PAL_STRIDE>(q0, e0, sa, pa, tx.w[k], t01, t23);
+            select_texel_pal<BITSB, CH, PAL_STRIDE>(q1, e1, sc, pc, tx.w[k], t01, t23);
+            if (k < 8) { qa[0] |= (uint32_t)q0 << (4 * k); qc[0] |= (uint32_t)q1 << (4 * k); }
+            else       { qa[1] |= (uint32_t)q0 << (4 * (k - 8)); qc[1] |= (uint32_t)q1 << (4 * (k - 8)); }
+            ta += e0; tc += e1;
+        }
+    }
+}
+
 // ---- least-squares endpoints for fixed indices (kernel.ispc:1198-1262 opt_endpoints) -------------------
 // The sums are exact integers (sum q*t <= 16*15*255); the 2x2 solve is fp32 exactly as in the reference.
 template <int BITS, int CH>
