@@ -732,7 +732,7 @@ __device__ __forceinline__ int32_t encode_scalar(uint32_t (&qb)[2], int32_t (&qe
 
 // one (mode, rotation, index-swap) candidate, given the rotation's line fit      [kernel.ispc:1565-1621]
 template <int MODE, int SWAP>
-__device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const Lane& ln, const Tex& rot, const float (&fit)[2][4],
+__device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const Lane& ln, const Tex& rot, const float (&fit)[2][4], int32_t tt,
                                          const bc7_enc_settings& S, int rotation)
 {
     constexpr int BITS = SWAP ? 3 : 2;
@@ -742,18 +742,17 @@ __device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const La
 
     int32_t q[2][4], d[2][4];
     uint32_t qb[2];
-    Segment sg[3];
     quant_mode<MODE, true>(q, d, fit, 3);
-    sg[0] = make_segment<BITS, 3>(d); sg[1] = sg[0]; sg[2] = sg[0];
-    int32_t err = select_block<BITS, 3, 1>(qb, rot, sg, 0u);
+    PalSegment ps = build_palette<BITS, 3, TPB>(ln.pal, d);
+    int32_t err = select_block_pal<BITS, 3, TPB>(qb, rot, ps, ln.pal, tt);
     const int iters = S.refineIterations[MODE];
     for (int it = 0; it < iters; it++) {
         float ep[2][4];
         ep[0][3] = 0.f; ep[1][3] = 0.f;
         refit_line<BITS, 3>(ep, rot.pl, qb, all, ln.T);
         quant_mode<MODE, false>(q, d, ep, 3);
-        sg[0] = make_segment<BITS, 3>(d);
-        err = select_block<BITS, 3, 1>(qb, rot, sg, 0u);
+        ps = build_palette<BITS, 3, TPB>(ln.pal, d);
+        err = select_block_pal<BITS, 3, TPB>(qb, rot, ps, ln.pal, tt);
     }
 
     int32_t aq[2];
@@ -824,9 +823,10 @@ __device__ __forceinline__ void modes_45(Lane& ln, const bc7_enc_settings& S)   
         float fit[2][4];
         fit[0][3] = 0.f; fit[1][3] = 0.f;
         fit_line<3>(fit, rot, 0xffffu, st, rcp_of_count(16), ln.T);
-        try_dual<4, 0>(best4, err4, ln, rot, fit, S, r);
-        try_dual<4, 1>(best4, err4, ln, rot, fit, S, r);
-        try_dual<5, 0>(best5, err5, ln, rot, fit, S, r);
+        const int32_t tt = st.m[0] + st.m[4] + st.m[7];          // |texel|^2 summed over the rotated colour block
+        try_dual<4, 0>(best4, err4, ln, rot, fit, tt, S, r);
+        try_dual<4, 1>(best4, err4, ln, rot, fit, tt, S, r);
+        try_dual<5, 0>(best5, err5, ln, rot, fit, tt, S, r);
     }
     if (err4 < ln.best_err) { ln.best_err = err4; ln.improved = true; emit_dual<4>(ln.best, best4); }
     if (err5 < ln.best_err) { ln.best_err = err5; ln.improved = true; emit_dual<5>(ln.best, best5); }
@@ -960,6 +960,7 @@ bc7_finish_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
+    __shared__ uint2 s_pal[FAMILY == F_MODES456 ? 8 * TPB : 1];     // one palette per lane for the mode 4/5 vector part (16 KiB)
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
@@ -967,7 +968,7 @@ bc7_finish_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
     const bool live = gid < nblocks;
     const int32_t b = live ? gid : nblocks - 1;
     ln.keys = nullptr;
-    ln.pal = nullptr;
+    ln.pal = s_pal + (FAMILY == F_MODES456 ? threadIdx.x : 0);
     load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
 
     ln.best_err = first ? ERR_MAX : err_ws[b];

@@ -553,6 +553,22 @@ __device__ __forceinline__ void select_subset2_pal(uint32_t (&qa)[2], int32_t& t
     }
 }
 
+// Whole block against one palette (one-subset modes); returns the exact block error (`tt` = sum of |texel|^2 over the block).
+template <int BITS, int CH, int PAL_STRIDE>
+__device__ __forceinline__ int32_t select_block_pal(uint32_t (&qb)[2], const Tex& tx, const PalSegment& sg, const uint2* pal, int32_t tt)
+{
+    int32_t total = tt;
+    qb[0] = qb[1] = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int32_t q, e;
+        select_texel_pal<BITS, CH, PAL_STRIDE>(q, e, sg, pal, tx.w[k], tx.pair01(k), tx.template pair23<CH == 4>(k));
+        if (k < 8) qb[0] |= (uint32_t)q << (4 * k); else qb[1] |= (uint32_t)q << (4 * (k - 8));
+        total += e;
+    }
+    return total;
+}
+
 // ---- least-squares endpoints for fixed indices (kernel.ispc:1198-1262 opt_endpoints) -------------------
 // The sums are exact integers (sum q*t <= 16*15*255); the 2x2 solve is fp32 exactly as in the reference.
 template <int BITS, int CH>
