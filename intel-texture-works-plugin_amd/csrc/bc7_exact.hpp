@@ -443,7 +443,7 @@ __device__ __forceinline__ void select_subset2(uint32_t (&qa)[2], int32_t& ta, u
 // FMA), one 16-byte LDS read of the two neighbouring levels, and per candidate one v_dot4_u32_u8 against the texel as
 // loaded:  |P - t|^2 = |P|^2 - 2 P.t + |t|^2.  |t|^2 is the same for both candidates and sums to a per-block constant
 // over the texels (each texel belongs to exactly one subset), which the caller adds once per shape: the block error is
-// still the reference's exact integer.  Entry layout: {P0 | P1 << 8 | P2 << 16 | P3 << 24, |P|^2}, level-major,
+// still the reference's exact integer.  Entry layout: {P0 | P1 << 8 | P2 << 16 | P3 << 24, -|P|^2}, level-major,
 // lane-minor (`pal[level * PAL_STRIDE]`): any mix of levels across a wave is bank-conflict free.
 struct PalSegment {
     uint32_t ba01, ba23;    // endpoint 1 - endpoint 0 (as in Segment; CH == 3: ba23 = int32 of channel 2)
@@ -493,7 +493,7 @@ __device__ __forceinline__ PalSegment build_palette(uint2* pal, const int32_t (&
             bytes = __builtin_amdgcn_perm(x2, x01, 0x0c040200u);
             pp = (uint32_t)dot2(x01, x01, (int32_t)mul_lo_u16(x2, x2));
         }
-        pal[q * PAL_STRIDE] = make_uint2(bytes, pp);
+        pal[q * PAL_STRIDE] = make_uint2(bytes, 0u - pp);                                 // negated: 2 P.t - |P|^2 is one v_lshl_add
     }
     return s;
 }
@@ -511,12 +511,13 @@ __device__ __forceinline__ void select_texel_pal(int32_t& q_out, int32_t& e_out,
     const float mf = (float)(sg.c - n);                                     // M = -N, as in select_texel
     const float x = __builtin_fmaf(mf, sg.k0, sg.k1);
     const int32_t q1 = imed3((int32_t)x, 1, LEVELS - 1);
-    const uint2 lo = pal[(q1 - 1) * PAL_STRIDE], hi = pal[q1 * PAL_STRIDE];
-    const uint32_t c0 = udot4(lo.x, w, 0u), c1 = udot4(hi.x, w, 0u);
-    const int32_t e0 = (int32_t)(lo.y - (c0 + c0)), e1 = (int32_t)(hi.y - (c1 + c1));
-    const bool first = e0 < e1;
+    const uint2* p = pal + (q1 - 1) * PAL_STRIDE;                           // one address, two reads a level apart
+    const uint2 lo = p[0], hi = p[PAL_STRIDE];
+    // f = 2 P.t - |P|^2 = -(|P - t|^2 - |t|^2): the smaller error is the larger f; ties go to q1 like the reference's `<`
+    const int32_t f0 = (int32_t)((udot4(lo.x, w, 0u) << 1) + lo.y), f1 = (int32_t)((udot4(hi.x, w, 0u) << 1) + hi.y);
+    const bool first = f0 > f1;
     q_out = first ? q1 - 1 : q1;
-    e_out = min(e0, e1);
+    e_out = -max(f0, f1);
 }
 
 // Texels of one subset (wave-uniform mask) against one or two palettes; accumulates errors WITHOUT the |t|^2 terms.
