@@ -447,8 +447,8 @@ __device__ __forceinline__ void select_subset2(uint32_t (&qa)[2], int32_t& ta, u
 // lane-minor (`pal[level * PAL_STRIDE]`): any mix of levels across a wave is bank-conflict free.
 struct PalSegment {
     uint32_t ba01, ba23;    // endpoint 1 - endpoint 0 (as in Segment; CH == 3: ba23 = int32 of channel 2)
-    int32_t c;              // sum a*(b-a): N = sum t*(b-a) - c
-    float k0, k1;           // the biased quotient constants of Segment (BITS <= 3)
+    int32_t nc;             // -sum a*(b-a): N = sum t*(b-a) + nc
+    float k0, k1;           // LEVELS/|b-a|^2 (sign folded: x~ = N*k0 + k1) and 0.5 + 1/(4|b-a|^2), cf. Segment
 };
 
 template <int BITS, int CH, int PAL_STRIDE>
@@ -465,31 +465,34 @@ __device__ __forceinline__ PalSegment build_palette(uint2* pal, const int32_t (&
         a23 = pack16(d[0][2], d[0][3]);
         s.ba23 = pk_sub(pack16(d[1][2], d[1][3]), a23);
         dd = dot2(s.ba01, s.ba01, dot2(s.ba23, s.ba23, 0));
-        s.c = dot2(a01, s.ba01, dot2(a23, s.ba23, 0));
+        s.nc = -dot2(a01, s.ba01, dot2(a23, s.ba23, 0));
     } else {
         const int32_t ba2 = d[1][2] - d[0][2];
         a23 = (uint32_t)d[0][2];
         s.ba23 = (uint32_t)ba2;
         dd = dot2(s.ba01, s.ba01, ba2 * ba2);
-        s.c = dot2(a01, s.ba01, d[0][2] * ba2);
+        s.nc = -dot2(a01, s.ba01, d[0][2] * ba2);
     }
     const float dn = -(float)dd;
-    const float r = (dd == 0) ? 0.0f : 1.0f / dn;
-    s.k0 = (float)LEVELS * r;
+    const float r = (dd == 0) ? 0.0f : 1.0f / dn;                          // = RN(-1/D), cf. make_segment
+    s.k0 = -((float)LEVELS * r);                                           // M*k0 with M = -N  ==  N*(-k0): exact sign flips
     s.k1 = 0.5f - 0.25f * r;
     const s16x2 k32 = {32, 32}, six = {6, 6};
 #pragma unroll
     for (int q = 0; q < LEVELS; q++) {
         constexpr int D = LEVELS - 1;
         const uint32_t w = (uint32_t)((q * 128 + D) / (2 * D)) * 0x00010001u;           // the format's weight, both halves
-        const uint32_t x01 = pk_add(as_u32((as_s16x2(w) * as_s16x2(s.ba01) + k32) >> six), a01);      // decoded c0 | c1 << 16
+        // decoded c0 | c1 << 16; the end levels are the endpoints themselves ((0*d + 32) >> 6 = 0, (64*d + 32) >> 6 = d)
+        const uint32_t x01 = (q == 0) ? a01 : (q == D) ? pk_add(s.ba01, a01)
+                                            : pk_add(as_u32((as_s16x2(w) * as_s16x2(s.ba01) + k32) >> six), a01);
         uint32_t bytes, pp;
         if (CH == 4) {
-            const uint32_t x23 = pk_add(as_u32((as_s16x2(w) * as_s16x2(s.ba23) + k32) >> six), a23);
+            const uint32_t x23 = (q == 0) ? a23 : (q == D) ? pk_add(s.ba23, a23)
+                                                : pk_add(as_u32((as_s16x2(w) * as_s16x2(s.ba23) + k32) >> six), a23);
             bytes = __builtin_amdgcn_perm(x23, x01, 0x06040200u);                         // low byte of each half
             pp = (uint32_t)dot2(x01, x01, dot2(x23, x23, 0));
         } else {
-            const uint32_t x2 = add_u16(ashr6_i16(add32_u16(mul_lo_u16(w, s.ba23))), a23);
+            const uint32_t x2 = (q == 0) ? a23 : (q == D) ? (uint32_t)d[1][2] : add_u16(ashr6_i16(add32_u16(mul_lo_u16(w, s.ba23))), a23);
             bytes = __builtin_amdgcn_perm(x2, x01, 0x0c040200u);
             pp = (uint32_t)dot2(x01, x01, (int32_t)mul_lo_u16(x2, x2));
         }
@@ -505,11 +508,10 @@ __device__ __forceinline__ void select_texel_pal(int32_t& q_out, int32_t& e_out,
                                                  uint32_t w, uint32_t t01, uint32_t t23)
 {
     constexpr int LEVELS = 1 << BITS;
-    int32_t n;                                                              // sum t*(b-a)
-    if (CH == 4) n = dot2(t01, sg.ba01, dot2(t23, sg.ba23, 0));
-    else         n = dot2(t01, sg.ba01, (int32_t)t23 * (int32_t)sg.ba23);
-    const float mf = (float)(sg.c - n);                                     // M = -N, as in select_texel
-    const float x = __builtin_fmaf(mf, sg.k0, sg.k1);
+    int32_t n;                                                              // N = sum (t-a)*(b-a)
+    if (CH == 4) n = dot2(t01, sg.ba01, dot2(t23, sg.ba23, sg.nc));
+    else         n = dot2(t01, sg.ba01, (int32_t)t23 * (int32_t)sg.ba23 + sg.nc);
+    const float x = __builtin_fmaf((float)n, sg.k0, sg.k1);                 // = fma(M, k0', k1) of select_texel, signs folded
     const int32_t q1 = imed3((int32_t)x, 1, LEVELS - 1);
     const uint2* p = pal + (q1 - 1) * PAL_STRIDE;                           // one address, two reads a level apart
     const uint2 lo = p[0], hi = p[PAL_STRIDE];
