@@ -41,6 +41,10 @@
 
 namespace itw {
 
+#define BCN_TABLE_QUAL __device__ const
+#include "bc7_f02_schedule.h"
+#undef BCN_TABLE_QUAL
+
 constexpr int TPB = 256;                  // four waves share one staged seed table
 constexpr float INV255 = 1.0f / 255.0f;   // x/255f under fast-math = x*(1.f/255.f)
 constexpr int32_t ERR_MAX = 0x7fffffff;
@@ -462,27 +466,63 @@ __device__ __forceinline__ void take(Win& w, int32_t err, const uint32_t (&qb)[2
     w.err = err; w.shape = shape; w.key = key;
 }
 
-// modes 0 and 2: three subsets; shapes in table order (wave-uniform), one fit per subset.  [kernel.ispc:1386-1394]
-// List order == table order, so the reference's strict `<` is reproduced by a strict `<`.
+// modes 0 and 2: three subsets, every shape a candidate, one fit per subset.              [kernel.ispc:1386-1394]
+// The reference scans the shapes in table order with a strict `<`: the winner is the lowest error and, among equal
+// errors, the lowest table index -- whatever the visiting order.  With mode 2 enabled the scan therefore follows
+// BC7_F02_SCHEDULE (tools/gen_bc7_f02_schedule.py): 192 (shape, subset) pairs use only 140 distinct texel masks and a
+// subset's whole mode 2 result (indices, error) depends on the mask alone, so the order clusters equal masks and a
+// three-entry register cache, driven by the wave-uniform schedule word, turns 37 subset evaluations into loads (7 more
+// keep their fit for mode 0 and skip the mode 2 part).
+struct SubsetResult { int32_t e; uint32_t q[2]; };
+
+// three named entries (not an array: a runtime-indexed array would live in scratch); `slot` is wave-uniform
+struct SubsetCache { SubsetResult s0, s1, s2; };
+__device__ __forceinline__ SubsetResult cache_get(const SubsetCache& c, uint32_t slot)
+{
+    SubsetResult r;
+    r.e    = slot == 0u ? c.s0.e    : (slot == 1u ? c.s1.e    : c.s2.e);
+    r.q[0] = slot == 0u ? c.s0.q[0] : (slot == 1u ? c.s1.q[0] : c.s2.q[0]);
+    r.q[1] = slot == 0u ? c.s0.q[1] : (slot == 1u ? c.s1.q[1] : c.s2.q[1]);
+    return r;
+}
+__device__ __forceinline__ void cache_put(SubsetCache& c, uint32_t slot, const SubsetResult& r)
+{
+    c.s0.e = slot == 0u ? r.e : c.s0.e; c.s0.q[0] = slot == 0u ? r.q[0] : c.s0.q[0]; c.s0.q[1] = slot == 0u ? r.q[1] : c.s0.q[1];
+    c.s1.e = slot == 1u ? r.e : c.s1.e; c.s1.q[0] = slot == 1u ? r.q[0] : c.s1.q[0]; c.s1.q[1] = slot == 1u ? r.q[1] : c.s1.q[1];
+    c.s2.e = slot == 2u ? r.e : c.s2.e; c.s2.q[0] = slot == 2u ? r.q[0] : c.s2.q[0]; c.s2.q[1] = slot == 2u ? r.q[1] : c.s2.q[1];
+}
+
 __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, Win& b0, Win& b2)
 {
     reset(b0, 64); reset(b2, 64);
     IStats<3> full;
     stats_int<3>(full, ln.tx.pl, whole_block());
     const int32_t tt = full.m[0] + full.m[4] + full.m[7];          // sum over the block of |texel|^2
-    const int count = S.skip_mode2 ? 16 : 64;
-    for (int part = 0; part < count; part++) {
+    const bool do2 = !S.skip_mode2;
+    const int count = do2 ? 64 : 16;
+    SubsetCache cache = {{0, {0u, 0u}}, {0, {0u, 0u}}, {0, {0u, 0u}}};
+    for (int pos = 0; pos < count; pos++) {
         ln.tx.fence();
-        const bool do0 = part < 16, do2 = !S.skip_mode2;
+        const uint32_t sched = do2 ? BC7_F02_SCHEDULE[pos] : (uint32_t)pos;     // mode 0 alone: table order, nothing cached
+        const int part = (int)(sched & 63u);
+        const bool do0 = part < 16;
         uint32_t q0[2] = {0u, 0u}, q2[2] = {0u, 0u};
         int32_t e0 = 0, e2 = 0;
         IStats<3> rest = full;
+        bool rest_valid = true;                          // `rest` = block minus the subsets handled so far
         #pragma unroll 1
         for (int j = 0; j < 3; j++) {
             ln.tx.fence();                                // texel-derived values are used once per shape: do not hoist
+            const uint32_t act = (sched >> (8 + 4 * j)) & 3u, slot = (sched >> (10 + 4 * j)) & 3u;
+            const bool load = act == 2u;
+            if (load) {                                   // this mask's mode 2 result is in the cache
+                const SubsetResult r = cache_get(cache, slot);
+                e2 += r.e; q2[0] |= r.q[0]; q2[1] |= r.q[1];
+                if (!do0) { rest_valid = false; continue; }
+            }
             const SubsetMask sm = subset_of(64 + part, j);
             IStats<3> st;
-            if (j < 2) stats_int<3>(st, ln.tx.pl, sm); else st = rest;
+            if (j < 2 || !rest_valid) stats_int<3>(st, ln.tx.pl, sm); else st = rest;
             stats_sub<3>(rest, st);
             float fit[2][4];
             fit[0][3] = 0.f; fit[1][3] = 0.f;            // the reference's unwritten alpha slots, pinned to 0
@@ -493,15 +533,19 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
                 const PalSegment ps = build_palette<3, 3, TPB>(ln.pal, d);
                 select_subset_pal<3, 3, TPB>(q0, e0, ln.tx, ps, ln.pal, sm.bits);
             }
-            if (do2) {
+            if (do2 && !load) {
                 quant_mode<2, true>(q, d, fit, 3);
                 const PalSegment ps = build_palette<2, 3, TPB>(ln.pal + 8 * TPB, d);
-                select_subset_pal<2, 3, TPB>(q2, e2, ln.tx, ps, ln.pal + 8 * TPB, sm.bits);
+                SubsetResult r = {0, {0u, 0u}};
+                select_subset_pal<2, 3, TPB>(r.q, r.e, ln.tx, ps, ln.pal + 8 * TPB, sm.bits);
+                e2 += r.e; q2[0] |= r.q[0]; q2[1] |= r.q[1];
+                if (act == 1u) cache_put(cache, slot, r);
             }
         }
         e0 += tt; e2 += tt;                              // the |t|^2 terms the palette path leaves out
-        if (do0 && e0 < b0.err) take(b0, e0, q0, 64 + part, part);
-        if (do2 && e2 < b2.err) take(b2, e2, q2, 64 + part, part);
+        const int shape = 64 + part;
+        if (do0 && (e0 < b0.err || (e0 == b0.err && shape < b0.shape))) take(b0, e0, q0, shape, part);
+        if (do2 && (e2 < b2.err || (e2 == b2.err && shape < b2.shape))) take(b2, e2, q2, shape, part);
     }
 }
 
