@@ -475,22 +475,9 @@ __device__ __forceinline__ void take(Win& w, int32_t err, const uint32_t (&qb)[2
 // keep their fit for mode 0 and skip the mode 2 part).
 struct SubsetResult { int32_t e; uint32_t q[2]; };
 
-// three named entries (not an array: a runtime-indexed array would live in scratch); `slot` is wave-uniform
-struct SubsetCache { SubsetResult s0, s1, s2; };
-__device__ __forceinline__ SubsetResult cache_get(const SubsetCache& c, uint32_t slot)
-{
-    SubsetResult r;
-    r.e    = slot == 0u ? c.s0.e    : (slot == 1u ? c.s1.e    : c.s2.e);
-    r.q[0] = slot == 0u ? c.s0.q[0] : (slot == 1u ? c.s1.q[0] : c.s2.q[0]);
-    r.q[1] = slot == 0u ? c.s0.q[1] : (slot == 1u ? c.s1.q[1] : c.s2.q[1]);
-    return r;
-}
-__device__ __forceinline__ void cache_put(SubsetCache& c, uint32_t slot, const SubsetResult& r)
-{
-    c.s0.e = slot == 0u ? r.e : c.s0.e; c.s0.q[0] = slot == 0u ? r.q[0] : c.s0.q[0]; c.s0.q[1] = slot == 0u ? r.q[1] : c.s0.q[1];
-    c.s1.e = slot == 1u ? r.e : c.s1.e; c.s1.q[0] = slot == 1u ? r.q[0] : c.s1.q[0]; c.s1.q[1] = slot == 1u ? r.q[1] : c.s1.q[1];
-    c.s2.e = slot == 2u ? r.e : c.s2.e; c.s2.q[0] = slot == 2u ? r.q[0] : c.s2.q[0]; c.s2.q[1] = slot == 2u ? r.q[1] : c.s2.q[1];
-}
+// The cache is nine scalars (an indexed aggregate would be demoted to scratch); `slot` is wave-uniform.
+#define ITW_CACHE_GET(F, slot) ((slot) == 0u ? F##0 : ((slot) == 1u ? F##1 : F##2))
+#define ITW_CACHE_PUT(F, slot, v) do { F##0 = (slot) == 0u ? (v) : F##0; F##1 = (slot) == 1u ? (v) : F##1; F##2 = (slot) == 2u ? (v) : F##2; } while (0)
 
 __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, Win& b0, Win& b2)
 {
@@ -500,7 +487,8 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
     const int32_t tt = full.m[0] + full.m[4] + full.m[7];          // sum over the block of |texel|^2
     const bool do2 = !S.skip_mode2;
     const int count = do2 ? 64 : 16;
-    SubsetCache cache = {{0, {0u, 0u}}, {0, {0u, 0u}}, {0, {0u, 0u}}};
+    int32_t ce0 = 0, ce1 = 0, ce2 = 0;               // cached subset results: error, index bits (low / high word)
+    uint32_t cl0 = 0u, cl1 = 0u, cl2 = 0u, ch0 = 0u, ch1 = 0u, ch2 = 0u;
     for (int pos = 0; pos < count; pos++) {
         ln.tx.fence();
         const uint32_t sched = do2 ? BC7_F02_SCHEDULE[pos] : (uint32_t)pos;     // mode 0 alone: table order, nothing cached
@@ -516,8 +504,7 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
             const uint32_t act = (sched >> (8 + 4 * j)) & 3u, slot = (sched >> (10 + 4 * j)) & 3u;
             const bool load = act == 2u;
             if (load) {                                   // this mask's mode 2 result is in the cache
-                const SubsetResult r = cache_get(cache, slot);
-                e2 += r.e; q2[0] |= r.q[0]; q2[1] |= r.q[1];
+                e2 += ITW_CACHE_GET(ce, slot); q2[0] |= ITW_CACHE_GET(cl, slot); q2[1] |= ITW_CACHE_GET(ch, slot);
                 if (!do0) { rest_valid = false; continue; }
             }
             const SubsetMask sm = subset_of(64 + part, j);
@@ -539,7 +526,7 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
                 SubsetResult r = {0, {0u, 0u}};
                 select_subset_pal<2, 3, TPB>(r.q, r.e, ln.tx, ps, ln.pal + 8 * TPB, sm.bits);
                 e2 += r.e; q2[0] |= r.q[0]; q2[1] |= r.q[1];
-                if (act == 1u) cache_put(cache, slot, r);
+                if (act == 1u) { ITW_CACHE_PUT(ce, slot, r.e); ITW_CACHE_PUT(cl, slot, r.q[0]); ITW_CACHE_PUT(ch, slot, r.q[1]); }
             }
         }
         e0 += tt; e2 += tt;                              // the |t|^2 terms the palette path leaves out
