@@ -11,20 +11,26 @@
 //     planar bytes (bc7_exact.hpp);
 //   * everything the reference computes in fp32 that cannot round (texels and decoded
 //     endpoints are integers <= 255) runs on the packed integer units: subset moment
-//     sums are masked v_dot4_u32_u8 chains, index selection is v_dot2_i32_i16 /
-//     v_pk_mad_i16 arithmetic with an exactly rounded quotient, least-squares sums are
-//     dot4 chains (proofs in bc7_exact.hpp).  What can round (PCA, endpoint
-//     quantisation, the 2x2 solve) is fp32 with the pinned x86 arithmetic;
-//   * one kernel per mode family ({0,2} {1,3} {7} {4,5,6}), run in the reference's
-//     order.  Families only communicate through "best error so far" (kernel.ispc:1358,
-//     1638, 1684), which travels in a 4 B/block workspace;
-//   * shapes are visited in TABLE order wherever the candidate list is the whole table
-//     (modes 0/2 always; modes 1/3/7 when their fastSkipTreshold is >= 64, the `slow`
-//     profiles): the shape is wave-uniform, its subset masks are scalars, a texel costs
-//     work only in the subset it belongs to (scalar branches), and the loop over subsets
-//     is rolled so every code path exists once.  The reference scans its PCA-ranked
-//     list with a strict `<`, i.e. among equal errors the lowest rank key wins; here the
-//     rank key (part + 64*bound) is only evaluated when two shapes actually tie;
+//     sums are masked v_dot4_u32_u8 chains, index selection projects with v_dot2 and an
+//     exactly rounded quotient and compares the two candidate indices through per-segment
+//     palettes in LDS (one v_dot4 per candidate), least-squares sums are dot4 chains
+//     (proofs in bc7_exact.hpp).  What can round (PCA, endpoint quantisation, the 2x2
+//     solve) is fp32 with the pinned x86 arithmetic;
+//   * per multi-subset mode family ({0,2} {1,3} {7}) a SEARCH kernel (the scan of the
+//     shapes, 112-128 VGPRs, 4 waves per SIMD) and a FINISH kernel (refinement of the
+//     winners, per-lane shapes); modes 4/5/6 are one kernel.  Families run in the
+//     reference's order and only communicate through "best error so far"
+//     (kernel.ispc:1358, 1638, 1684) and the search winners, in a 36 B/block workspace;
+//   * shapes are visited in a wave-uniform order wherever the candidate list is the
+//     whole table (modes 0/2 always; modes 1/3/7 when their fastSkipTreshold is >= 64,
+//     the `slow` profiles): subset masks are scalars, a texel costs work only in the
+//     subset it belongs to (scalar branches), and the loop over subsets is rolled so
+//     every code path exists once.  The reference scans its PCA-ranked list with a
+//     strict `<`, i.e. among equal errors the lowest rank key wins; here the rank key
+//     (part + 64*bound) is only evaluated when two shapes actually tie;
+//   * modes 0/2: a subset's mode 2 result depends on its texel mask alone and 192
+//     subsets use 140 masks, so the scan follows a generated schedule that clusters
+//     equal masks and reloads results from a three-entry register cache;
 //   * shorter ranked lists (fast profiles) keep the per-lane order: the i-th entry of
 //     the reference's selection sort (kernel.ispc:1365-1384) is the smallest key above
 //     the previous one -- a 64-entry LDS scan, no sort, no dynamic register indexing;
@@ -34,8 +40,8 @@
 //     serves its three mode 4/5 candidates;
 //   * the RCPPS/RSQRTPS seed tables are staged in LDS once per workgroup.
 //
-// VALU bound; nothing GEMM shaped, so no MFMA.  Bit-exactness with the oracle forbids
-// FMA contraction and any re-association of sums that can round.
+// VALU issue bound; nothing GEMM shaped, so no MFMA.  Bit-exactness with
+// the oracle forbids FMA contraction and any re-association of sums that can round.
 #include "bc7_exact.hpp"
 #include "kernels.hpp"
 

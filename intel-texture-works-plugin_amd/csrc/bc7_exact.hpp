@@ -403,40 +403,6 @@ __device__ __forceinline__ int32_t select_block(uint32_t (&qb)[2], const Tex& tx
     return total;
 }
 
-// Texels of ONE subset (wave-uniform mask: scalar branches skip the others) against its segment; accumulates.
-template <int BITS, int CH>
-__device__ __forceinline__ void select_subset(uint32_t (&qb)[2], int32_t& total, const Tex& tx, const Segment& sg, uint32_t mask)
-{
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        if ((mask >> k) & 1u) {
-            int32_t q, e;
-            select_texel<BITS, CH>(q, e, sg, tx.pair01(k), tx.template pair23<CH == 4>(k));
-            if (k < 8) qb[0] |= (uint32_t)q << (4 * k); else qb[1] |= (uint32_t)q << (4 * (k - 8));
-            total += e;
-        }
-    }
-}
-
-// Two modes at once over the texels of one subset (the two dependency chains interleave).
-template <int BITSA, int BITSB, int CH>
-__device__ __forceinline__ void select_subset2(uint32_t (&qa)[2], int32_t& ta, uint32_t (&qc)[2], int32_t& tc, const Tex& tx,
-                                               const Segment& sa, const Segment& sc, uint32_t mask)
-{
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        if ((mask >> k) & 1u) {
-            const uint32_t t01 = tx.pair01(k), t23 = tx.template pair23<CH == 4>(k);
-            int32_t q0, e0, q1, e1;
-            select_texel<BITSA, CH>(q0, e0, sa, t01, t23);
-            select_texel<BITSB, CH>(q1, e1, sc, t01, t23);
-            if (k < 8) { qa[0] |= (uint32_t)q0 << (4 * k); qc[0] |= (uint32_t)q1 << (4 * k); }
-            else       { qa[1] |= (uint32_t)q0 << (4 * (k - 8)); qc[1] |= (uint32_t)q1 << (4 * (k - 8)); }
-            ta += e0; tc += e1;
-        }
-    }
-}
-
 // ---- index selection through a per-segment palette in LDS ---------------------------------------------------
 // The decoded colour of index q on a segment does not depend on the texel, so a table-order scan decodes every level
 // ONCE per (subset, mode) -- LEVELS x ~30 cycles -- into LDS and each texel then needs: the projection (2 dot ops, one
