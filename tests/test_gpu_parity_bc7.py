@@ -155,3 +155,20 @@ def test_full_size_4096_slow_properties(itw, gpu, oracle):
     assert (modes >= 0).all()
     mse = np.mean((dec[..., :3].astype(np.float64) - cell[..., :3].astype(np.float64)) ** 2)
     assert 10 * np.log10(255 ** 2 / mse) > 30.0
+
+
+def test_band_of_the_16k_configuration(itw, gpu):
+    """BASELINE configs[4]: 16384^2 over 8 GPUs = a 16384 x 2048 band per GPU (band rule: 512 block rows each).  One such
+    band on this GPU: tiled from a 512^2 cell it must reproduce the cell's block stream periodically (blocks are
+    independent), which also exercises 2 M blocks per launch and the wide pitch."""
+    import torch
+    from itw_amd import surfaces
+    y0, rows, off = itw.band_for_part(16384, 16384, "bc7", 3, 8)
+    assert (y0, rows, off) == (3 * 2048, 2048, 3 * 512 * 4096 * 16)
+    cell = surfaces.ldr_smooth(512, 512)
+    band = surfaces.tile_to(cell, 2048, 16384)
+    got = gpu_encode(itw, gpu, band, "slow").reshape(512, 4096, 16)
+    tile = gpu_encode(itw, gpu, cell, "slow").reshape(128, 128, 16)
+    for ty in range(4):
+        for tx in range(32):
+            assert (got[ty * 128:(ty + 1) * 128, tx * 128:(tx + 1) * 128] == tile).all(), (ty, tx)
