@@ -203,3 +203,33 @@ def test_integer_moment_sums_are_exact_in_fp32():
     for k in rng.permutation(16):                        # any order
         acc += t[:, k, 0] * t[:, k, 1]
     assert np.array_equal(acc, (t[:, :, 0].astype(np.int64) * t[:, :, 1].astype(np.int64)).sum(axis=1).astype(np.float32))
+
+
+def test_f02_schedule_is_a_valid_cache_program():
+    """csrc/bc7_f02_schedule.h (tools/gen_bc7_f02_schedule.py): every three-subset shape is visited exactly once, and
+    every `load` finds in its slot the result of the SAME texel mask, stored earlier and not overwritten since."""
+    def arr(text, name, n):
+        body = text[text.index(name):]
+        body = body[body.index("{") + 1:body.index("}")]
+        v = [int(x, 16) for x in re.findall(r"0x([0-9a-fA-F]+)u", body)]
+        assert len(v) == n, (name, len(v))
+        return v
+    masks = arr(_header("bc7_tables.h"), "BCN_SUBSET_MASKS[128]", 128)
+    sched = arr(_header("bc7_f02_schedule.h"), "BC7_F02_SCHEDULE[64]", 64)
+    assert sorted(w & 63 for w in sched) == list(range(64))
+    slots = {}
+    loads = 0
+    for w in sched:
+        shape = 64 + (w & 63)
+        m0, m1 = masks[shape] & 0xffff, masks[shape] >> 16
+        sub = [m0, m1, ~(m0 | m1) & 0xffff]
+        assert m0 and m1 and sub[2] and (m0 | m1 | sub[2]) == 0xffff and not (m0 & m1)
+        for j in range(3):
+            act, slot = (w >> (8 + 4 * j)) & 3, (w >> (10 + 4 * j)) & 3
+            assert act in (0, 1, 2) and slot in (0, 1, 2)
+            if act == 2:
+                assert slots.get(slot) == sub[j], (hex(w), j)
+                loads += 1
+            elif act == 1:
+                slots[slot] = sub[j]
+    assert loads >= 40                                    # the point of the exercise: 44 of 192 with three slots
