@@ -84,6 +84,15 @@ rgba_surface itwPadToMultipleOf4(const rgba_surface* input, int pixel_size);
 void itwFreeSurface(rgba_surface* s);
 void itwPadToMultipleOf4Device(const rgba_surface* input, int pixel_size, uint8_t* out_ptr);
 
+/* Photoshop's interleaved planes -> the encoder's surface, on the device (IntelPlugin.cpp:741-810 ConvertToBCFrom8/16/
+ * 32Bit and :291-366 ConvertToBC6From8/16/32Bit): `src` holds width*height pixels of `planes` (1..4) interleaved
+ * channels of `depth` bits (8, 16 = Photoshop's 0..32768 range, 32 = float); missing colour planes become 0, alpha is
+ * opaque unless has_alpha (then plane 3; the reference's 32-bit -> half variant reads plane 2, kept).  `dst` is a
+ * tightly pitched RGBA8 / RGBA16F surface.  Device pointers, asynchronous on the calling thread's stream.
+ * gamma_correct applies the reference's pow(v, 1/2.2) to 32-bit input.  Returns 0, -1 on bad arguments. */
+int itwConvertToRGBA8Device(const void* src, int depth, int planes, int has_alpha, int gamma_correct, int width, int height, uint8_t* dst);
+int itwConvertToRGBA16FDevice(const void* src, int depth, int planes, int has_alpha, int width, int height, uint16_t* dst);
+
 #ifdef __cplusplus
 }
 #endif

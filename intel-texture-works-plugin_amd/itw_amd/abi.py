@@ -20,7 +20,8 @@ EXPORTED_SYMBOLS = tuple(
     + ["GetProcessorCount", "InitWin32Threads", "DestroyThreads", "GetBytesPerBlock", "CompressImageMT", "CompressImageST",
        "CompressImageBC1", "CompressImageBC3"]
     + ["CompressImageBC7_" + p for p in BC7_PROFILES] + ["CompressImageBC6H_" + p for p in BC6H_PROFILES]
-    + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device"]
+    + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
+       "itwConvertToRGBA8Device", "itwConvertToRGBA16FDevice"]
     # include/itw_decode.h: device decoders
     + ["itwDecodeBlocks"]
     # include/itw_dds.h: DDS container
@@ -115,6 +116,10 @@ def lib():
         L.itwFreeSurface.restype = None
         L.itwPadToMultipleOf4Device.argtypes = [C.POINTER(RgbaSurface), C.c_int, C.c_void_p]
         L.itwPadToMultipleOf4Device.restype = None
+        L.itwConvertToRGBA8Device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.itwConvertToRGBA8Device.restype = C.c_int
+        L.itwConvertToRGBA16FDevice.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.itwConvertToRGBA16FDevice.restype = C.c_int
         L.itwDecodeBlocks.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         L.itwDecodeBlocks.restype = C.c_int
         # DDS container (itw_dds.h)
