@@ -769,13 +769,14 @@ __device__ __forceinline__ int32_t encode_scalar(uint32_t (&qb)[2], int32_t (&qe
 
 // one (mode, rotation, index-swap) candidate, given the rotation's line fit      [kernel.ispc:1565-1621]
 template <int MODE, int SWAP>
-__device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const Lane& ln, const Tex& rot, const float (&fit)[2][4], int32_t tt,
+__device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const Lane& ln, Tex& rot, const float (&fit)[2][4], int32_t tt,
                                          const bc7_enc_settings& S, int rotation)
 {
     constexpr int BITS = SWAP ? 3 : 2;
     constexpr int ABITS = SWAP ? 2 : ((MODE == 4) ? 3 : 2);
     constexpr int AEPB = (MODE == 4) ? 6 : 8;
     const SubsetMask all = whole_block();
+    rot.fence();                                    // values derived from the rotated texels must not stay live across candidates
 
     int32_t q[2][4], d[2][4];
     uint32_t qb[2];
