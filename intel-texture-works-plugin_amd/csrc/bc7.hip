@@ -544,8 +544,10 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
 
 // Two-subset modes.  FAMILY7 = false: modes 1 and 3 (3-channel fit, shared);  true: mode 7 (4-channel fit).
 // RANK_CH: channels used by the PCA ranking (3 for modes 1/3; the profile's channel count for mode 7).
-// RANKED: at least one of the family's lists is a proper prefix of the PCA ranking (fast profiles).
-template <bool FAMILY7, int RANK_CH, bool RANKED>
+// RANKED: 0 = every shape is a candidate (table-order scan); 1 = at least one of the family's lists is a proper prefix
+// of the PCA ranking (fast profiles), keys in LDS; 2 = the same with lists of at most 16 shapes (every preset of the
+// reference): the 16 smallest keys are kept sorted in registers while the keys are produced, no LDS.
+template <bool FAMILY7, int RANK_CH, int RANKED>
 __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settings& S, Win& wa, Win& wb)
 {
     constexpr int FIT_CH = FAMILY7 ? 4 : 3;
@@ -568,7 +570,7 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
         stats_float<RANK_CH>(rfull, t);
     }
 
-    if (!RANKED) {
+    if (RANKED == 0) {
         // every shape is a candidate: table order; the rank key is only needed to order shapes of equal error
         for (int part = 0; part < 64; part++) {
             ln.tx.fence();
@@ -631,20 +633,37 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
             }
         }
     } else {
-        // ranked prefix: keys to LDS, then walk them in increasing order per lane        [kernel.ispc:1400-1414]
+        // ranked prefix: the i-th list entry of the reference's selection sort is the i-th smallest key (keys are
+        // distinct: their low 6 bits are the shape)                                      [kernel.ispc:1400-1414]
+        int32_t top[16];
+        #pragma unroll
+        for (int i = 0; i < 16; i++) top[i] = 0x7fffffff;
         for (int part = 0; part < 64; part++) {
             ln.tx.fence();
-            ln.keys[part * TPB] = rank_key<RANK_CH>(part, ln.tx, rfull, ln.T);
+            const int32_t key = rank_key<RANK_CH>(part, ln.tx, rfull, ln.T);
+            if (RANKED == 1) {
+                ln.keys[part * TPB] = key;
+            } else {
+                int32_t x = key;                                 // sorted insertion, 16 compare-exchanges
+                #pragma unroll
+                for (int i = 0; i < 16; i++) { const int32_t lo = min(top[i], x); x = max(top[i], x); top[i] = lo; }
+            }
         }
-        const int n = min(max(na, nb), 64);
+        const int n = min(max(na, nb), RANKED == 1 ? 64 : 16);
         int32_t prev = 0;
         for (int i = 0; i < n; i++) {
-            int32_t cur = 0x7fffffff;
-            for (int t = 0; t < 64; t++) {
-                const int32_t k = ln.keys[t * TPB];
-                if ((i == 0 || k > prev) && k <= cur) cur = k;
+            if (RANKED == 1) {
+                int32_t cur = 0x7fffffff;
+                for (int t = 0; t < 64; t++) {
+                    const int32_t k = ln.keys[t * TPB];
+                    if ((i == 0 || k > prev) && k <= cur) cur = k;
+                }
+                prev = cur;
+            } else {
+                prev = top[0];
+                #pragma unroll
+                for (int t = 0; t < 15; t++) top[t] = top[t + 1];
             }
-            prev = cur;
             ln.tx.fence();
             const int shape = prev & 63;
             const Shape sh = load_shape(shape);
@@ -950,23 +969,26 @@ __device__ __forceinline__ void load_win(Win& w, const uint4* __restrict__ wins,
 #ifndef SWR
 #define SWR 2
 #endif
+#ifndef SWR2
+#define SWR2 3
+#endif
 #ifndef FW
 #define FW 3
 #endif
 #ifndef FW456
 #define FW456 2
 #endif
-__host__ __device__ constexpr int search_waves(int family, bool ranked) { return ranked ? SWR : (family == F_MODE7 ? SW7 : (family == F_MODES02 ? SW02 : SW13)); }
+__host__ __device__ constexpr int search_waves(int family, int ranked) { return ranked == 2 ? SWR2 : ranked ? SWR : (family == F_MODE7 ? SW7 : (family == F_MODES02 ? SW02 : SW13)); }
 __host__ __device__ constexpr int finish_waves(int family) { return family == F_MODES13 ? FW : FW456; }
 
-template <int FAMILY, bool RANKED, bool VEC16>
+template <int FAMILY, int RANKED, bool VEC16>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(search_waves(FAMILY, RANKED), search_waves(FAMILY, RANKED))))
 bc7_search_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
                   uint4* __restrict__ wins, const bc7_enc_settings S)
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
-    extern __shared__ int32_t s_keys[];            // 64 * TPB keys, only allocated for ranked lists
+    extern __shared__ int32_t s_keys[];            // 64 * TPB keys, only allocated for RANKED == 1
     __shared__ uint2 s_pal[RANKED ? 1 : 12 * TPB]; // per-lane palettes of the table-order scans: 8 + 4 levels (24 KiB)
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
@@ -1054,10 +1076,10 @@ struct Bc7Launch {
     uint8_t* dst; int32_t* err; uint4* wins; bc7_enc_settings S; int first;
 };
 
-template <int FAMILY, bool RANKED>
+template <int FAMILY, int RANKED>
 static void launch_search(const Bc7Launch& L)
 {
-    const size_t lds = RANKED ? (size_t)64 * TPB * sizeof(int32_t) : 0;
+    const size_t lds = RANKED == 1 ? (size_t)64 * TPB * sizeof(int32_t) : 0;
     if (L.vec) hipLaunchKernelGGL((bc7_search_kernel<FAMILY, RANKED, true>),  L.grid, dim3(TPB), lds, L.st, L.src, L.stride, L.bx, L.n, L.wins, L.S);
     else       hipLaunchKernelGGL((bc7_search_kernel<FAMILY, RANKED, false>), L.grid, dim3(TPB), lds, L.st, L.src, L.stride, L.bx, L.n, L.wins, L.S);
 }
@@ -1093,14 +1115,19 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
     L.st = st; L.src = src; L.stride = stride; L.bx = bx; L.n = (int32_t)n; L.dst = dst; L.first = 1;
     const bc7_enc_settings& S = L.S;
     auto ranked = [](int t) { return t > 0 && t < 64; };
-    if (S.mode_selection[0]) { launch_search<F_MODES02, false>(L); launch_finish<F_MODES02>(L); }
+    auto small = [](int t) { return t <= 16; };                  // non-positive thresholds disable the mode
+    if (S.mode_selection[0]) { launch_search<F_MODES02, 0>(L); launch_finish<F_MODES02>(L); }
     if (S.mode_selection[1] && (S.fastSkipTreshold_mode1 > 0 || S.fastSkipTreshold_mode3 > 0)) {
-        if (ranked(S.fastSkipTreshold_mode1) || ranked(S.fastSkipTreshold_mode3)) launch_search<F_MODES13, true>(L);
-        else launch_search<F_MODES13, false>(L);
+        if (ranked(S.fastSkipTreshold_mode1) || ranked(S.fastSkipTreshold_mode3)) {
+            if (small(S.fastSkipTreshold_mode1) && small(S.fastSkipTreshold_mode3)) launch_search<F_MODES13, 2>(L);
+            else launch_search<F_MODES13, 1>(L);
+        } else launch_search<F_MODES13, 0>(L);
         launch_finish<F_MODES13>(L);
     }
     if (S.mode_selection[1] && S.fastSkipTreshold_mode7 > 0) {
-        if (ranked(S.fastSkipTreshold_mode7)) launch_search<F_MODE7, true>(L); else launch_search<F_MODE7, false>(L);
+        if (ranked(S.fastSkipTreshold_mode7)) {
+            if (small(S.fastSkipTreshold_mode7)) launch_search<F_MODE7, 2>(L); else launch_search<F_MODE7, 1>(L);
+        } else launch_search<F_MODE7, 0>(L);
         launch_finish<F_MODE7>(L);
     }
     if (S.mode_selection[2] || S.mode_selection[3]) launch_finish<F_MODES456>(L);

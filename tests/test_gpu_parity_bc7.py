@@ -56,7 +56,11 @@ def test_custom_settings_struct(itw, gpu, oracle):
     from itw_amd import surfaces
     img = surfaces.ldr_smooth(64, 64)
     for tweak in ({"fastSkipTreshold_mode7": 5}, {"fastSkipTreshold_mode1": 0, "fastSkipTreshold_mode3": 7},
-                  {"fastSkipTreshold_mode1": 20, "fastSkipTreshold_mode3": 3}, {"mode45_channel0": 2}):
+                  {"fastSkipTreshold_mode1": 20, "fastSkipTreshold_mode3": 3}, {"mode45_channel0": 2},
+                  # 16 / 17: the boundary between the in-register top-16 ranking and the LDS-key ranking (bc7.hip RANKED 2 / 1)
+                  {"fastSkipTreshold_mode1": 16, "fastSkipTreshold_mode3": 16, "fastSkipTreshold_mode7": 16},
+                  {"fastSkipTreshold_mode1": 17, "fastSkipTreshold_mode3": 2, "fastSkipTreshold_mode7": 17},
+                  {"fastSkipTreshold_mode1": 1, "fastSkipTreshold_mode3": 0, "fastSkipTreshold_mode7": 1}):
         s = itw.bc7_profile("basic")
         so = oracle.bc7_profile("basic")
         for k, v in tweak.items():
