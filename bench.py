@@ -36,10 +36,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB
 VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, separate mul/add (contract=off => no FMA credit)
 
 # algorithmic bytes per 4x4 block: texels read + block written
-ALG_BYTES = {"bc1": 64 + 8, "bc3": 64 + 16, "bc7": 64 + 16, "bc6h": 128 + 16}
+ALG_BYTES = {"bc1": 64 + 8, "bc3": 64 + 16, "bc7": 64 + 16, "bc6h": 128 + 16, "bc4": 64 + 8, "bc5": 64 + 16}
 
 WORKLOADS = {
-    "bc1": ("bc1", None), "bc3": ("bc3", None),
+    "bc1": ("bc1", None), "bc3": ("bc3", None), "bc4": ("bc4", None), "bc5": ("bc5", None),
     "bc7_ultrafast": ("bc7", "ultrafast"), "bc7_veryfast": ("bc7", "veryfast"), "bc7_fast": ("bc7", "fast"),
     "bc7_basic": ("bc7", "basic"), "bc7_slow": ("bc7", "slow"),
     "bc7_alpha_basic": ("bc7", "alpha_basic"), "bc7_alpha_slow": ("bc7", "alpha_slow"),
@@ -240,7 +240,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_formats:
         side = {}
-        for wl in ("bc1", "bc3", "bc7_basic", "bc7_slow", "bc7_alpha_slow", "bc6h_fast", "bc6h_slow"):
+        for wl in ("bc1", "bc3", "bc4", "bc5", "bc7_basic", "bc7_slow", "bc7_alpha_slow", "bc6h_fast", "bc6h_slow"):
             if wl == args.workload:
                 continue
             f2, p2 = WORKLOADS[wl]

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include "../../include/itw_amd.h"
+#include "../../include/itw_bc45.h"
 #include "kernels.hpp"
 #include "x86_math.hpp"
 
@@ -83,7 +84,7 @@ bool is_device_pointer(const void* p)
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
-enum class Fmt { BC1, BC3, BC7, BC6H };
+enum class Fmt { BC1, BC3, BC7, BC6H, BC4, BC5 };
 
 struct Job {
     Fmt fmt;
@@ -117,6 +118,8 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
     case Fmt::BC3:  itw::launch_bc3(d_src, stride, w, h, d_dst, st); break;
     case Fmt::BC7:  itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st), st); break;
     case Fmt::BC6H: itw::launch_bc6h(d_src, stride, w, h, d_dst, *j.s6, st); break;
+    case Fmt::BC4:  itw::launch_bc4(d_src, stride, w, h, d_dst, st); break;
+    case Fmt::BC5:  itw::launch_bc5(d_src, stride, w, h, d_dst, st); break;
     }
     ITW_CHECK(hipGetLastError());
 }
@@ -125,15 +128,18 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst)
 {
     if (!src) { std::fprintf(stderr, "libispc_texcomp (itw-amd): null surface\n"); std::abort(); }
     const int w = src->width, h = src->height;
-    const int bx = w / 4, by = h / 4;                 // partial blocks dropped (kernel.ispc:600-601)
+    // ISPC formats drop partial blocks (kernel.ispc:600-601); the DirectXTex formats keep them (DirectXTexCompress.cpp:108-116)
+    const bool keep_partial = (j.fmt == Fmt::BC4 || j.fmt == Fmt::BC5);
+    const int bx = keep_partial ? (w > 0 ? (w + 3) / 4 : 0) : w / 4, by = keep_partial ? (h > 0 ? (h + 3) / 4 : 0) : h / 4;
     if (bx <= 0 || by <= 0) return;                   // nothing to encode: the reference's loops do not run either
     if (!src->ptr || !dst) {
         std::fprintf(stderr, "libispc_texcomp (itw-amd): null texel or destination pointer\n");
         std::abort();
     }
-    const int bpb = (j.fmt == Fmt::BC1) ? 8 : 16;
+    const int bpb = (j.fmt == Fmt::BC1 || j.fmt == Fmt::BC4) ? 8 : 16;
     const int texel_bytes = (j.fmt == Fmt::BC6H) ? 8 : 4;
-    const size_t row_bytes = (size_t)bx * 4 * texel_bytes;
+    const size_t row_bytes = keep_partial ? (size_t)w * 4 : (size_t)bx * 4 * texel_bytes;
+    const size_t rows = keep_partial ? (size_t)h : (size_t)by * 4;
     const size_t out_bytes = (size_t)bx * by * bpb;
 
     const bool src_dev = is_device_pointer(src->ptr);
@@ -151,8 +157,8 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst)
     if (!src_dev) {
         // tight staging pitch, 16-byte aligned rows so the vector load path applies
         const size_t pitch = (row_bytes + 15) & ~(size_t)15;
-        uint8_t* in = (uint8_t*)grow(tls.d_in, tls.in_cap, pitch * (size_t)by * 4);
-        ITW_CHECK(hipMemcpy2DAsync(in, pitch, src->ptr, (size_t)src->stride, row_bytes, (size_t)by * 4,
+        uint8_t* in = (uint8_t*)grow(tls.d_in, tls.in_cap, pitch * rows);
+        ITW_CHECK(hipMemcpy2DAsync(in, pitch, src->ptr, (size_t)src->stride, row_bytes, rows,
                                    hipMemcpyHostToDevice, st));
         d_src = in; d_stride = (int64_t)pitch;
     } else if (tls.user_stream != st) {
@@ -273,6 +279,15 @@ void CompressBlocksBC6H(const rgba_surface* src, uint8_t* dst, bc6h_enc_settings
 {
     if (!settings) { std::fprintf(stderr, "libispc_texcomp (itw-amd): null bc6h settings\n"); std::abort(); }
     Job j; j.fmt = Fmt::BC6H; j.s6 = settings; compress(j, src, dst);
+}
+
+void CompressBlocksBC4(const rgba_surface* src, uint8_t* dst)
+{
+    Job j; j.fmt = Fmt::BC4; compress(j, src, dst);
+}
+void CompressBlocksBC5(const rgba_surface* src, uint8_t* dst)
+{
+    Job j; j.fmt = Fmt::BC5; compress(j, src, dst);
 }
 
 void  itwSetStream(void* s) { tls.user_stream = (hipStream_t)s; }

@@ -10,6 +10,10 @@ namespace itw {
 // output tightly packed in raster block order; asynchronous on `st`.
 void launch_bc1 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
 void launch_bc3 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
+// BC4_UNORM / BC5_UNORM of the R (and G) channel of an RGBA8 surface, DirectXTex's encoder (bc4_bc5.hip).  Any
+// width/height >= 1: ceil(width/4) x ceil(height/4) blocks, partial blocks replicated by DirectXTex's rule.
+void launch_bc4 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
+void launch_bc5 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
 // BC7 runs as up to seven kernels (search + finish per multi-subset mode family, one for modes 4/5/6) that hand
 // "best error so far" and the search winners to each other through
 // `workspace`: device memory, bc7_workspace_bytes(width, height) bytes, 16 B aligned, contents irrelevant on entry.

@@ -12,5 +12,5 @@ GPU is present, calls raise / the library aborts.  Nothing here imports oracle/.
 from .abi import (  # noqa: F401
     lib, lib_path, RgbaSurface, Bc7Settings, Bc6hSettings, BC7_PROFILES, BC6H_PROFILES,
     bc7_profile, bc6h_profile, compress, compress_numpy, band_for_part, version, device_info,
-    BYTES_PER_BLOCK, EXPORTED_SYMBOLS, DXGI_FORMAT, DdsDesc, image_func, compress_image, pad_to_multiple_of_4, dds_file, decode,
+    BYTES_PER_BLOCK, EXPORTED_SYMBOLS, DXGI_FORMAT, DdsDesc, image_func, compress_image, pad_to_multiple_of_4, dds_file, decode, block_count, KEEPS_PARTIAL_BLOCKS,
 )

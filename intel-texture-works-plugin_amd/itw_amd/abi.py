@@ -5,7 +5,8 @@ import os
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.normpath(os.path.join(_PKG, "..", "lib", "libispc_texcomp.so"))
 
-BYTES_PER_BLOCK = {"bc1": 8, "bc3": 16, "bc7": 16, "bc6h": 16}
+BYTES_PER_BLOCK = {"bc1": 8, "bc3": 16, "bc7": 16, "bc6h": 16, "bc4": 8, "bc5": 16}
+KEEPS_PARTIAL_BLOCKS = ("bc4", "bc5")     # DirectXTex formats: ceil(w/4) x ceil(h/4) blocks (include/itw_bc45.h)
 BC7_PROFILES = ("ultrafast", "veryfast", "fast", "basic", "slow",
                 "alpha_ultrafast", "alpha_veryfast", "alpha_fast", "alpha_basic", "alpha_slow")
 BC6H_PROFILES = ("veryfast", "fast", "basic", "slow", "veryslow")
@@ -22,6 +23,8 @@ EXPORTED_SYMBOLS = tuple(
     + ["CompressImageBC7_" + p for p in BC7_PROFILES] + ["CompressImageBC6H_" + p for p in BC6H_PROFILES]
     + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
        "itwConvertToRGBA8Device", "itwConvertToRGBA16FDevice"]
+    # include/itw_bc45.h: the DirectXTex formats of the plugin
+    + ["CompressBlocksBC4", "CompressBlocksBC5"]
     # include/itw_decode.h: device decoders
     + ["itwDecodeBlocks"]
     # include/itw_dds.h: DDS container
@@ -81,6 +84,10 @@ def lib():
                 "or `make -C intel-texture-works-plugin_amd/csrc`.  There is no CPU fallback.")
         L = C.CDLL(_LIB, mode=C.RTLD_GLOBAL)
         L.CompressBlocksBC1.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
+        L.CompressBlocksBC4.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
+        L.CompressBlocksBC5.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
+        L.CompressBlocksBC4.restype = None
+        L.CompressBlocksBC5.restype = None
         L.CompressBlocksBC3.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
         L.CompressBlocksBC7.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.POINTER(Bc7Settings)]
         L.CompressBlocksBC6H.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.POINTER(Bc6hSettings)]
@@ -179,6 +186,10 @@ def _call(fmt, surf, dst_ptr, settings):
         L.CompressBlocksBC1(C.byref(surf), dst_ptr)
     elif fmt == "bc3":
         L.CompressBlocksBC3(C.byref(surf), dst_ptr)
+    elif fmt == "bc4":
+        L.CompressBlocksBC4(C.byref(surf), dst_ptr)
+    elif fmt == "bc5":
+        L.CompressBlocksBC5(C.byref(surf), dst_ptr)
     elif fmt == "bc7":
         st = settings if isinstance(settings, Bc7Settings) else bc7_profile(settings or "slow")
         L.CompressBlocksBC7(C.byref(surf), dst_ptr, C.byref(st))
@@ -189,6 +200,13 @@ def _call(fmt, surf, dst_ptr, settings):
         raise ValueError(fmt)
 
 
+def block_count(fmt, width, height):
+    """Blocks a width x height surface encodes to: the ISPC formats drop partial blocks, the DirectXTex ones keep them."""
+    if fmt in KEEPS_PARTIAL_BLOCKS:
+        return ((width + 3) // 4) * ((height + 3) // 4)
+    return (width // 4) * (height // 4)
+
+
 def compress_numpy(fmt, img, settings=None):
     """Host-pointer path (what the Photoshop plugin does): img (H, W, 4) uint8, or uint16 half bits for bc6h.
     Synchronous; returns a uint8 numpy array of packed blocks."""
@@ -196,7 +214,7 @@ def compress_numpy(fmt, img, settings=None):
     assert img.ndim == 3 and img.shape[2] == 4 and img.strides[2] == img.itemsize and img.strides[1] == 4 * img.itemsize
     assert img.dtype == (np.uint16 if fmt == "bc6h" else np.uint8)
     h, w = img.shape[:2]
-    out = np.empty((h // 4) * (w // 4) * BYTES_PER_BLOCK[fmt], dtype=np.uint8)
+    out = np.empty(block_count(fmt, w, h) * BYTES_PER_BLOCK[fmt], dtype=np.uint8)
     surf = RgbaSurface(img.ctypes.data, w, h, img.strides[0])
     _call(fmt, surf, out.ctypes.data, settings)
     return out
@@ -211,7 +229,7 @@ def compress(fmt, img, settings=None, out=None):
     assert es == (2 if fmt == "bc6h" else 1), "texel type does not match the format"
     assert img.stride(2) == 1 and img.stride(1) == 4
     h, w = img.shape[:2]
-    nbytes = (h // 4) * (w // 4) * BYTES_PER_BLOCK[fmt]
+    nbytes = block_count(fmt, w, h) * BYTES_PER_BLOCK[fmt]
     if out is None:
         out = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
     assert out.is_cuda and out.numel() >= nbytes and out.is_contiguous()

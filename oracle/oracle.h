@@ -74,6 +74,13 @@ void oracle_decode_bc3 (const uint8_t blk[16], uint8_t out_rgba[64]);
 int  oracle_decode_bc7 (const uint8_t blk[16], uint8_t out_rgba[64]);   /* returns mode, -1 if reserved */
 int  oracle_decode_bc6h(const uint8_t blk[16], uint16_t out_rgb[48]);  /* unsigned; returns mode 0..13 (kernel.ispc numbering), -1 if reserved */
 
+/* BC4_UNORM / BC5_UNORM: the DirectXTex encoder the plugin uses for these two formats (bc4_bc5.c).  Source = RGBA8
+ * surface (R, or R and G, are encoded); any width/height >= 1, ceil(w/4) x ceil(h/4) blocks out. */
+void oracle_CompressBlocksBC4(const oracle_surface* src, uint8_t* dst);
+void oracle_CompressBlocksBC5(const oracle_surface* src, uint8_t* dst);
+void oracle_bc4_block(const float texels[16], uint8_t out[8]);
+void oracle_decode_bc4(const uint8_t blk[8], float out[16]);
+
 #ifdef __cplusplus
 }
 #endif

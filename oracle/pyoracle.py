@@ -73,6 +73,9 @@ def lib():
             if hasattr(L, n):
                 getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, n).restype = C.c_int
+        for n in ("oracle_CompressBlocksBC4", "oracle_CompressBlocksBC5", "oracle_bc4_block", "oracle_decode_bc4"):
+            getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
+            getattr(L, n).restype = None
         _lib = L
     return _lib
 
@@ -109,6 +112,8 @@ def encode(fmt, img, profile=None, rows=None):
     img = np.ascontiguousarray(img)
     if rows is not None:
         img = img[rows[0]:rows[1]]
+    if fmt in ("bc4", "bc5"):
+        return encode_bc45(fmt, img)
     h, w = img.shape[:2]
     # kernel.ispc:157 places block row yy at byte yy*width*data_size: only for width % 4 == 0 is that the tight
     # pitch (width/4)*bytes_per_block.  Other widths are outside the reference's contract (ispc_texcomp.h:95).
@@ -135,6 +140,41 @@ def encode(fmt, img, profile=None, rows=None):
     else:
         raise ValueError(fmt)
     return out
+
+
+def encode_bc45(fmt, img):
+    """BC4/BC5 (DirectXTex path): img (H, W, 4) uint8, any H, W >= 1 -> ceil(W/4) x ceil(H/4) blocks."""
+    img = np.ascontiguousarray(img)
+    assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 4
+    h, w = img.shape[:2]
+    bpb = 8 if fmt == "bc4" else 16
+    out = np.zeros(((h + 3) // 4) * ((w + 3) // 4) * bpb, dtype=np.uint8)
+    s = _surface(img)
+    fn = lib().oracle_CompressBlocksBC4 if fmt == "bc4" else lib().oracle_CompressBlocksBC5
+    fn(C.byref(s), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def bc4_block(texels):
+    """One channel of one block: 16 float32 texels in [0, 1] -> 8 bytes."""
+    t = np.ascontiguousarray(texels, dtype=np.float32).reshape(16)
+    out = np.zeros(8, dtype=np.uint8)
+    lib().oracle_bc4_block(t.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def decode_bc45(fmt, blocks, width, height):
+    """DirectXTex's float decode of a BC4/BC5 stream -> (ceil4(H), ceil4(W), channels) float32."""
+    nch = 1 if fmt == "bc4" else 2
+    bx, by = (width + 3) // 4, (height + 3) // 4
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(by, bx, nch, 8)
+    out = np.zeros((by, bx, nch, 16), dtype=np.float32)
+    L = lib()
+    for y in range(by):
+        for x in range(bx):
+            for c in range(nch):
+                L.oracle_decode_bc4(blocks[y, x, c].ctypes.data_as(C.c_void_p), out[y, x, c].ctypes.data_as(C.c_void_p))
+    return out.reshape(by, bx, nch, 4, 4).transpose(0, 3, 1, 4, 2).reshape(by * 4, bx * 4, nch)
 
 
 def usable_cores():

@@ -79,5 +79,25 @@ def main():
         print(f"{k:40s} {v.size:8d} B  sha256 {surfaces.sha256(v)[:16]}")
 
 
+def main_bc45():
+    """BC4/BC5 (the DirectXTex formats): separate file so the ISPC-format fixtures stay byte-identical.  Includes the
+    217 x 215 and 5 x 7 crops of monkey.png (odd sizes: DirectXTex's partial-block rule on both edges)."""
+    pyoracle.build()
+    monkey = load_png_rgba("monkey.png")
+    data = {"monkey_crop.input": np.ascontiguousarray(monkey[1:218, 2:217]),
+            "tiny.input": np.ascontiguousarray(monkey[40:45, 60:67])}
+    cases = {"baboon": load_png_rgba("baboon.png"), "edge_cases": surfaces.ldr_edge_cases(),
+             "monkey_crop": data["monkey_crop.input"], "tiny": data["tiny.input"]}
+    for name, img in cases.items():
+        for fmt in ("bc4", "bc5"):
+            data[f"{name}.{fmt}"] = pyoracle.encode_bc45(fmt, img)
+    np.savez_compressed(os.path.join(OUT, "golden_bc45.npz"), **data)
+    for k, v in sorted(data.items()):
+        print(f"{k:40s} {v.size:8d} B  sha256 {surfaces.sha256(v)[:16]}")
+
+
 if __name__ == "__main__":
-    main()
+    if "--bc45" in sys.argv:
+        main_bc45()
+    else:
+        main()
