@@ -18,7 +18,7 @@ extern "C" {
 typedef struct ItwDdsDesc {
     uint32_t width, height;     /* top mip, texels */
     uint32_t mip_levels;        /* >= 1 */
-    uint32_t dxgi_format;       /* DXGI_FORMAT_BCn_* value (71,72,77,78,95,96,98,99) */
+    uint32_t dxgi_format;       /* DXGI_FORMAT_BCn_* value (71,72,77,78,80,83,95,96,98,99) */
     uint32_t is_cubemap;        /* 0 / 1: six faces */
     uint32_t array_size;        /* number of textures (cubes when is_cubemap); >= 1 */
 } ItwDdsDesc;

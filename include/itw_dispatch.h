@@ -27,6 +27,7 @@ typedef void (CompressionFunc)(const rgba_surface* input, uint8_t* output);
 enum {
     ITW_DXGI_FORMAT_BC1_UNORM = 71, ITW_DXGI_FORMAT_BC1_UNORM_SRGB = 72,
     ITW_DXGI_FORMAT_BC3_UNORM = 77, ITW_DXGI_FORMAT_BC3_UNORM_SRGB = 78,
+    ITW_DXGI_FORMAT_BC4_UNORM = 80, ITW_DXGI_FORMAT_BC5_UNORM = 83,       /* the DirectXTex formats, itw_bc45.h */
     ITW_DXGI_FORMAT_BC6H_UF16 = 95, ITW_DXGI_FORMAT_BC6H_SF16 = 96,
     ITW_DXGI_FORMAT_BC7_UNORM = 98, ITW_DXGI_FORMAT_BC7_UNORM_SRGB = 99
 };
@@ -38,7 +39,8 @@ int  GetProcessorCount(void);
 void InitWin32Threads(void);
 void DestroyThreads(void);
 
-/* win32Threads.cpp:192-209: 8 for BC1 (and anything unknown), 16 for BC3 / BC7 / BC6H */
+/* win32Threads.cpp:192-209: 8 for BC1 (and anything unknown, so BC4 too), 16 for BC3 / BC7 / BC6H -- and for BC5, which
+ * the reference's switch does not list because BC5 never reaches it there */
 int  GetBytesPerBlock(int dxgi_format);
 
 /* win32Threads.cpp:211-249, 277-282.  `input`/`output` are host or device pointers exactly as CompressBlocks* accepts
@@ -50,6 +52,10 @@ bool CompressImageST(const rgba_surface* input, uint8_t* output, CompressionFunc
 /* win32Threads.h:58-80 / win32Threads.cpp:289-329: profile trampolines */
 void CompressImageBC1(const rgba_surface* input, uint8_t* output);
 void CompressImageBC3(const rgba_surface* input, uint8_t* output);
+/* same shape for the two formats the plugin sends to DirectX::Compress instead (IntelPlugin.cpp:271-273); with these the
+ * band / slice rules above also keep the partial last block row and column (itw_bc45.h) */
+void CompressImageBC4(const rgba_surface* input, uint8_t* output);
+void CompressImageBC5(const rgba_surface* input, uint8_t* output);
 void CompressImageBC7_ultrafast(const rgba_surface* input, uint8_t* output);
 void CompressImageBC7_veryfast(const rgba_surface* input, uint8_t* output);
 void CompressImageBC7_fast(const rgba_surface* input, uint8_t* output);

@@ -22,14 +22,24 @@ constexpr uint32_t fourcc(char a, char b, char c, char d)
 int bytes_per_block(uint32_t f)
 {
     switch (f) {
-    case 71: case 72: return 8;
-    case 77: case 78: case 95: case 96: case 98: case 99: return 16;
+    case 71: case 72: case 80: return 8;                    // BC1, BC4_UNORM
+    case 77: case 78: case 83: case 95: case 96: case 98: case 99: return 16;   // BC3, BC5_UNORM, BC6H, BC7
     default: return 0;
     }
 }
 
 // legacy FourCC for the formats DirectXTex maps without the DX10 extension
-uint32_t legacy_fourcc(uint32_t f) { return f == 71 ? fourcc('D', 'X', 'T', '1') : f == 77 ? fourcc('D', 'X', 'T', '5') : 0u; }
+// (DirectXTexDDS.cpp:474-483; DDS.h:71-90: BC4_UNORM -> "BC4U", BC5_UNORM -> "BC5U")
+uint32_t legacy_fourcc(uint32_t f)
+{
+    switch (f) {
+    case 71: return fourcc('D', 'X', 'T', '1');
+    case 77: return fourcc('D', 'X', 'T', '5');
+    case 80: return fourcc('B', 'C', '4', 'U');
+    case 83: return fourcc('B', 'C', '5', 'U');
+    default: return 0u;
+    }
+}
 
 bool needs_dx10(const ItwDdsDesc& d)
 {
@@ -119,6 +129,8 @@ size_t itwDdsReadHeader(const uint8_t* src, size_t size, ItwDdsDesc* out)
     const uint32_t cc = get32(h, 20);
     if (cc == fourcc('D', 'X', 'T', '1')) d.dxgi_format = 71;
     else if (cc == fourcc('D', 'X', 'T', '5')) d.dxgi_format = 77;
+    else if (cc == fourcc('B', 'C', '4', 'U') || cc == fourcc('A', 'T', 'I', '1')) d.dxgi_format = 80;   // DirectXTexDDS.cpp:64-70
+    else if (cc == fourcc('B', 'C', '5', 'U') || cc == fourcc('A', 'T', 'I', '2')) d.dxgi_format = 83;
     else if (cc == fourcc('D', 'X', '1', '0')) {
         if (size < 148) return 0;
         const uint8_t* e = h + 124;

@@ -70,7 +70,9 @@ __device__ __forceinline__ void decode_color(uint32_t w0, uint32_t idx, bool all
     }
 }
 
-__device__ __forceinline__ void decode_bc3_alpha(uint32_t w0, uint32_t w1, uint32_t (&px)[16])
+// The 8-byte interpolated-scalar block shared by BC3 alpha, BC4 and both halves of BC5; the value lands in byte SHIFT/8.
+template <int SHIFT>
+__device__ __forceinline__ void decode_scalar_block(uint32_t w0, uint32_t w1, uint32_t (&px)[16])
 {
     int a[8];
     a[0] = (int)(w0 & 255u); a[1] = (int)((w0 >> 8) & 255u);
@@ -89,9 +91,10 @@ __device__ __forceinline__ void decode_bc3_alpha(uint32_t w0, uint32_t w1, uint3
         int v = a[0];
 #pragma unroll
         for (int i = 1; i < 8; i++) v = (q == (uint32_t)i) ? a[i] : v;
-        px[k] = (px[k] & 0x00ffffffu) | ((uint32_t)v << 24);
+        px[k] = (px[k] & ~(0xffu << SHIFT)) | ((uint32_t)v << SHIFT);
     }
 }
+__device__ __forceinline__ void decode_bc3_alpha(uint32_t w0, uint32_t w1, uint32_t (&px)[16]) { decode_scalar_block<24>(w0, w1, px); }
 
 // ---- BC7 ---------------------------------------------------------------------------------------------------
 struct Bc7Mode { unsigned char ns, pb, rb, isb, cb, ab, epb, spb, ib, ib2; };
@@ -268,6 +271,17 @@ decode_kernel(const uint8_t* __restrict__ blocks, int32_t blocks_x, int32_t nblo
             const uint4 w = *reinterpret_cast<const uint4*>(blocks + (int64_t)b * 16);
             decode_color(w.z, w.w, false, px);
             decode_bc3_alpha(w.x, w.y, px);
+        } else if (FMT == 4) {                                   // BC4_UNORM -> (R, 0, 0, 255) like D3DXDecodeBC4U (BC4BC5.cpp:373-385)
+            const uint2 w = *reinterpret_cast<const uint2*>(blocks + (int64_t)b * 8);
+#pragma unroll
+            for (int k = 0; k < 16; k++) px[k] = 0xff000000u;
+            decode_scalar_block<0>(w.x, w.y, px);
+        } else if (FMT == 5) {                                   // BC5_UNORM -> (R, G, 0, 255) (BC4BC5.cpp:449-462)
+            const uint4 w = *reinterpret_cast<const uint4*>(blocks + (int64_t)b * 16);
+#pragma unroll
+            for (int k = 0; k < 16; k++) px[k] = 0xff000000u;
+            decode_scalar_block<0>(w.x, w.y, px);
+            decode_scalar_block<8>(w.z, w.w, px);
         } else {
             const uint4 w = *reinterpret_cast<const uint4*>(blocks + (int64_t)b * 16);
             Bits bs{(unsigned long long)w.x | ((unsigned long long)w.y << 32), (unsigned long long)w.z | ((unsigned long long)w.w << 32), 0};
@@ -301,11 +315,11 @@ bool on_device(const void* p)
 
 extern "C" int itwDecodeBlocks(int f, const uint8_t* blocks, int width, int height, uint8_t* out, int64_t out_stride, int32_t* modes)
 {
-    const int kind = (f == 71 || f == 72) ? 1 : (f == 77 || f == 78) ? 3 : (f == 98 || f == 99) ? 7 : (f == 95 || f == 96) ? 6 : 0;
+    const int kind = (f == 71 || f == 72) ? 1 : (f == 77 || f == 78) ? 3 : (f == 98 || f == 99) ? 7 : (f == 95 || f == 96) ? 6 : f == 80 ? 4 : f == 83 ? 5 : 0;
     if (!kind || width < 4 || height < 4 || (width & 3) || (height & 3) || (out_stride & 3)) return -1;
     const int bx = width / 4, by = height / 4;
     const int64_t n = (int64_t)bx * by;
-    const size_t in_bytes = (size_t)n * (kind == 1 ? 8 : 16), texel = kind == 6 ? 8 : 4;
+    const size_t in_bytes = (size_t)n * ((kind == 1 || kind == 4) ? 8 : 16), texel = kind == 6 ? 8 : 4;
     const size_t row_bytes = (size_t)width * texel;
     if ((size_t)out_stride < row_bytes) return -1;
     hipStream_t st = (hipStream_t)itwGetStream();
@@ -322,6 +336,8 @@ extern "C" int itwDecodeBlocks(int f, const uint8_t* blocks, int width, int heig
     case 1: hipLaunchKernelGGL((itw::decode_kernel<1>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
     case 3: hipLaunchKernelGGL((itw::decode_kernel<3>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
     case 7: hipLaunchKernelGGL((itw::decode_kernel<7>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
+    case 4: hipLaunchKernelGGL((itw::decode_kernel<4>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
+    case 5: hipLaunchKernelGGL((itw::decode_kernel<5>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
     default: hipLaunchKernelGGL((itw::decode_kernel<6>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
     }
     DEC_CHECK(hipGetLastError());

@@ -17,6 +17,7 @@
 #include <vector>
 #include "../../include/itw_dispatch.h"
 #include "../../include/itw_amd.h"
+#include "../../include/itw_bc45.h"
 
 namespace {
 
@@ -24,6 +25,7 @@ struct Job {
     rgba_surface input;
     uint8_t* output = nullptr;
     CompressionFunc* fn = nullptr;
+    int min_height = 4;         // bands shorter than one block row are skipped (win32Threads.cpp:263); 1 for BC4/BC5
     bool pending = false;
 };
 
@@ -47,7 +49,7 @@ struct Pool {
             if (quit) return;
             Job j = jobs[idx];
             lk.unlock();
-            if (j.input.height >= 4) j.fn(&j.input, j.output);     // win32Threads.cpp:263
+            if (j.input.height >= j.min_height) j.fn(&j.input, j.output);
             lk.lock();
             jobs[idx].pending = false;
             if (--outstanding == 0) done.notify_all();
@@ -133,9 +135,14 @@ void DestroyThreads(void)
     g_pool = nullptr;
 }
 
+// The DirectXTex formats keep partial blocks (itw_bc45.h); the ISPC formats drop them (kernel.ispc:600-601).
+static bool keeps_partial_blocks(int f) { return f == ITW_DXGI_FORMAT_BC4_UNORM || f == ITW_DXGI_FORMAT_BC5_UNORM; }
+static int blocks_across(int width, int f) { return keeps_partial_blocks(f) ? (width + 3) / 4 : width / 4; }
+
 int GetBytesPerBlock(int f)
 {
     switch (f) {
+    case ITW_DXGI_FORMAT_BC5_UNORM:                              // not in the reference's switch (BC5 never reaches it there)
     case ITW_DXGI_FORMAT_BC3_UNORM_SRGB: case ITW_DXGI_FORMAT_BC3_UNORM:
     case ITW_DXGI_FORMAT_BC7_UNORM_SRGB: case ITW_DXGI_FORMAT_BC7_UNORM:
     case ITW_DXGI_FORMAT_BC6H_UF16: case ITW_DXGI_FORMAT_BC6H_SF16:
@@ -166,12 +173,14 @@ bool CompressImageMT(const rgba_surface* input, uint8_t* output, CompressionFunc
         for (int i = 0; i < n; i++) {
             int y0 = (lines * i) / 4 * 4, y1 = (lines * (i + 1)) / 4 * 4;
             if (y1 > input->height) y1 = input->height;
+            if (i == n - 1 && keeps_partial_blocks(dxgi_format)) y1 = input->height;   // the partial block row, if any
             Job& j = p->jobs[i];
             j.input = *input;
             j.input.ptr = input->ptr + (int64_t)y0 * input->stride;
             j.input.height = y1 - y0;
-            j.output = output + (int64_t)(y0 / 4) * (input->width / 4) * bpb;
+            j.output = output + (int64_t)(y0 / 4) * blocks_across(input->width, dxgi_format) * bpb;
             j.fn = cmpFunc;
+            j.min_height = keeps_partial_blocks(dxgi_format) ? 1 : 4;
             j.pending = true;
         }
         p->outstanding = n;
@@ -184,6 +193,8 @@ bool CompressImageMT(const rgba_surface* input, uint8_t* output, CompressionFunc
 
 void CompressImageBC1(const rgba_surface* input, uint8_t* output) { CompressBlocksBC1(input, output); }
 void CompressImageBC3(const rgba_surface* input, uint8_t* output) { CompressBlocksBC3(input, output); }
+void CompressImageBC4(const rgba_surface* input, uint8_t* output) { CompressBlocksBC4(input, output); }
+void CompressImageBC5(const rgba_surface* input, uint8_t* output) { CompressBlocksBC5(input, output); }
 
 #define ITW_BC7_TRAMPOLINE(profile)                                                    \
     void CompressImageBC7_##profile(const rgba_surface* input, uint8_t* output)        \
@@ -214,7 +225,7 @@ bool itwCompressImageSliced(const rgba_surface* source, uint8_t* target, int64_t
     int slices = (int)(((int64_t)source->width * source->height) / slice_pixels);
     if (slices < 1) slices = 1;
     // the ABI packs block rows tightly; a wider pitch would need one call per block row
-    const int64_t tight = (int64_t)(source->width / 4) * GetBytesPerBlock(dxgi_format);
+    const int64_t tight = (int64_t)blocks_across(source->width, dxgi_format) * GetBytesPerBlock(dxgi_format);
     if (block_row_pitch != tight) {
         std::fprintf(stderr, "itwCompressImageSliced: block_row_pitch %lld != %lld (tight)\n", (long long)block_row_pitch, (long long)tight);
         return false;
@@ -224,6 +235,7 @@ bool itwCompressImageSliced(const rgba_surface* source, uint8_t* target, int64_t
         int ylo = (int)((int64_t)i * source->height / slices) & ~0x3;
         int yhi = (int)((int64_t)(i + 1) * source->height / slices) & ~0x3;
         if (yhi > source->height) yhi = source->height;
+        if (i == slices - 1 && keeps_partial_blocks(dxgi_format)) yhi = source->height;
         if (yhi > ylo) {
             rgba_surface input = *source;
             input.ptr += (int64_t)input.stride * ylo;

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = tuple(
        "itwTestRcp", "itwTestRsqrt", "itwTestF2I"]
     # include/itw_dispatch.h: the reference's dispatch layer (win32Threads.h), slice loop, pad pre-pass
     + ["GetProcessorCount", "InitWin32Threads", "DestroyThreads", "GetBytesPerBlock", "CompressImageMT", "CompressImageST",
-       "CompressImageBC1", "CompressImageBC3"]
+       "CompressImageBC1", "CompressImageBC3", "CompressImageBC4", "CompressImageBC5"]
     + ["CompressImageBC7_" + p for p in BC7_PROFILES] + ["CompressImageBC6H_" + p for p in BC6H_PROFILES]
     + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
        "itwConvertToRGBA8Device", "itwConvertToRGBA16FDevice"]
@@ -55,7 +55,7 @@ class Bc6hSettings(C.Structure):
 
 assert C.sizeof(RgbaSurface) == 24 and C.sizeof(Bc7Settings) == 64 and C.sizeof(Bc6hSettings) == 16
 
-DXGI_FORMAT = {"bc1": 71, "bc1_srgb": 72, "bc3": 77, "bc3_srgb": 78, "bc6h": 95, "bc6h_sf16": 96, "bc7": 98, "bc7_srgb": 99}
+DXGI_FORMAT = {"bc1": 71, "bc1_srgb": 72, "bc3": 77, "bc3_srgb": 78, "bc4": 80, "bc5": 83, "bc6h": 95, "bc6h_sf16": 96, "bc7": 98, "bc7_srgb": 99}
 
 
 class DdsDesc(C.Structure):
@@ -243,7 +243,7 @@ def compress(fmt, img, settings=None, out=None):
 
 def image_func(fmt, profile=None):
     """Address of the CompressImage* trampoline (win32Threads.h:58-80) for a format / profile, as a void*."""
-    name = {"bc1": "CompressImageBC1", "bc3": "CompressImageBC3"}.get(fmt) or \
+    name = {"bc1": "CompressImageBC1", "bc3": "CompressImageBC3", "bc4": "CompressImageBC4", "bc5": "CompressImageBC5"}.get(fmt) or \
         ("CompressImageBC7_" if fmt == "bc7" else "CompressImageBC6H_") + (profile or "slow")
     return C.cast(getattr(lib(), name), C.c_void_p)
 
@@ -253,10 +253,10 @@ def compress_image(fmt, img, profile=None, multithreaded=True, slice_pixels=0, p
     trampoline -> CompressBlocks*.  img: host numpy (H, W, 4) uint8 / uint16 half bits.  Returns (ok, blocks)."""
     import numpy as np
     h, w = img.shape[:2]
-    out = np.zeros((h // 4) * (w // 4) * BYTES_PER_BLOCK[fmt], dtype=np.uint8)
+    out = np.zeros(block_count(fmt, w, h) * BYTES_PER_BLOCK[fmt], dtype=np.uint8)
     surf = RgbaSurface(img.ctypes.data, w, h, img.strides[0])
     cb = PROGRESS_FUNC(progress) if progress else None
-    ok = lib().itwCompressImageSliced(C.byref(surf), out.ctypes.data, (w // 4) * BYTES_PER_BLOCK[fmt], image_func(fmt, profile),
+    ok = lib().itwCompressImageSliced(C.byref(surf), out.ctypes.data, block_count(fmt, w, 4) * BYTES_PER_BLOCK[fmt], image_func(fmt, profile),
                                       DXGI_FORMAT[fmt], multithreaded, slice_pixels, C.cast(cb, C.c_void_p) if cb else None, None)
     return bool(ok), out
 
@@ -295,7 +295,7 @@ def decode(fmt, blocks, width, height, want_modes=False):
     (H, W, 4) uint8 -- uint16 half bit patterns for bc6h -- in the same kind of container, plus the per-block modes
     (int32) when asked."""
     import numpy as np
-    key = {"bc1": 71, "bc3": 77, "bc7": 98, "bc6h": 95}[fmt]
+    key = {"bc1": 71, "bc3": 77, "bc7": 98, "bc6h": 95, "bc4": 80, "bc5": 83}[fmt]
     nb = (width // 4) * (height // 4)
     es = 2 if fmt == "bc6h" else 1
     if isinstance(blocks, np.ndarray):

@@ -177,7 +177,7 @@ void oracle_CompressBlocksBC4(const oracle_surface* src, uint8_t* dst) { compres
 void oracle_CompressBlocksBC5(const oracle_surface* src, uint8_t* dst) { compress(src, dst, 2); }
 
 /* D3DXDecodeBC4U / BC5U (BC4BC5.cpp:373-385, 449-462): 16 floats per channel, raster order */
-void oracle_decode_bc4(const uint8_t blk[8], float out[16])
+void oracle_decode_bc4_float(const uint8_t blk[8], float out[16])
 {
     uint64_t data = 0;
     for (int i = 0; i < 8; i++) data |= (uint64_t)blk[i] << (8 * i);

@@ -61,9 +61,9 @@ static void decode_color_block(const uint8_t blk[8], uint8_t out[64], int allow_
 void oracle_decode_bc1(const uint8_t blk[8], uint8_t out[64]) { decode_color_block(blk, out, 1); }
 
 /* ---- BC3 = interpolated alpha block + BC1 colour block (always 4-colour) ---- */
-void oracle_decode_bc3(const uint8_t blk[16], uint8_t out[64])
+/* the 8-byte interpolated-scalar block of BC3 alpha / BC4 / BC5: value of texel k -> out[k * 4 + channel] */
+static void decode_scalar_block(const uint8_t blk[8], uint8_t out[64], int channel)
 {
-    decode_color_block(blk + 8, out, 0);
     int a[8];
     a[0] = blk[0]; a[1] = blk[1];
     if (a[0] > a[1]) {
@@ -74,7 +74,26 @@ void oracle_decode_bc3(const uint8_t blk[16], uint8_t out[64])
     }
     uint64_t bits = 0;
     for (int i = 0; i < 6; i++) bits |= (uint64_t)blk[2 + i] << (8 * i);
-    for (int k = 0; k < 16; k++) out[k * 4 + 3] = (uint8_t)a[(bits >> (3 * k)) & 7];
+    for (int k = 0; k < 16; k++) out[k * 4 + channel] = (uint8_t)a[(bits >> (3 * k)) & 7];
+}
+
+void oracle_decode_bc3(const uint8_t blk[16], uint8_t out[64])
+{
+    decode_color_block(blk + 8, out, 0);
+    decode_scalar_block(blk, out, 3);
+}
+
+/* ---- BC4_UNORM / BC5_UNORM to RGBA8: (R, 0, 0, 255) / (R, G, 0, 255), 8-bit values by the integer definition ---- */
+void oracle_decode_bc4_rgba8(const uint8_t blk[8], uint8_t out[64])
+{
+    for (int k = 0; k < 16; k++) { out[k * 4] = out[k * 4 + 1] = out[k * 4 + 2] = 0; out[k * 4 + 3] = 255; }
+    decode_scalar_block(blk, out, 0);
+}
+
+void oracle_decode_bc5_rgba8(const uint8_t blk[16], uint8_t out[64])
+{
+    oracle_decode_bc4_rgba8(blk, out);
+    decode_scalar_block(blk + 8, out, 1);
 }
 
 /* ---- BC7 ---- */

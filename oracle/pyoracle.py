@@ -69,11 +69,11 @@ def lib():
             if hasattr(L, n):
                 getattr(L, n).argtypes = [C.c_char_p, C.c_void_p]
                 getattr(L, n).restype = C.c_int
-        for n in ("oracle_decode_bc1", "oracle_decode_bc3", "oracle_decode_bc7", "oracle_decode_bc6h"):
+        for n in ("oracle_decode_bc1", "oracle_decode_bc3", "oracle_decode_bc7", "oracle_decode_bc6h", "oracle_decode_bc4_rgba8", "oracle_decode_bc5_rgba8"):
             if hasattr(L, n):
                 getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
                 getattr(L, n).restype = C.c_int
-        for n in ("oracle_CompressBlocksBC4", "oracle_CompressBlocksBC5", "oracle_bc4_block", "oracle_decode_bc4"):
+        for n in ("oracle_CompressBlocksBC4", "oracle_CompressBlocksBC5", "oracle_bc4_block", "oracle_decode_bc4_float"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
             getattr(L, n).restype = None
         _lib = L
@@ -173,7 +173,7 @@ def decode_bc45(fmt, blocks, width, height):
     for y in range(by):
         for x in range(bx):
             for c in range(nch):
-                L.oracle_decode_bc4(blocks[y, x, c].ctypes.data_as(C.c_void_p), out[y, x, c].ctypes.data_as(C.c_void_p))
+                L.oracle_decode_bc4_float(blocks[y, x, c].ctypes.data_as(C.c_void_p), out[y, x, c].ctypes.data_as(C.c_void_p))
     return out.reshape(by, bx, nch, 4, 4).transpose(0, 3, 1, 4, 2).reshape(by * 4, bx * 4, nch)
 
 
@@ -215,7 +215,7 @@ def encode_mt(fmt, img, profile=None, threads=None):
 def decode(fmt, blocks, width, height):
     """From-spec decode of a tightly packed block stream -> (H, W, 4) uint8, or (H, W, 3) uint16 for bc6h."""
     L = lib()
-    bpb = 8 if fmt == "bc1" else 16
+    bpb = 8 if fmt in ("bc1", "bc4") else 16
     bx, by = width // 4, height // 4
     blocks = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(by * bx, bpb)
     if fmt == "bc6h":
@@ -231,7 +231,8 @@ def decode(fmt, blocks, width, height):
     out = np.zeros((by * 4, bx * 4, 4), dtype=np.uint8)
     tmp = (C.c_uint8 * 64)()
     modes = np.zeros(by * bx, dtype=np.int32)
-    fn = {"bc1": L.oracle_decode_bc1, "bc3": L.oracle_decode_bc3, "bc7": L.oracle_decode_bc7}[fmt]
+    fn = {"bc1": L.oracle_decode_bc1, "bc3": L.oracle_decode_bc3, "bc7": L.oracle_decode_bc7,
+          "bc4": L.oracle_decode_bc4_rgba8, "bc5": L.oracle_decode_bc5_rgba8}[fmt]
     fn.restype = C.c_int
     for i in range(by * bx):
         r = fn(blocks[i].ctypes.data_as(C.c_void_p), tmp)

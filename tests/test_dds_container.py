@@ -21,7 +21,7 @@ def _words(buf):
 
 
 def test_legacy_fourcc_headers(itw):
-    for key, cc, bpb in (("bc1", b"DXT1", 8), ("bc3", b"DXT5", 16)):
+    for key, cc, bpb in (("bc1", b"DXT1", 8), ("bc3", b"DXT5", 16), ("bc4", b"BC4U", 8), ("bc5", b"BC5U", 16)):   # DDS.h:71-90
         d, buf = _hdr(itw, key, 4096, 4096)
         assert buf.size == 128
         w = _words(buf)
@@ -101,3 +101,19 @@ def test_golden_blocks_as_dds(itw, golden_blocks, golden_inputs):
     blocks = golden_blocks[key]
     f = itw.dds_file("bc1", 256, 256, [blocks])
     assert f.size == 128 + blocks.size and np.array_equal(f[128:], blocks.reshape(-1))
+
+
+def test_bc4_bc5_legacy_fourcc_read_both_spellings(itw):
+    """DirectXTex writes 'BC4U' / 'BC5U' (DDS.h:83-90) and also accepts the older 'ATI1' / 'ATI2' (DirectXTexDDS.cpp:64-70)."""
+    import os
+    g = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_bc45.npz")))
+    blocks = g["monkey_crop.bc5"]                                      # 217 x 215 texels -> 55 x 54 blocks
+    f = itw.dds_file("bc5", 215, 217, [blocks])
+    assert f.size == 128 + 54 * 55 * 16 and np.array_equal(f[128:], blocks)
+    d = itw.DdsDesc()
+    assert itw.lib().itwDdsReadHeader(f.ctypes.data, f.size, C.byref(d)) == 128
+    assert (d.width, d.height, d.mip_levels, d.dxgi_format) == (215, 217, 1, 83)
+    for cc, fmt in ((b"ATI1", 80), (b"ATI2", 83), (b"BC4U", 80)):
+        alt = f.copy()
+        alt[84:88] = np.frombuffer(cc, dtype=np.uint8)                 # ddspf.dwFourCC
+        assert itw.lib().itwDdsReadHeader(alt.ctypes.data, alt.size, C.byref(d)) == 128 and d.dxgi_format == fmt

@@ -10,6 +10,7 @@ import pytest
 def test_bytes_per_block_and_worker_count(itw):
     L = itw.lib()
     assert [L.GetBytesPerBlock(f) for f in (71, 72, 77, 78, 95, 96, 98, 99, 0, 28)] == [8, 8, 16, 16, 16, 16, 16, 16, 8, 8]
+    assert [L.GetBytesPerBlock(f) for f in (80, 83)] == [8, 16]      # BC4 (the reference's default), BC5 (extension)
     assert L.GetProcessorCount() >= 1                        # "1 or more" (win32Threads.h:51)
 
 
@@ -39,11 +40,12 @@ def test_trampolines_equal_direct_calls_and_oracle(itw, gpu, oracle):
     from itw_amd import surfaces
     ldr = surfaces.ldr_smooth(64, 96)
     hdr = surfaces.hdr_smooth(32, 64)
+    odd = np.ascontiguousarray(ldr[:61, :90])                 # the DirectXTex formats keep partial blocks
     cases = [("bc1", ldr, None), ("bc3", ldr, None)] + [("bc7", ldr, p) for p in itw.BC7_PROFILES] \
-        + [("bc6h", hdr, p) for p in itw.BC6H_PROFILES]
+        + [("bc6h", hdr, p) for p in itw.BC6H_PROFILES] + [("bc4", ldr, None), ("bc5", ldr, None), ("bc4", odd, None), ("bc5", odd, None)]
     for fmt, img, prof in cases:
         h, w = img.shape[:2]
-        out = np.zeros((h // 4) * (w // 4) * itw.BYTES_PER_BLOCK[fmt], dtype=np.uint8)
+        out = np.zeros(itw.block_count(fmt, w, h) * itw.BYTES_PER_BLOCK[fmt], dtype=np.uint8)
         surf = itw.RgbaSurface(img.ctypes.data, w, h, img.strides[0])
         fn = itw.image_func(fmt, prof)
         for entry in ("CompressImageMT", "CompressImageST"):
@@ -70,6 +72,9 @@ def test_slice_loop_progress_and_abort(itw, gpu, oracle):
     assert np.array_equal(out[:done], want[:done]) and not out[done:].any()
     ok, out = itw.compress_image("bc1", img)                  # default slice size: one slice, no callback needed
     assert ok and np.array_equal(out, oracle.encode("bc1", img).reshape(-1))
+    odd = np.ascontiguousarray(img[:126, :61])                # BC5, partial last block row / column, 3 slices
+    ok, out = itw.compress_image("bc5", odd, slice_pixels=2048, progress=lambda i, n, u: True)
+    assert ok and np.array_equal(out, oracle.encode("bc5", odd).reshape(-1))
 
 
 @pytest.mark.gpu
@@ -119,9 +124,11 @@ from itw_amd import surfaces
 from oracle import pyoracle
 L = itw_amd.lib()
 assert L.GetProcessorCount() == 8
-for h, w, fmt, prof in ((100, 64, "bc1", None), (36, 32, "bc3", None), (256, 64, "bc7", "veryfast"), (8, 16, "bc7", "alpha_basic"), (64, 32, "bc6h", "fast")):
-    img = surfaces.hdr_smooth(h, w) if fmt == "bc6h" else surfaces.ldr_smooth(h, w)
-    out = np.zeros((h // 4) * (w // 4) * itw_amd.BYTES_PER_BLOCK[fmt], dtype=np.uint8)
+for h, w, fmt, prof in ((100, 64, "bc1", None), (36, 32, "bc3", None), (256, 64, "bc7", "veryfast"), (8, 16, "bc7", "alpha_basic"), (64, 32, "bc6h", "fast"),
+                        (102, 63, "bc4", None), (35, 30, "bc5", None), (3, 5, "bc5", None)):
+    H, W = (h + 3) // 4 * 4, (w + 3) // 4 * 4
+    img = surfaces.hdr_smooth(h, w) if fmt == "bc6h" else np.ascontiguousarray(surfaces.ldr_smooth(H, W)[:h, :w])
+    out = np.zeros(itw_amd.block_count(fmt, w, h) * itw_amd.BYTES_PER_BLOCK[fmt], dtype=np.uint8)
     surf = itw_amd.RgbaSurface(img.ctypes.data, w, h, img.strides[0])
     for rep in range(3):
         out[:] = 0
