@@ -257,6 +257,19 @@ def main():
                 del d2, o2
             except Exception as e:  # a format whose kernel is not built yet aborts in C; anything else lands here
                 side[wl] = {"error": repr(e)}
+        if size == 4096:
+            # SURVEY 8(d) input I2: the reference's colors-16M.png (regenerated by formula), same 4096^2 block count
+            try:
+                from itw_amd import surfaces
+                d2 = torch.from_numpy(surfaces.colors_16m()).to(dev)
+                o2 = torch.empty(nblocks * 16, dtype=torch.uint8, device=dev)
+                for wl in ("bc1", "bc7_slow"):
+                    f2, p2 = WORKLOADS[wl]
+                    avg, mn = time_kernel(itw_amd, f2, p2, d2, o2, steps=3 if f2 == "bc7" else 20, warmup=1)
+                    side[wl + "@colors16m"] = {"Mpixels/s": round(size * size / (avg * 1e-3) / 1e6, 1), "kernel_ms_avg": round(avg, 4)}
+                del d2, o2
+            except Exception as e:
+                side["@colors16m"] = {"error": repr(e)}
         result["formats"] = side
 
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -106,6 +106,23 @@ def hdr_random_bits(h, w, seed=SEED + 4):
     return rng.integers(0, 65536, size=(h, w, 4), dtype=np.uint16)
 
 
+COLORS_16M_SHA256 = "734d23cb367afaf0a40f4d4bcfc47088f0af7eb0d85109ee1c5809bd01dd9e85"   # sha256 of colors_16m(); equals the decoded PNG
+
+
+def colors_16m(size=4096):
+    """I2 of SURVEY.md 8d without the file: the reference's `Sample Images/colors-16M.png` (4096 x 4096, every 24-bit
+    colour once) is R = x mod 256, G = y mod 256, B = 16 * (y div 256) + (x div 256); alpha = 255 as the plugin's
+    RGB -> RGBA8 conversion fills it (IntelPlugin.cpp:741-766).  tests/test_oracle_bc1_bc3.py checks this formula
+    against the PNG when the reference tree is present.  `size` < 4096 returns the top-left crop."""
+    y, x = np.mgrid[0:size, 0:size]
+    img = np.empty((size, size, 4), dtype=np.uint8)
+    img[..., 0] = x % 256
+    img[..., 1] = y % 256
+    img[..., 2] = 16 * (y // 256) + x // 256
+    img[..., 3] = 255
+    return img
+
+
 def tile_to(img, h, w):
     """Tile `img` up to (h, w) and crop."""
     ry = -(-h // img.shape[0])
