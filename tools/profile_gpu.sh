@@ -9,17 +9,17 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-KERNELS='bc7_search_kernel|bc7_finish_kernel|bc13_kernel|bc6h_'
+KERNELS='bc7_search_kernel|bc7_finish_kernel|bc13_kernel|bc6h_|bc45_kernel'
 
 # 1. kernel trace + stats of the same command the driver runs
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 find $OUT/trace -name '*kernel_stats*.csv' -exec cp {} $OUT/kernel_stats.csv \;
-find $OUT/trace -name '*kernel_trace*.csv' | head -1 | xargs -I{} sh -c "head -1 {} > $OUT/kernel_trace_head.csv; grep -m8 bc7_ {} >> $OUT/kernel_trace_head.csv; grep -m3 bc13_kernel {} >> $OUT/kernel_trace_head.csv; grep -m3 bc6h_ {} >> $OUT/kernel_trace_head.csv"
+find $OUT/trace -name '*kernel_trace*.csv' | head -1 | xargs -I{} sh -c "head -1 {} > $OUT/kernel_trace_head.csv; grep -m8 bc7_ {} >> $OUT/kernel_trace_head.csv; grep -m3 bc13_kernel {} >> $OUT/kernel_trace_head.csv; grep -m3 bc6h_ {} >> $OUT/kernel_trace_head.csv; grep -m3 bc45_ {} >> $OUT/kernel_trace_head.csv"
 rm -rf $OUT/trace
 
 # 2. PMC passes, one counter group per run, short workloads
-for wl in bc1 bc3 bc7_slow bc6h_slow; do
-  steps=3; [ "$wl" = bc1 -o "$wl" = bc3 ] && steps=10
+for wl in bc1 bc3 bc4 bc5 bc7_slow bc6h_slow; do
+  steps=3; case $wl in bc1|bc3|bc4|bc5) steps=10;; esac
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${wl}_$ctr -o pmc -- python $ROOT/bench.py --workload $wl --no-formats --no-cpu --steps $steps --warmup 1 > /dev/null 2> $OUT/pmc_${wl}_$ctr.log
     f=$(find $OUT/pmc_${wl}_$ctr -name '*counter_collection*.csv' | head -1)

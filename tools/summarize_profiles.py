@@ -36,7 +36,7 @@ def main():
         if name.endswith((".csv", ".json")):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
     traffic = {}
-    for wl in ("bc1", "bc3", "bc7_slow", "bc6h_slow"):
+    for wl in ("bc1", "bc3", "bc4", "bc5", "bc7_slow", "bc6h_slow"):
         f = os.path.join(src, f"pmc_{wl}_FETCH_SIZE.csv")
         w = os.path.join(src, f"pmc_{wl}_WRITE_SIZE.csv")
         if not (os.path.exists(f) and os.path.exists(w)):
