@@ -142,3 +142,37 @@ print("ok")
     r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "intel-texture-works-plugin_amd"))],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_legacy_call_granularity_64_workers(gpu, oracle):
+    """What the unmodified plugin does on a 64-thread host (hard part 4): 0x40000-pixel slices
+    (IntelPlugin.cpp:851) each cut into 64 bands (win32Threads.cpp:217) -> host-pointer calls of ~4 k pixels from 64
+    threads at once, all landing on one device.  Streams, staging buffers and the BC7 workspace are per host thread."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import itw_amd
+from itw_amd import surfaces
+from oracle import pyoracle
+assert itw_amd.lib().GetProcessorCount() == 64
+img = surfaces.ldr_smooth(1024, 1024)                      # 4 slices x 64 bands of 4 rows
+for fmt, prof in (("bc1", None), ("bc7", "veryfast"), ("bc7", "alpha_basic"), ("bc5", None)):
+    calls = []
+    ok, out = itw_amd.compress_image(fmt, img, prof, multithreaded=True, slice_pixels=0, progress=lambda i, n, u: calls.append(n) or True)
+    assert ok and calls == [4, 4, 4]
+    assert np.array_equal(out, pyoracle.encode_mt(fmt, img, prof).reshape(-1)), (fmt, prof)
+hdr = surfaces.hdr_smooth(512, 512)
+ok, out = itw_amd.compress_image("bc6h", hdr, "basic")
+assert ok and np.array_equal(out, pyoracle.encode_mt("bc6h", hdr, "basic").reshape(-1))
+itw_amd.lib().DestroyThreads()
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ITW_WORKERS="64")
+    r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "intel-texture-works-plugin_amd"))],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
