@@ -62,3 +62,42 @@ def encode_sharded(fmt, surface, settings=None, group=None, encode=None):
     local, _, _ = encode_band(fmt, surface, settings, rank, world, encode)
     h, w = surface.shape[:2]
     return gather_bands(local, w, h, fmt, group)
+
+
+class BandPipeline:
+    """Steady state of a sharded encoder: every step this rank encodes its band and the bands are all-gathered, with
+    the gather of step i overlapped with the encode of step i+1.  Two (depth) whole-image buffers alternate; the
+    collective is launched asynchronously (RCCL runs it on its own stream after the encode it depends on) and is only
+    waited for when its buffer comes round again, or in drain().  The band is encoded in place at its offset of the
+    whole-image buffer, so the all-gather is NCCL's in-place form (send = recv + rank * count) and nothing is copied.
+
+    encode_into(out_band) launches / performs the encode of this rank's band into `out_band` (a uint8 view)."""
+
+    def __init__(self, band_bytes, world, rank, device, encode_into, group=None, depth=2):
+        import torch
+        self.world, self.rank, self.group, self.depth = world, rank, group, depth
+        self.encode_into = encode_into
+        self.full = [torch.empty(world * band_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.band = [f[rank * band_bytes:(rank + 1) * band_bytes] for f in self.full]
+        self.work = [None] * depth
+        self.steps = 0
+
+    def step(self):
+        """Encode + start the gather; returns the index of the buffer that will hold this step's whole image."""
+        b = self.steps % self.depth
+        self.steps += 1
+        if self.work[b] is not None:                 # the gather that last used this buffer must be done with it
+            self.work[b].wait()
+            self.work[b] = None
+        self.encode_into(self.band[b])
+        if self.world > 1:
+            import torch.distributed as dist
+            self.work[b] = dist.all_gather_into_tensor(self.full[b], self.band[b], group=self.group, async_op=True)
+        return b
+
+    def drain(self):
+        """Wait for every gather in flight (stream-level on GPUs: follow with a device synchronize to read on the host)."""
+        for b in range(self.depth):
+            if self.work[b] is not None:
+                self.work[b].wait()
+                self.work[b] = None

@@ -60,3 +60,56 @@ def test_band_sharding_and_gather(world, fmt, prof, h, w):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert len({n for _, _, n in res}) == 1
+
+
+def _pipeline_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "intel-texture-works-plugin_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from itw_amd import shard
+    nbytes = 4096
+    state = {"step": 0}
+
+    def encode_into(out):                          # stands in for the HIP encode: content depends on (rank, step)
+        out.copy_(torch.full((nbytes,), (17 * state["step"] + 3 * rank + 1) % 256, dtype=torch.uint8))
+
+    pipe = shard.BandPipeline(nbytes, world, rank, torch.device("cpu"), encode_into)
+    ok = True
+    history = []
+    for step in range(7):
+        state["step"] = step
+        history.append((step, pipe.step()))
+        if step >= 1:                              # the previous step's image is complete once its gather is waited for
+            ps, pb = history[-2]
+            if pipe.work[pb] is not None:
+                pipe.work[pb].wait()
+                pipe.work[pb] = None
+            want = torch.cat([torch.full((nbytes,), (17 * ps + 3 * r + 1) % 256, dtype=torch.uint8) for r in range(world)])
+            ok = ok and bool((pipe.full[pb] == want).all())
+    pipe.drain()
+    ps, pb = history[-1]
+    want = torch.cat([torch.full((nbytes,), (17 * ps + 3 * r + 1) % 256, dtype=torch.uint8) for r in range(world)])
+    ok = ok and bool((pipe.full[pb] == want).all()) and all(w is None for w in pipe.work)
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_gather_double_buffering(world):
+    """bench.py --gpus N overlaps the all-gather of step i with the encode of step i+1 (shard.BandPipeline); here the same
+    object over gloo: every step's whole image is exactly the bands of that step, buffers alternate, nothing is left in flight."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
