@@ -158,8 +158,15 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst)
         // tight staging pitch, 16-byte aligned rows so the vector load path applies
         const size_t pitch = (row_bytes + 15) & ~(size_t)15;
         uint8_t* in = (uint8_t*)grow(tls.d_in, tls.in_cap, pitch * rows);
-        ITW_CHECK(hipMemcpy2DAsync(in, pitch, src->ptr, (size_t)src->stride, row_bytes, rows,
-                                   hipMemcpyHostToDevice, st));
+        if ((int64_t)src->stride >= (int64_t)row_bytes) {
+            ITW_CHECK(hipMemcpy2DAsync(in, pitch, src->ptr, (size_t)src->stride, row_bytes, rows,
+                                       hipMemcpyHostToDevice, st));
+        } else {
+            // bottom-up (negative stride) or overlapping rows: the reference just indexes ptr + y*stride with a signed
+            // stride (kernel.ispc:105-151), which a pitched copy cannot express -- stage row by row
+            for (size_t y = 0; y < rows; y++)
+                ITW_CHECK(hipMemcpyAsync(in + y * pitch, src->ptr + (int64_t)y * src->stride, row_bytes, hipMemcpyHostToDevice, st));
+        }
         d_src = in; d_stride = (int64_t)pitch;
     } else if (tls.user_stream != st) {
         // producer of the device surface may still be running on the caller's stream

@@ -123,3 +123,32 @@ def test_concurrent_host_threads(itw, gpu, oracle):
     for off, blk in res:
         got[off:off + blk.size] = blk
     assert (got == want).all()
+
+
+def test_bottom_up_and_repeated_rows(itw, gpu, oracle):
+    """`stride` is a signed int the reference simply multiplies by y (kernel.ispc:105-151): a negative stride walks a
+    bottom-up image, stride 0 repeats one row.  Host pointers (staged row by row) and device pointers alike."""
+    import ctypes as C
+    import torch
+    from itw_amd import surfaces
+    img = surfaces.ldr_smooth(64, 96)
+    flipped = np.ascontiguousarray(img[::-1])
+    want = oracle.encode("bc3", flipped)
+    out = np.zeros(want.size, dtype=np.uint8)
+    last_row = img.ctypes.data + 63 * img.strides[0]
+    surf = itw.RgbaSurface(last_row, 96, 64, -img.strides[0])
+    itw.lib().CompressBlocksBC3(C.byref(surf), out.ctypes.data)
+    assert first_mismatch(out, want, 16) is None, first_mismatch(out, want, 16)
+    d = torch.from_numpy(img).to(gpu)
+    d_out = torch.zeros(want.size, dtype=torch.uint8, device=gpu)
+    itw.lib().itwSetStream(torch.cuda.current_stream().cuda_stream)
+    surf = itw.RgbaSurface(d.data_ptr() + 63 * 96 * 4, 96, 64, -96 * 4)
+    itw.lib().CompressBlocksBC3(C.byref(surf), d_out.data_ptr())
+    torch.cuda.synchronize()
+    assert first_mismatch(d_out.cpu().numpy(), want, 16) is None
+    same = np.ascontiguousarray(np.broadcast_to(img[5:6], (8, 96, 4)))
+    want = oracle.encode("bc1", same)
+    out = np.zeros(want.size, dtype=np.uint8)
+    surf = itw.RgbaSurface(img.ctypes.data + 5 * img.strides[0], 96, 8, 0)
+    itw.lib().CompressBlocksBC1(C.byref(surf), out.ctypes.data)
+    assert first_mismatch(out, want, 8) is None
