@@ -32,7 +32,9 @@ namespace {
 // calls independent without a lock.
 struct ThreadCtx {
     hipStream_t user_stream = nullptr;     // itwSetStream
-    hipStream_t own_stream  = nullptr;     // staging path
+    hipStream_t own_stream  = nullptr;     // staging path: kernels (and the copies of single-chunk calls)
+    hipStream_t copy_stream = nullptr;     // staging path: copies of chunked calls, overlapped with own_stream
+    hipEvent_t  ev_in[8] = {}, ev_done[8] = {};
     void*  d_in = nullptr;  size_t in_cap = 0;
     void*  d_out = nullptr; size_t out_cap = 0;
     void*  d_ws = nullptr;  size_t ws_cap = 0;      // BC7 inter-family workspace
@@ -45,6 +47,9 @@ struct ThreadCtx {
         if (d_out) (void)hipFree(d_out);
         if (d_ws)  (void)hipFree(d_ws);
         if (own_stream) (void)hipStreamDestroy(own_stream);
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        for (auto e : ev_in) if (e) (void)hipEventDestroy(e);
+        for (auto e : ev_done) if (e) (void)hipEventDestroy(e);
     }
 };
 thread_local ThreadCtx tls;
@@ -59,9 +64,15 @@ void ensure_device_ctx()
         if (tls.d_out) { (void)hipFree(tls.d_out); tls.d_out = nullptr; tls.out_cap = 0; }
         if (tls.d_ws)  { (void)hipFree(tls.d_ws);  tls.d_ws = nullptr;  tls.ws_cap = 0; tls.ws_used = false; }
         if (tls.own_stream) { (void)hipStreamDestroy(tls.own_stream); tls.own_stream = nullptr; }
+        if (tls.copy_stream) { (void)hipStreamDestroy(tls.copy_stream); tls.copy_stream = nullptr; }
+        for (auto& e : tls.ev_in) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (auto& e : tls.ev_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         tls.device = dev;
     }
     if (!tls.own_stream) ITW_CHECK(hipStreamCreateWithFlags(&tls.own_stream, hipStreamNonBlocking));
+    if (!tls.copy_stream) ITW_CHECK(hipStreamCreateWithFlags(&tls.copy_stream, hipStreamNonBlocking));
+    for (auto& e : tls.ev_in) if (!e) ITW_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : tls.ev_done) if (!e) ITW_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 }
 
 void* grow(void*& buf, size_t& cap, size_t need)
@@ -103,6 +114,9 @@ float* bc7_workspace(int w, int h, hipStream_t st)
         if (tls.d_out) { (void)hipFree(tls.d_out); tls.d_out = nullptr; tls.out_cap = 0; }
         if (tls.d_ws)  { (void)hipFree(tls.d_ws);  tls.d_ws = nullptr;  tls.ws_cap = 0; tls.ws_used = false; }
         if (tls.own_stream) { (void)hipStreamDestroy(tls.own_stream); tls.own_stream = nullptr; }
+        if (tls.copy_stream) { (void)hipStreamDestroy(tls.copy_stream); tls.copy_stream = nullptr; }
+        for (auto& e : tls.ev_in) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (auto& e : tls.ev_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         tls.device = dev;
     }
     if (tls.ws_used && tls.ws_stream != st) ITW_CHECK(hipStreamSynchronize(tls.ws_stream));
@@ -151,30 +165,76 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst)
     }
 
     ensure_device_ctx();
-    hipStream_t st = tls.own_stream;
-    const uint8_t* d_src = src->ptr;
-    int64_t d_stride = src->stride;
-    if (!src_dev) {
-        // tight staging pitch, 16-byte aligned rows so the vector load path applies
-        const size_t pitch = (row_bytes + 15) & ~(size_t)15;
-        uint8_t* in = (uint8_t*)grow(tls.d_in, tls.in_cap, pitch * rows);
-        if ((int64_t)src->stride >= (int64_t)row_bytes) {
-            ITW_CHECK(hipMemcpy2DAsync(in, pitch, src->ptr, (size_t)src->stride, row_bytes, rows,
-                                       hipMemcpyHostToDevice, st));
-        } else {
-            // bottom-up (negative stride) or overlapping rows: the reference just indexes ptr + y*stride with a signed
-            // stride (kernel.ispc:105-151), which a pitched copy cannot express -- stage row by row
-            for (size_t y = 0; y < rows; y++)
-                ITW_CHECK(hipMemcpyAsync(in + y * pitch, src->ptr + (int64_t)y * src->stride, row_bytes, hipMemcpyHostToDevice, st));
-        }
-        d_src = in; d_stride = (int64_t)pitch;
-    } else if (tls.user_stream != st) {
+    hipStream_t st = tls.own_stream, cs = tls.copy_stream;
+    if (src_dev && tls.user_stream != st) {
         // producer of the device surface may still be running on the caller's stream
         ITW_CHECK(hipStreamSynchronize(tls.user_stream));
     }
+    // tight staging pitch, 16-byte aligned rows so the vector load path applies
+    const size_t pitch = (row_bytes + 15) & ~(size_t)15;
+    uint8_t* in = src_dev ? nullptr : (uint8_t*)grow(tls.d_in, tls.in_cap, pitch * rows);
+    const uint8_t* d_src = src_dev ? src->ptr : in;
+    const int64_t d_stride = src_dev ? (int64_t)src->stride : (int64_t)pitch;
     uint8_t* d_dst = dst_dev ? dst : (uint8_t*)grow(tls.d_out, tls.out_cap, out_bytes);
-    launch(j, d_src, d_stride, w, h, d_dst, st);
-    if (!dst_dev) ITW_CHECK(hipMemcpyAsync(dst, d_dst, out_bytes, hipMemcpyDeviceToHost, st));
+
+    // BC7 / BC6H spend milliseconds per surface: cut the call into runs of block rows so that the upload of run c+1 and
+    // the download of run c-1 (copy stream; a pageable copy blocks only this host thread) overlap the kernels of run c.
+    // A run must still fill the chip several times over (one block per lane: 1024 workgroups = one round of the BC7
+    // scans), or the kernels' tails cost more than the copies save -- measured at 4096^2 (tools/host_chunks_probe.py):
+    // BC7 slow 9.58 / 9.19 / 9.60 / 11.6 ms for 1 / 2 / 4 / 8 runs, BC6H slow 7.61 / 6.15 / 5.64 / 5.57 ms.
+    // The first run is the largest, so the BC7 workspace is sized once.  BC1/3/4/5 are PCIe-bound: one run.
+    int nch = 1;
+    if (!src_dev && (j.fmt == Fmt::BC7 || j.fmt == Fmt::BC6H)) {
+        const int min_rows = (j.fmt == Fmt::BC7) ? 512 : 256;     // block rows per run
+        nch = by / min_rows;
+        nch = nch < 1 ? 1 : (nch > 4 ? 4 : nch);
+    }
+    if (const char* e = std::getenv("ITW_HOST_CHUNKS")) {         // tuning / test knob (1..8 runs); 1 disables the overlap
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 8 && !src_dev && by >= 4 * v) nch = v;
+    }
+    const int cb = (by + nch - 1) / nch;
+    hipStream_t copy = (nch > 1) ? cs : st;
+    int c = 0;
+    for (int row0 = 0; row0 < by; row0 += cb, c++) {
+        const int nb = (by - row0 < cb) ? by - row0 : cb;
+        const size_t y0 = (size_t)row0 * 4;
+        const size_t nrows = (rows - y0 < (size_t)nb * 4) ? rows - y0 : (size_t)nb * 4;
+        if (!src_dev) {
+            const uint8_t* hs = src->ptr + (int64_t)y0 * src->stride;
+            if ((int64_t)src->stride >= (int64_t)row_bytes) {
+                ITW_CHECK(hipMemcpy2DAsync(in + y0 * pitch, pitch, hs, (size_t)src->stride, row_bytes, nrows, hipMemcpyHostToDevice, copy));
+            } else {
+                // bottom-up (negative stride) or overlapping rows: the reference just indexes ptr + y*stride with a
+                // signed stride (kernel.ispc:105-151), which a pitched copy cannot express -- stage row by row
+                for (size_t y = 0; y < nrows; y++)
+                    ITW_CHECK(hipMemcpyAsync(in + (y0 + y) * pitch, hs + (int64_t)y * src->stride, row_bytes, hipMemcpyHostToDevice, copy));
+            }
+            if (nch > 1) {
+                ITW_CHECK(hipEventRecord(tls.ev_in[c], cs));
+                ITW_CHECK(hipStreamWaitEvent(st, tls.ev_in[c], 0));
+            }
+        }
+        launch(j, d_src + (int64_t)y0 * d_stride, d_stride, w, (int)nrows, d_dst + (size_t)row0 * bx * bpb, st);
+        if (!dst_dev && nch > 1) {
+            ITW_CHECK(hipEventRecord(tls.ev_done[c], st));
+            if (c > 0) {                               // download the previous run while this one computes
+                const size_t off = (size_t)(row0 - cb) * bx * bpb, len = (size_t)cb * bx * bpb;
+                ITW_CHECK(hipStreamWaitEvent(cs, tls.ev_done[c - 1], 0));
+                ITW_CHECK(hipMemcpyAsync(dst + off, d_dst + off, len, hipMemcpyDeviceToHost, cs));
+            }
+        }
+    }
+    if (!dst_dev) {
+        if (nch > 1) {
+            const size_t off = (size_t)(c - 1) * cb * bx * bpb;
+            ITW_CHECK(hipStreamWaitEvent(cs, tls.ev_done[c - 1], 0));
+            ITW_CHECK(hipMemcpyAsync(dst + off, d_dst + off, out_bytes - off, hipMemcpyDeviceToHost, cs));
+            ITW_CHECK(hipStreamSynchronize(cs));
+        } else {
+            ITW_CHECK(hipMemcpyAsync(dst, d_dst, out_bytes, hipMemcpyDeviceToHost, st));
+        }
+    }
     ITW_CHECK(hipStreamSynchronize(st));
 }
 

@@ -176,3 +176,42 @@ def test_band_of_the_16k_configuration(itw, gpu):
     for ty in range(4):
         for tx in range(32):
             assert (got[ty * 128:(ty + 1) * 128, tx * 128:(tx + 1) * 128] == tile).all(), (ty, tx)
+
+
+@pytest.mark.parametrize("fmt,prof", [("bc7", "veryfast"), ("bc7", "alpha_basic"), ("bc6h", "fast")])
+def test_host_pointers_chunked_overlap(itw, gpu, oracle, fmt, prof):
+    """Large host-pointer calls of BC7 / BC6H are cut into runs of block rows whose uploads / downloads overlap the kernels
+    (abi.hip compress(); 512 / 256 block rows per run by default, forced to four runs here with ITW_HOST_CHUNKS): unequal
+    last run (130 and 131 block rows), pitched rows, a bottom-up (negative-stride) surface, and a device destination
+    with a host source."""
+    import ctypes as C
+    import os
+    import torch
+    from itw_amd import surfaces
+    os.environ["ITW_HOST_CHUNKS"] = "4"
+    try:
+        _chunked_cases(itw, gpu, oracle, fmt, prof, C, torch, surfaces)
+    finally:
+        del os.environ["ITW_HOST_CHUNKS"]
+
+
+def _chunked_cases(itw, gpu, oracle, fmt, prof, C, torch, surfaces):
+    for h, w in ((520, 64), (524, 36)):
+        img = surfaces.hdr_smooth(h, w) if fmt == "bc6h" else surfaces.ldr_smooth(h, w)
+        want = oracle.encode(fmt, img, prof)
+        assert first_mismatch(itw.compress_numpy(fmt, img, prof), want, 16) is None, (h, w)
+        wide = np.zeros((h, w + 5, 4), img.dtype)
+        wide[:, 2:w + 2] = img
+        assert first_mismatch(itw.compress_numpy(fmt, wide[:, 2:w + 2], prof), want, 16) is None, (h, w, "pitched")
+    flipped = np.ascontiguousarray(img[::-1])
+    want = oracle.encode(fmt, flipped, prof)
+    out = np.zeros(want.size, dtype=np.uint8)
+    surf = itw.RgbaSurface(img.ctypes.data + (h - 1) * img.strides[0], w, h, -img.strides[0])
+    st = itw.bc6h_profile(prof) if fmt == "bc6h" else itw.bc7_profile(prof)
+    fn = itw.lib().CompressBlocksBC6H if fmt == "bc6h" else itw.lib().CompressBlocksBC7
+    fn(C.byref(surf), out.ctypes.data, C.byref(st))
+    assert first_mismatch(out, want, 16) is None, "bottom-up"
+    d_out = torch.zeros(want.size, dtype=torch.uint8, device=gpu)          # host source, device destination
+    fn(C.byref(surf), d_out.data_ptr(), C.byref(st))
+    torch.cuda.synchronize()
+    assert first_mismatch(d_out.cpu().numpy(), want, 16) is None, "host -> device"
