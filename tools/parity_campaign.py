@@ -33,7 +33,7 @@ def mixed_hdr(h, w):
     b = rng.integers(0, 65536, size=(h - q, w, 4), dtype=np.uint16)     # NaN / inf / negative halves included
     return np.ascontiguousarray(np.concatenate([a, b], axis=0))
 
-cases = [("bc1", None), ("bc3", None)] + [("bc7", p) for p in itw_amd.BC7_PROFILES] + [("bc6h", p) for p in itw_amd.BC6H_PROFILES]
+cases = [("bc1", None), ("bc3", None), ("bc4", None), ("bc5", None)] + [("bc7", p) for p in itw_amd.BC7_PROFILES] + [("bc6h", p) for p in itw_amd.BC6H_PROFILES]
 torch.cuda.set_device(0)
 bad_total, blocks_total = 0, 0
 ldr, hdr = mixed_ldr(H, W), mixed_hdr(H, W)
