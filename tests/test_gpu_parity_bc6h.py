@@ -80,3 +80,14 @@ def test_full_size_4096_properties(itw, gpu, oracle):
     f = lambda a: a.astype(np.uint16).view(np.float16).astype(np.float64)
     rel = np.abs(f(dec) - f(cell[..., :3])) / np.maximum(f(cell[..., :3]), 1e-3)
     assert np.median(rel) < 0.10      # the 512-px cell of the synthetic field is busy: ~6 % median error at 8 bpp
+
+
+@pytest.mark.parametrize("prof", ["fast", "slow"])
+def test_full_size_i4_monkey_hdr_whole_surface(itw, gpu, oracle, golden_inputs, prof):
+    """SURVEY 8(d) input I4 / BASELINE configs[3]: the reference's monkey-32bit.hdr (RGBE -> half, committed fixture) tiled
+    to 4096 x 4096; all 1 048 576 blocks against the threaded oracle."""
+    from itw_amd import surfaces
+    img = surfaces.tile_to(golden_inputs["monkey_hdr"], 4096, 4096)
+    got = gpu_encode(itw, gpu, img, prof)
+    want = oracle.encode_mt("bc6h", img, prof).reshape(-1)
+    assert first_mismatch(got, want, 16) is None, first_mismatch(got, want, 16)

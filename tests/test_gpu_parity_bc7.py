@@ -215,3 +215,14 @@ def _chunked_cases(itw, gpu, oracle, fmt, prof, C, torch, surfaces):
     fn(C.byref(surf), d_out.data_ptr(), C.byref(st))
     torch.cuda.synchronize()
     assert first_mismatch(d_out.cpu().numpy(), want, 16) is None, "host -> device"
+
+
+@pytest.mark.parametrize("prof", ["slow", "alpha_slow"])
+def test_full_size_4096_bench_surface_whole(itw, gpu, oracle, prof):
+    """The exact surface bench.py times (synthetic I3, 4096 x 4096, seed of rank 0): all 1 048 576 blocks against the
+    threaded oracle (~15-20 s on the GPU box's 16 host cores)."""
+    from itw_amd import surfaces
+    img = surfaces.ldr_smooth(4096, 4096)
+    got = gpu_encode(itw, gpu, img, prof)
+    want = oracle.encode_mt("bc7", img, prof).reshape(-1)
+    assert first_mismatch(got, want, 16) is None, first_mismatch(got, want, 16)
