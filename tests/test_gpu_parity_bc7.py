@@ -226,3 +226,24 @@ def test_full_size_4096_bench_surface_whole(itw, gpu, oracle, prof):
     got = gpu_encode(itw, gpu, img, prof)
     want = oracle.encode_mt("bc7", img, prof).reshape(-1)
     assert first_mismatch(got, want, 16) is None, first_mismatch(got, want, 16)
+
+
+def test_whole_16384_surface_on_one_gpu(itw, gpu, oracle):
+    """BASELINE configs[4]'s surface (16384 x 16384 = 16.8 M blocks, 1 GiB of texels) in ONE device-resident call: the
+    288 GB of HBM make the single-GPU case legal, and it exercises every offset computation beyond 2^31 bits / 2^28
+    bytes.  The surface is a 512 x 512 cell tiled on the device; blocks are independent, so every 128 x 128-block tile
+    of the output must equal the oracle's stream of the cell."""
+    import torch
+    from itw_amd import surfaces
+    cell = surfaces.ldr_smooth(512, 512)
+    d_cell = torch.from_numpy(cell).to(gpu)
+    img = d_cell.repeat(32, 32, 1)                                     # (16384, 16384, 4), 1 GiB
+    assert img.shape == (16384, 16384, 4) and img.is_contiguous()
+    for fmt, prof, bpb in (("bc7", "slow", 16), ("bc1", None, 8)):
+        out = itw.compress(fmt, img, prof)
+        torch.cuda.synchronize()
+        want = torch.from_numpy(oracle.encode_mt(fmt, cell, prof).reshape(128, 128 * bpb)).to(gpu)
+        got = out.view(32, 128, 32, 128 * bpb)                         # [tile_y][block_row][tile_x][bytes of 128 blocks]
+        same = (got == want[None, :, None, :]).all(dim=3).all(dim=1)   # per tile
+        assert bool(same.all()), (fmt, torch.nonzero(~same)[:4].tolist())
+        del out, got
