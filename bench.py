@@ -120,6 +120,30 @@ def pmc_valu(workload):
     return best
 
 
+def rocprof_kernels(fmt):
+    """Per-kernel average duration (ms) of this format's kernels from the latest committed `rocprofv3 --kernel-trace --stats`
+    summary (profiles/*_kernel_stats.csv), so the live HIP-event time of the call can be checked against the profiler's."""
+    import csv
+    import re
+    pat = {"bc7": "bc7_", "bc6h": "bc6h_kernel", "bc1": "bc13_kernel<false", "bc3": "bc13_kernel<true",
+           "bc4": "bc45_kernel<1", "bc5": "bc45_kernel<2"}[fmt]
+    try:
+        suffix = "_kernel_stats.csv" if fmt == "bc7" else "_kernel_stats_all_formats.csv"   # headline-only pass / all formats
+        names = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith(suffix)) \
+            or sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_kernel_stats.csv"))
+        if not names:
+            return None
+        out = {}
+        with open(os.path.join(ROOT, "profiles", names[-1])) as f:
+            for r in csv.DictReader(f):
+                if pat in r["Name"]:
+                    m = re.search(r"(bc\w+_kernel<[^>]*>)", r["Name"])
+                    out[m.group(1) if m else r["Name"][:48]] = round(float(r["AverageNs"]) / 1e6, 4)
+        return {"source": "profiles/" + names[-1], "avg_ms": out} if out else None
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def pmc_traffic(workload):
     """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), if present."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -229,6 +253,11 @@ def main():
                          "note": "BC7/BC6H are VALU-issue bound (no MFMA-shaped work); the HBM fraction is reported "
                                  "because the contract asks for it; `valu` is the roofline that binds (DESIGN.md 3)"},
         }
+        rk = rocprof_kernels(fmt)
+        if rk and world == 1 and size == 4096:
+            # the call is several kernels for BC7; `achieved` uses the whole call.  For the slow / alpha_slow profiles the
+            # kernels listed are exactly the call's (the ranked variants <.., 1|2, ..> belong to the faster presets).
+            result["roofline"]["rocprof_kernels"] = rk
         insts = pmc_valu(args.workload)
         if insts and world == 1 and size == 4096:
             lane_ops = insts * 64 / (k_avg_ms * 1e-3) / 1e12
