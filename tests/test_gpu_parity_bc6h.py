@@ -91,3 +91,22 @@ def test_full_size_i4_monkey_hdr_whole_surface(itw, gpu, oracle, golden_inputs, 
     got = gpu_encode(itw, gpu, img, prof)
     want = oracle.encode_mt("bc6h", img, prof).reshape(-1)
     assert first_mismatch(got, want, 16) is None, first_mismatch(got, want, 16)
+
+
+def test_random_settings_fuzz(itw, gpu, oracle):
+    """bc6h_enc_settings is a caller-owned POD (ispc_texcomp.h:43-50): 96 random structs (mode gates, refine counts 0..4,
+    thresholds 0..32) on smooth + adversarial content, bit-exact against the oracle."""
+    from itw_amd import surfaces
+    rng = np.random.default_rng(66)
+    img = np.ascontiguousarray(np.concatenate([surfaces.hdr_smooth(32, 64), surfaces.hdr_random_bits(16, 64)], axis=0))
+    for trial in range(96):
+        s, so = itw.Bc6hSettings(), oracle.Bc6hSettings()
+        vals = {"slow_mode": bool(rng.integers(0, 2)), "fast_mode": bool(rng.integers(0, 2)),
+                "refineIterations_1p": int(rng.integers(0, 5)), "refineIterations_2p": int(rng.integers(0, 5)),
+                "fastSkipTreshold": int(rng.choice([0, 1, 2, 4, 7, 16, 31, 32]))}
+        for t in (s, so):
+            for k, v in vals.items():
+                setattr(t, k, v)
+        got = gpu_encode(itw, gpu, img, s)
+        want = oracle.encode("bc6h", img, so)
+        assert first_mismatch(got, want, 16) is None, (trial, vals, first_mismatch(got, want, 16))

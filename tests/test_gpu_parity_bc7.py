@@ -247,3 +247,34 @@ def test_whole_16384_surface_on_one_gpu(itw, gpu, oracle):
         same = (got == want[None, :, None, :]).all(dim=3).all(dim=1)   # per tile
         assert bool(same.all()), (fmt, torch.nonzero(~same)[:4].tolist())
         del out, got
+
+
+def test_random_settings_fuzz(itw, gpu, oracle):
+    """The settings struct is a caller-owned POD (ispc_texcomp.h:27-41) and any combination is legal input: 160 random
+    structs -- mode families on/off, refine counts 0..5 per mode, thresholds 0 / at the 16|17 and 64 boundaries /
+    above 64, every mode45_channel0, both channel counts -- on mixed content, bit-exact against the oracle."""
+    from itw_amd import surfaces
+    rng = np.random.default_rng(77)
+    img = np.concatenate([surfaces.ldr_smooth(32, 64), surfaces.ldr_uniform(16, 64), _posterised(16, 64, 4)], axis=0)
+    img = np.ascontiguousarray(img)
+    thresholds = [0, 1, 2, 5, 12, 16, 17, 40, 63, 64, 70]      # negative counts index the tables out of bounds in the reference
+    for trial in range(160):
+        s, so = itw.Bc7Settings(), oracle.Bc7Settings()
+        vals = {"skip_mode2": bool(rng.integers(0, 2)), "fastSkipTreshold_mode1": int(rng.choice(thresholds)),
+                "fastSkipTreshold_mode3": int(rng.choice(thresholds)), "fastSkipTreshold_mode7": int(rng.choice(thresholds)),
+                "mode45_channel0": int(rng.integers(0, 4)), "refineIterations_channel": int(rng.integers(0, 6)),
+                "channels": int(rng.choice([3, 4]))}
+        sel = [bool(rng.integers(0, 2)) for _ in range(4)]
+        if not any(sel):
+            sel[int(rng.integers(0, 4))] = True
+        ref = [int(rng.integers(0, 6)) for _ in range(8)]
+        for t in (s, so):
+            for k, v in vals.items():
+                setattr(t, k, v)
+            for i in range(4):
+                t.mode_selection[i] = sel[i]
+            for i in range(8):
+                t.refineIterations[i] = ref[i]
+        got = gpu_encode(itw, gpu, img, s)
+        want = oracle.encode("bc7", img, so)
+        assert first_mismatch(got, want, 16) is None, (trial, vals, sel, ref, first_mismatch(got, want, 16))
