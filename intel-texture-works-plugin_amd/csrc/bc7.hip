@@ -30,7 +30,7 @@
 //     (part + 64*bound) is only evaluated when two shapes actually tie;
 //   * modes 0/2: a subset's mode 2 result depends on its texel mask alone and 192
 //     subsets use 140 masks, so the scan follows a generated schedule that clusters
-//     equal masks and reloads results from a three-entry register cache;
+//     equal masks and reloads results from a four-entry register cache;
 //   * shorter ranked lists (fast profiles) keep the per-lane order: the i-th entry of
 //     the reference's selection sort (kernel.ispc:1365-1384) is the smallest key above
 //     the previous one -- a 64-entry LDS scan, no sort, no dynamic register indexing;
@@ -213,8 +213,7 @@ struct Lane {
     uint2* pal;               // LDS column of palettes (table-order scans): 12 levels, pal[level * TPB]
 };
 
-struct Win {                  // winner of one multi-subset mode during the search
-    uint32_t qb[2];
+struct Win {                  // winner of one multi-subset mode during the search (its indices are recomputed by the finish kernel)
     int32_t err;
     int32_t shape;            // table index 0..63 (two subsets) / 64..127 (three)
     int32_t key;              // rank key of `shape`; < 0 = not evaluated yet (table-order scans)
@@ -222,7 +221,6 @@ struct Win {                  // winner of one multi-subset mode during the sear
 
 __device__ __forceinline__ void reset(Win& w, int shape0)
 {
-    w.qb[0] = w.qb[1] = 0u;
     w.err = ERR_MAX;
     w.shape = shape0;
     w.key = -1;
@@ -415,24 +413,33 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
     SubsetMask sm[3];
     #pragma unroll
     for (int j = 0; j < M.pairs; j++) sm[j] = subset_of(w.shape, j);
-    // endpoint codes of the search-time winner: refit + quantise its shape again (same inputs, same bits)
+    // endpoint codes and indices of the search-time winner: the scan kept only its error, so refit + quantise its
+    // shape again (same inputs, same bits) and select once; the error found equals w.err
     int32_t cq[3][2][4];
+    uint32_t wqb[2];
     #pragma unroll
     for (int j = 0; j < 3; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) cq[j][i][p] = 0;
-    #pragma unroll 1
-    for (int j = 0; j < M.pairs; j++) {
-        const SubsetMask s = (j == 0) ? sm[0] : ((j == 1) ? sm[1] : sm[2]);
-        IStats<M.ch> st;
-        stats_int<M.ch>(st, ln.tx.pl, s);
-        float ep[2][4];
-        ep[0][3] = 0.f; ep[1][3] = 0.f;
-        fit_line<M.ch>(ep, ln.tx, s.bits, st, ispc_rcp((float)s.n, ln.T), ln.T);
-        int32_t q[2][4], d[2][4];
-        quant_mode<MODE, true>(q, d, ep, M.ch);
-        #pragma unroll
-        for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) {
-            if (j == 0) cq[0][i][p] = q[i][p]; else if (j == 1) cq[1][i][p] = q[i][p]; else cq[2][i][p] = q[i][p];
+    {
+        Segment sg0[3];
+        #pragma unroll 1
+        for (int j = 0; j < M.pairs; j++) {
+            const SubsetMask s = (j == 0) ? sm[0] : ((j == 1) ? sm[1] : sm[2]);
+            IStats<M.ch> st;
+            stats_int<M.ch>(st, ln.tx.pl, s);
+            float ep[2][4];
+            ep[0][3] = 0.f; ep[1][3] = 0.f;
+            fit_line<M.ch>(ep, ln.tx, s.bits, st, ispc_rcp((float)s.n, ln.T), ln.T);
+            int32_t q[2][4], d[2][4];
+            quant_mode<MODE, true>(q, d, ep, M.ch);
+            const Segment sgj = make_segment<M.bits, M.ch>(d);
+            #pragma unroll
+            for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) {
+                if (j == 0) cq[0][i][p] = q[i][p]; else if (j == 1) cq[1][i][p] = q[i][p]; else cq[2][i][p] = q[i][p];
+            }
+            if (j == 0) sg0[0] = sgj; else if (j == 1) sg0[1] = sgj; else sg0[2] = sgj;
         }
+        if (M.pairs == 2) sg0[2] = sg0[1];
+        (void)select_block<M.bits, M.ch, M.pairs>(wqb, ln.tx, sg0, sh.pattern);
     }
     for (int it = 0; it < iterations; it++) {
         ln.tx.fence();
@@ -443,7 +450,7 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
             float ep[2][4];
             int32_t d[2][4];
             ep[0][3] = 0.f; ep[1][3] = 0.f;
-            refit_line<M.bits, M.ch>(ep, ln.tx.pl, w.qb, sm[j], ln.T);
+            refit_line<M.bits, M.ch>(ep, ln.tx.pl, wqb, sm[j], ln.T);
             quant_mode<MODE, false>(q[j], d, ep, settings_channels);       // :1343 passes the profile's channel count
             sg[j] = make_segment<M.bits, M.ch>(d);
         }
@@ -453,7 +460,7 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
         if (err < w.err) {
             #pragma unroll
             for (int j = 0; j < M.pairs; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) cq[j][i][p] = q[j][i][p];
-            w.qb[0] = qb[0]; w.qb[1] = qb[1];
+            wqb[0] = qb[0]; wqb[1] = qb[1];
             w.err = err;
         }
     }
@@ -462,13 +469,12 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
     if (err < ln.best_err) {
         ln.best_err = err;
         ln.improved = true;
-        emit_multi<MODE>(ln.best, cq, w.qb, w.shape);
+        emit_multi<MODE>(ln.best, cq, wqb, w.shape);
     }
 }
 
-__device__ __forceinline__ void take(Win& w, int32_t err, const uint32_t (&qb)[2], int shape, int32_t key)
+__device__ __forceinline__ void take(Win& w, int32_t err, int shape, int32_t key)
 {
-    w.qb[0] = qb[0]; w.qb[1] = qb[1];
     w.err = err; w.shape = shape; w.key = key;
 }
 
@@ -477,13 +483,12 @@ __device__ __forceinline__ void take(Win& w, int32_t err, const uint32_t (&qb)[2
 // errors, the lowest table index -- whatever the visiting order.  With mode 2 enabled the scan therefore follows
 // BC7_F02_SCHEDULE (tools/gen_bc7_f02_schedule.py): 192 (shape, subset) pairs use only 140 distinct texel masks and a
 // subset's whole mode 2 result (indices, error) depends on the mask alone, so the order clusters equal masks and a
-// three-entry register cache, driven by the wave-uniform schedule word, turns 37 subset evaluations into loads (7 more
+// four-entry register cache, driven by the wave-uniform schedule word, turns 39 subset evaluations into loads (9 more
 // keep their fit for mode 0 and skip the mode 2 part).
-struct SubsetResult { int32_t e; uint32_t q[2]; };
-
-// The cache is nine scalars (an indexed aggregate would be demoted to scratch); `slot` is wave-uniform.
-#define ITW_CACHE_GET(F, slot) ((slot) == 0u ? F##0 : ((slot) == 1u ? F##1 : F##2))
-#define ITW_CACHE_PUT(F, slot, v) do { F##0 = (slot) == 0u ? (v) : F##0; F##1 = (slot) == 1u ? (v) : F##1; F##2 = (slot) == 2u ? (v) : F##2; } while (0)
+// A cached subset result is its error (the scans carry no indices).
+// The cache is four scalars (an indexed aggregate would be demoted to scratch); `slot` is wave-uniform.
+#define ITW_CACHE_GET(F, slot) ((slot) == 0u ? F##0 : ((slot) == 1u ? F##1 : ((slot) == 2u ? F##2 : F##3)))
+#define ITW_CACHE_PUT(F, slot, v) do { F##0 = (slot) == 0u ? (v) : F##0; F##1 = (slot) == 1u ? (v) : F##1; F##2 = (slot) == 2u ? (v) : F##2; F##3 = (slot) == 3u ? (v) : F##3; } while (0)
 
 __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, Win& b0, Win& b2)
 {
@@ -493,14 +498,12 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
     const int32_t tt = full.m[0] + full.m[4] + full.m[7];          // sum over the block of |texel|^2
     const bool do2 = !S.skip_mode2;
     const int count = do2 ? 64 : 16;
-    int32_t ce0 = 0, ce1 = 0, ce2 = 0;               // cached subset results: error, index bits (low / high word)
-    uint32_t cl0 = 0u, cl1 = 0u, cl2 = 0u, ch0 = 0u, ch1 = 0u, ch2 = 0u;
+    int32_t ce0 = 0, ce1 = 0, ce2 = 0, ce3 = 0;      // cached subset results (mode 2 error of a texel mask)
     for (int pos = 0; pos < count; pos++) {
         ln.tx.fence();
         const uint32_t sched = do2 ? BC7_F02_SCHEDULE[pos] : (uint32_t)pos;     // mode 0 alone: table order, nothing cached
         const int part = (int)(sched & 63u);
         const bool do0 = part < 16;
-        uint32_t q0[2] = {0u, 0u}, q2[2] = {0u, 0u};
         int32_t e0 = 0, e2 = 0;
         IStats<3> rest = full;
         bool rest_valid = true;                          // `rest` = block minus the subsets handled so far
@@ -510,7 +513,7 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
             const uint32_t act = (sched >> (8 + 4 * j)) & 3u, slot = (sched >> (10 + 4 * j)) & 3u;
             const bool load = act == 2u;
             if (load) {                                   // this mask's mode 2 result is in the cache
-                e2 += ITW_CACHE_GET(ce, slot); q2[0] |= ITW_CACHE_GET(cl, slot); q2[1] |= ITW_CACHE_GET(ch, slot);
+                e2 += ITW_CACHE_GET(ce, slot);
                 if (!do0) { rest_valid = false; continue; }
             }
             const SubsetMask sm = subset_of(64 + part, j);
@@ -524,21 +527,21 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
             if (do0) {
                 quant_mode<0, true>(q, d, fit, 3);
                 const PalSegment ps = build_palette<3, 3, TPB>(ln.pal, d);
-                select_subset_pal<3, 3, TPB>(q0, e0, ln.tx, ps, ln.pal, sm.bits);
+                subset_error_pal<3, 3, TPB>(e0, ln.tx, ps, ln.pal, sm.bits);
             }
             if (do2 && !load) {
                 quant_mode<2, true>(q, d, fit, 3);
                 const PalSegment ps = build_palette<2, 3, TPB>(ln.pal + 8 * TPB, d);
-                SubsetResult r = {0, {0u, 0u}};
-                select_subset_pal<2, 3, TPB>(r.q, r.e, ln.tx, ps, ln.pal + 8 * TPB, sm.bits);
-                e2 += r.e; q2[0] |= r.q[0]; q2[1] |= r.q[1];
-                if (act == 1u) { ITW_CACHE_PUT(ce, slot, r.e); ITW_CACHE_PUT(cl, slot, r.q[0]); ITW_CACHE_PUT(ch, slot, r.q[1]); }
+                int32_t r = 0;
+                subset_error_pal<2, 3, TPB>(r, ln.tx, ps, ln.pal + 8 * TPB, sm.bits);
+                e2 += r;
+                if (act == 1u) ITW_CACHE_PUT(ce, slot, r);
             }
         }
         e0 += tt; e2 += tt;                              // the |t|^2 terms the palette path leaves out
         const int shape = 64 + part;
-        if (do0 && (e0 < b0.err || (e0 == b0.err && shape < b0.shape))) take(b0, e0, q0, shape, part);
-        if (do2 && (e2 < b2.err || (e2 == b2.err && shape < b2.shape))) take(b2, e2, q2, shape, part);
+        if (do0 && (e0 < b0.err || (e0 == b0.err && shape < b0.shape))) take(b0, e0, shape, part);
+        if (do2 && (e2 < b2.err || (e2 == b2.err && shape < b2.shape))) take(b2, e2, shape, part);
     }
 }
 
@@ -574,7 +577,6 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
         // every shape is a candidate: table order; the rank key is only needed to order shapes of equal error
         for (int part = 0; part < 64; part++) {
             ln.tx.fence();
-            uint32_t qa[2] = {0u, 0u}, qc[2] = {0u, 0u};
             int32_t ea = 0, ec = 0;
             IStats<FIT_CH> rest = full;
             #pragma unroll 1
@@ -591,30 +593,30 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
                 if (FAMILY7) {
                     quant_mode<7, true>(q, d, fit, 4);
                     const PalSegment ps = build_palette<2, 4, TPB>(ln.pal, d);
-                    select_subset_pal<2, 4, TPB>(qa, ea, ln.tx, ps, ln.pal, sm.bits);
+                    subset_error_pal<2, 4, TPB>(ea, ln.tx, ps, ln.pal, sm.bits);
                 } else {
                     if (na > 0 && nb > 0) {
                         quant_mode<1, true>(q, d, fit, 3);
                         const PalSegment s1 = build_palette<3, 3, TPB>(ln.pal, d);
                         quant_mode<3, true>(q, d, fit, 3);
                         const PalSegment s3 = build_palette<2, 3, TPB>(ln.pal + 8 * TPB, d);
-                        select_subset2_pal<3, 2, 3, TPB>(qa, ea, qc, ec, ln.tx, s1, ln.pal, s3, ln.pal + 8 * TPB, sm.bits);
+                        subset_error2_pal<3, 2, 3, TPB>(ea, ec, ln.tx, s1, ln.pal, s3, ln.pal + 8 * TPB, sm.bits);
                     } else if (na > 0) {
                         quant_mode<1, true>(q, d, fit, 3);
                         const PalSegment ps = build_palette<3, 3, TPB>(ln.pal, d);
-                        select_subset_pal<3, 3, TPB>(qa, ea, ln.tx, ps, ln.pal, sm.bits);
+                        subset_error_pal<3, 3, TPB>(ea, ln.tx, ps, ln.pal, sm.bits);
                     } else {
                         quant_mode<3, true>(q, d, fit, 3);
                         const PalSegment ps = build_palette<2, 3, TPB>(ln.pal + 8 * TPB, d);
-                        select_subset_pal<2, 3, TPB>(qc, ec, ln.tx, ps, ln.pal + 8 * TPB, sm.bits);
+                        subset_error_pal<2, 3, TPB>(ec, ln.tx, ps, ln.pal + 8 * TPB, sm.bits);
                     }
                 }
             }
             ea += tt; ec += tt;                          // the |t|^2 terms the palette path leaves out
             const bool on_a = na > 0, on_b = !FAMILY7 && nb > 0;
             const bool tie_a = on_a && ea == wa.err, tie_b = on_b && ec == wb.err;
-            if (on_a && ea < wa.err) take(wa, ea, qa, part, -1);
-            if (on_b && ec < wb.err) take(wb, ec, qc, part, -1);
+            if (on_a && ea < wa.err) take(wa, ea, part, -1);
+            if (on_b && ec < wb.err) take(wb, ec, part, -1);
             if (tie_a || tie_b) {
                 // equal errors: the reference keeps whichever comes first in its ranked list = the lower key.
                 // One rolled loop evaluates the missing keys: this shape's, then the incumbents'.
@@ -628,8 +630,8 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
                         if (which == 0) key_here = k; else if (which == 1) wa.key = k; else wb.key = k;
                     }
                 }
-                if (tie_a && key_here < wa.key) take(wa, ea, qa, part, key_here);
-                if (tie_b && key_here < wb.key) take(wb, ec, qc, part, key_here);
+                if (tie_a && key_here < wa.key) take(wa, ea, part, key_here);
+                if (tie_b && key_here < wb.key) take(wb, ec, part, key_here);
             }
         }
     } else {
@@ -693,15 +695,15 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
             uint32_t qb[2];
             if (FAMILY7) {
                 const int32_t e = select_block<2, 4, 2>(qb, ln.tx, sa, sh.pattern);
-                if (e < wa.err) take(wa, e, qb, shape, prev);
+                if (e < wa.err) take(wa, e, shape, prev);
             } else {
                 if (i < na) {
                     const int32_t e = select_block<3, 3, 2>(qb, ln.tx, sa, sh.pattern);
-                    if (e < wa.err) take(wa, e, qb, shape, prev);
+                    if (e < wa.err) take(wa, e, shape, prev);
                 }
                 if (i < nb) {
                     const int32_t e = select_block<2, 3, 2>(qb, ln.tx, sc, sh.pattern);
-                    if (e < wb.err) take(wb, e, qb, shape, prev);
+                    if (e < wb.err) take(wb, e, shape, prev);
                 }
             }
         }
@@ -944,15 +946,15 @@ __device__ __forceinline__ void load_block(Tex& tx, const uint8_t* __restrict__ 
     tx.make_planar();
 }
 
-// winners of a family's two modes: [slot][block] x {qb0, qb1, err, shape}
+// winners of a family's two modes: [slot][block] x {err, shape}  (8 B; the workspace keeps its 16 B slots)
 __device__ __forceinline__ void store_win(uint4* __restrict__ wins, int32_t nblocks, int slot, int32_t b, const Win& w)
 {
-    wins[(int64_t)slot * nblocks + b] = make_uint4(w.qb[0], w.qb[1], (uint32_t)w.err, (uint32_t)w.shape);
+    reinterpret_cast<uint2*>(wins)[(int64_t)slot * nblocks + b] = make_uint2((uint32_t)w.err, (uint32_t)w.shape);
 }
 __device__ __forceinline__ void load_win(Win& w, const uint4* __restrict__ wins, int32_t nblocks, int slot, int32_t b)
 {
-    const uint4 v = wins[(int64_t)slot * nblocks + b];
-    w.qb[0] = v.x; w.qb[1] = v.y; w.err = (int32_t)v.z; w.shape = (int32_t)v.w; w.key = -1;
+    const uint2 v = reinterpret_cast<const uint2*>(wins)[(int64_t)slot * nblocks + b];
+    w.err = (int32_t)v.x; w.shape = (int32_t)v.y; w.key = -1;
 }
 
 // Register budgets (waves per SIMD) were picked by measurement on MI355X: the scans are bound by dependent-issue

@@ -488,6 +488,48 @@ __device__ __forceinline__ void select_texel_pal(int32_t& q_out, int32_t& e_out,
     e_out = -max(f0, f1);
 }
 
+// The scans only need a candidate's ERROR: which of the two neighbouring levels won, and the packed indices, matter for
+// the winner alone, and the finish kernels recompute them from the winner's endpoints (one selection pass per mode and
+// block instead of compare + select + shift-or per texel, mode and shape).
+template <int BITS, int CH, int PAL_STRIDE>
+__device__ __forceinline__ int32_t texel_error_pal(const PalSegment& sg, const uint2* pal, uint32_t w, uint32_t t01, uint32_t t23)
+{
+    constexpr int LEVELS = 1 << BITS;
+    int32_t n;
+    if (CH == 4) n = dot2(t01, sg.ba01, dot2(t23, sg.ba23, sg.nc));
+    else         n = dot2(t01, sg.ba01, (int32_t)t23 * (int32_t)sg.ba23 + sg.nc);
+    const float x = __builtin_fmaf((float)n, sg.k0, sg.k1);
+    const int32_t q1 = imed3((int32_t)x, 1, LEVELS - 1);
+    const uint2* p = pal + (q1 - 1) * PAL_STRIDE;
+    const uint2 lo = p[0], hi = p[PAL_STRIDE];
+    const int32_t f0 = (int32_t)((udot4(lo.x, w, 0u) << 1) + lo.y), f1 = (int32_t)((udot4(hi.x, w, 0u) << 1) + hi.y);
+    return max(f0, f1);                                                     // = -(error - |t|^2) of the better level
+}
+
+// Error of the texels of one subset (wave-uniform mask), WITHOUT the |t|^2 terms; `total` accumulates.
+template <int BITS, int CH, int PAL_STRIDE>
+__device__ __forceinline__ void subset_error_pal(int32_t& total, const Tex& tx, const PalSegment& sg, const uint2* pal, uint32_t mask)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if ((mask >> k) & 1u)
+            total -= texel_error_pal<BITS, CH, PAL_STRIDE>(sg, pal, tx.w[k], tx.pair01(k), tx.template pair23<CH == 4>(k));
+}
+
+template <int BITSA, int BITSB, int CH, int PAL_STRIDE>
+__device__ __forceinline__ void subset_error2_pal(int32_t& ta, int32_t& tc, const Tex& tx, const PalSegment& sa, const uint2* pa,
+                                                  const PalSegment& sc, const uint2* pc, uint32_t mask)
+{
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if ((mask >> k) & 1u) {
+            const uint32_t t01 = tx.pair01(k), t23 = tx.template pair23<CH == 4>(k);
+            ta -= texel_error_pal<BITSA, CH, PAL_STRIDE>(sa, pa, tx.w[k], t01, t23);
+            tc -= texel_error_pal<BITSB, CH, PAL_STRIDE>(sc, pc, tx.w[k], t01, t23);
+        }
+    }
+}
+
 // Texels of one subset (wave-uniform mask) against one or two palettes; accumulates errors WITHOUT the |t|^2 terms.
 template <int BITS, int CH, int PAL_STRIDE>
 __device__ __forceinline__ void select_subset_pal(uint32_t (&qb)[2], int32_t& total, const Tex& tx, const PalSegment& sg,

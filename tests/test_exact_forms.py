@@ -226,10 +226,10 @@ def test_f02_schedule_is_a_valid_cache_program():
         assert m0 and m1 and sub[2] and (m0 | m1 | sub[2]) == 0xffff and not (m0 & m1)
         for j in range(3):
             act, slot = (w >> (8 + 4 * j)) & 3, (w >> (10 + 4 * j)) & 3
-            assert act in (0, 1, 2) and slot in (0, 1, 2)
+            assert act in (0, 1, 2) and slot in (0, 1, 2, 3)
             if act == 2:
                 assert slots.get(slot) == sub[j], (hex(w), j)
                 loads += 1
             elif act == 1:
                 slots[slot] = sub[j]
-    assert loads >= 40                                    # the point of the exercise: 44 of 192 with three slots
+    assert loads >= 46                                    # the point of the exercise: 48 of 192 with four slots
