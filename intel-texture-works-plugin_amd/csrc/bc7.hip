@@ -400,7 +400,7 @@ __device__ __forceinline__ int32_t rank_key(int shape, const Tex& tx, const Stat
     stats_int<RANK_CH>(s0, tx.pl, sm);
     Stats<RANK_CH> f0;
     stats_float<RANK_CH>(f0, s0);
-    return (int32_t)((uint32_t)shape + (uint32_t)split_bound_from<RANK_CH, true>(f0, full, T) * 64u);
+    return (int32_t)((uint32_t)shape + (uint32_t)split_bound_from<RANK_CH, true>(f0, full, T, rcp_of_count(sm.n), rcp_of_count(16 - sm.n)) * 64u);
 }
 
 // Least-squares refinement of a mode's winner, then the mode competes for the block.  [kernel.ispc:1329-1362]

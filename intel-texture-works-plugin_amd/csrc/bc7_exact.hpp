@@ -204,16 +204,21 @@ __device__ __forceinline__ void fit_line(float (&ep)[2][4], const Tex& tx, uint3
     // finite, so a NaN can only come from a non-finite axis (degenerate normalisation): those lanes take the
     // compare-and-select form, everyone else two 4-cycle instructions per texel instead of four plus wait states.
     float lo = __builtin_inff(), hi = -__builtin_inff();
-    float probe = 0.f;
+    // The reference's `dot = 0; dot += ...` starts from +0: 0 + x == x except that it turns a -0 first product into +0,
+    // and a zero of either sign in `dot` (hence in lo / hi) ends in the same endpoints: (+-0) * axis + dc is dc, or +0
+    // when dc is +0 (dc, a sum of non-negative texels times a positive reciprocal, is never -0); hi - lo < 1 and the
+    // +-0.5 adjustment do not see the sign either.  So the sum starts from its first product.
+    float probe = axis[0];
 #pragma unroll
-    for (int p = 0; p < CH; p++) probe += axis[p] * 0.0f;                       // NaN iff some axis component is NaN or inf
+    for (int p = 1; p < CH; p++) probe += axis[p];
+    probe *= 0.0f;                                                              // NaN iff some axis component is NaN or inf
     if (__builtin_expect(probe != probe, 0)) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             if ((mask >> k) & 1u) {
-                float dot = 0.f;
+                float dot = axis[0] * (tx.get(0, k) - dc[0]);
 #pragma unroll
-                for (int p = 0; p < CH; p++) dot += axis[p] * (tx.get(p, k) - dc[p]);
+                for (int p = 1; p < CH; p++) dot += axis[p] * (tx.get(p, k) - dc[p]);
                 lo = fmin_x86(lo, dot);
                 hi = fmax_x86(hi, dot);
             }
@@ -222,9 +227,9 @@ __device__ __forceinline__ void fit_line(float (&ep)[2][4], const Tex& tx, uint3
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             if ((mask >> k) & 1u) {
-                float dot = 0.f;
+                float dot = axis[0] * (tx.get(0, k) - dc[0]);
 #pragma unroll
-                for (int p = 0; p < CH; p++) dot += axis[p] * (tx.get(p, k) - dc[p]);
+                for (int p = 1; p < CH; p++) dot += axis[p] * (tx.get(p, k) - dc[p]);
                 lo = __builtin_fminf(lo, dot);
                 hi = __builtin_fmaxf(hi, dot);
             }

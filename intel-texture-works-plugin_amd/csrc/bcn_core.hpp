@@ -144,9 +144,9 @@ __device__ __forceinline__ void principal_axis(float (&v)[4], const float (&cv)[
         #pragma unroll
         for (int p = 0; p < CH; p++) v[p] = a[p];
         if (it & 1) {
-            float nsq = 0.f;
+            float nsq = a[0] * a[0];                      // the reference's 0 + a0*a0: a square is never -0, so the sum is the square
             #pragma unroll
-            for (int p = 0; p < CH; p++) nsq += a[p] * a[p];
+            for (int p = 1; p < CH; p++) nsq += a[p] * a[p];
             const float rn = ispc_rsqrt<FAST>(nsq, T);
             #pragma unroll
             for (int p = 0; p < CH; p++) v[p] *= rn;
@@ -226,9 +226,9 @@ __device__ __forceinline__ float pca_residual(float (&cv)[10], const SeedTables&
         w[2] = cv[2] * axis[0] + cv[5] * axis[1] + cv[7] * axis[2] + cv[8] * axis[3];
         w[3] = cv[3] * axis[0] + cv[6] * axis[1] + cv[8] * axis[2] + cv[9] * axis[3];
     }
-    float sq_sum = 0.f;
+    float sq_sum = sq(w[0]);                              // 0 + w0*w0 of the reference: a square is never -0
     #pragma unroll
-    for (int p = 0; p < CH; p++) sq_sum += sq(w[p]);
+    for (int p = 1; p < CH; p++) sq_sum += sq(w[p]);
     const float lambda = sqrtf(sq_sum);
     float bound = cv[0] + cv[4] + cv[7];
     if (CH == 4) bound += cv[9];
@@ -238,20 +238,22 @@ __device__ __forceinline__ float pca_residual(float (&cv)[10], const SeedTables&
 
 // Lower bound on the two-subset error of a shape, as an integer sort key component:
 // (int)(sqrt(res(subset0) + res(rest)) * 256), rest = full - subset0.   (kernel.ispc:952-971, 1404-1409)
+// rn_a / rn_b: ISPC rcp of the two texel counts when the caller already has them (wave-uniform shapes read them from
+// the 17-entry table of bc7_exact.hpp instead of running the seed + Newton emulation twice per shape); < 0 = compute here.
 template <int CH, bool FAST = false>
-__device__ __forceinline__ int32_t split_bound_from(const Stats<CH>& a, const Stats<CH>& full, const SeedTables& T)
+__device__ __forceinline__ int32_t split_bound_from(const Stats<CH>& a, const Stats<CH>& full, const SeedTables& T,
+                                                    float rn_a = -1.f, float rn_b = -1.f)
 {
     float cv1[10], cv2[10];
-    covariance_of<CH>(cv1, a, ispc_rcp(a.n, T));
+    covariance_of<CH>(cv1, a, rn_a < 0.f ? ispc_rcp(a.n, T) : rn_a);
     Stats<CH> b;
     #pragma unroll
     for (int i = 0; i < 10; i++) b.m[i] = full.m[i] - a.m[i];
     #pragma unroll
     for (int i = 0; i < 4; i++) b.s[i] = full.s[i] - a.s[i];
     b.n = full.n - a.n;
-    covariance_of<CH>(cv2, b, ispc_rcp(b.n, T));
-    float bound = 0.f;
-    bound += pca_residual<CH, FAST>(cv1, T);
+    covariance_of<CH>(cv2, b, rn_b < 0.f ? ispc_rcp(b.n, T) : rn_b);
+    float bound = pca_residual<CH, FAST>(cv1, T);         // 0 + r1 of the reference: r1 = max(.., +0) is never -0
     bound += pca_residual<CH, FAST>(cv2, T);
     return f2i_x86(sqrtf(bound) * 256.0f);
 }
