@@ -176,15 +176,37 @@ __device__ __forceinline__ void fit_from_stats(float (&ep)[2][4], const TX& px, 
     float axis[4];
     principal_axis<CH, 8, FAST>(axis, cv, T);
 
+    // Extreme projections.  Two exact simplifications, as in bc7_exact.hpp fit_line: (1) the reference's `dot = 0; dot += ..`
+    // starts from its first product -- 0 + x differs from x only in the sign of a zero, and a zero of either sign in lo / hi
+    // gives the same endpoints ((+-0) * axis + dc with dc >= +0: texels here are non-negative finite numbers); (2) minps /
+    // maxps equal v_min / v_max_f32 unless a NaN is involved (again up to the sign of a zero), texels and dc are finite,
+    // so only lanes whose axis is not finite (degenerate normalisation) take the compare-and-select form.
     float lo = __builtin_inff(), hi = -__builtin_inff();
+    float probe = axis[0];
+    #pragma unroll
+    for (int p = 1; p < CH; p++) probe += axis[p];
+    probe *= 0.0f;                                                              // NaN iff some axis component is NaN or inf
+    if (__builtin_expect(probe != probe, 0)) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        if ((mask >> k) & 1u) {
-            float dot = 0.f;
-            #pragma unroll
-            for (int p = 0; p < CH; p++) dot += axis[p] * (px.get(p, k) - dc[p]);
-            lo = fmin_x86(lo, dot);
-            hi = fmax_x86(hi, dot);
+        for (int k = 0; k < 16; k++) {
+            if ((mask >> k) & 1u) {
+                float dot = axis[0] * (px.get(0, k) - dc[0]);
+                #pragma unroll
+                for (int p = 1; p < CH; p++) dot += axis[p] * (px.get(p, k) - dc[p]);
+                lo = fmin_x86(lo, dot);
+                hi = fmax_x86(hi, dot);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if ((mask >> k) & 1u) {
+                float dot = axis[0] * (px.get(0, k) - dc[0]);
+                #pragma unroll
+                for (int p = 1; p < CH; p++) dot += axis[p] * (px.get(p, k) - dc[p]);
+                lo = __builtin_fminf(lo, dot);
+                hi = __builtin_fmaxf(hi, dot);
+            }
         }
     }
     if (hi - lo < 1.0f) { lo -= 0.5f; hi += 0.5f; }
