@@ -47,7 +47,7 @@ struct HLane {
     int32_t qlo[3], qhi[3];   // endpoint clamp window in code space
     SeedTables T;
     int32_t* keys;            // LDS column, 32 entries: keys[i * TPB6]
-    uint32_t* wins;           // LDS column, 6 winners x {err bits, shape, qb0, qb1}: wins[(4 * m + f) * TPB6]
+    uint32_t* wins;           // LDS column, 6 winners x {err bits, shape, -, -}: wins[(4 * m + f) * TPB6]
 };
 
 // ---- format data (kernel.ispc:2080-2125) -----------------------------------
@@ -231,7 +231,11 @@ __device__ __forceinline__ HSeg make_hseg(const float (&e)[2][4])
 //    non-negative value is floor: d = a + floor((w*(b-a) + 32) / 64), every step exact (|w*(b-a)| < 2^23).
 //  * float -> int of the index: cvttps2dq gives INT_MIN (-> clamp 1) for NaN and for x >= 2^31, where
 //    v_cvt_i32_f32 would saturate upwards; x < -2^31 ends at 1 on both.
-template <int BITS, int PAIRS>
+//  * WANT_IDX = false (the shape scans): only the error is produced.  Which of the two levels won and the packed indices
+//    matter for a mode's winner alone, and finish_two_region recomputes them from the winner's endpoints.  Errors are
+//    finite (texels and decoded endpoints are finite integers-as-floats), so the reference's `err0 < err1 ? err0 : err1`
+//    is the IEEE minimum.
+template <int BITS, int PAIRS, bool WANT_IDX = true>
 __device__ __forceinline__ float select_hdr(uint32_t (&qb)[2], const TexF& px, const HSeg (&sg)[2], uint32_t pattern)
 {
     constexpr int LEVELS = 1 << BITS;
@@ -267,10 +271,15 @@ __device__ __forceinline__ float select_hdr(uint32_t (&qb)[2], const TexF& px, c
             err0 += sq(d0 - t[p]);
             err1 += sq(d1 - t[p]);
         }
-        const bool first = err0 < err1;
-        const float e = first ? err0 : err1;
-        const uint32_t qi = (uint32_t)(first ? q1 - 1 : q1);
-        if (k < 8) qb[0] += qi << (4 * k); else qb[1] += qi << (4 * (k - 8));
+        float e;
+        if (WANT_IDX) {
+            const bool first = err0 < err1;
+            e = first ? err0 : err1;
+            const uint32_t qi = (uint32_t)(first ? q1 - 1 : q1);
+            if (k < 8) qb[0] += qi << (4 * k); else qb[1] += qi << (4 * (k - 8));
+        } else {
+            e = __builtin_fminf(err0, err1);
+        }
         total += (float)f2i_x86(e);
     }
     return total;
@@ -325,6 +334,9 @@ __device__ __forceinline__ int two_region_mode(bool slow, int m, int gated)
 }
 
 // Scan of the `count` best ranked shapes: one pair of line fits per shape serves all `nmodes` modes. [2174-2273]
+// LEAN: the scan keeps errors only and the finish recomputes the winner's indices (pays when many candidates are scanned:
+// the slow profiles); otherwise the scan stores the indices with the winner.
+template <bool LEAN>
 __device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes, int gated, int count)
 {
     for (int m = 0; m < nmodes; m++) {
@@ -357,18 +369,18 @@ __device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes
                 sg[j] = make_hseg(ep);
             }
             uint32_t qb[2];
-            const float err = select_hdr<3, 2>(qb, ln.tex, sg, sh.pattern);
+            const float err = select_hdr<3, 2, !LEAN>(qb, ln.tex, sg, sh.pattern);
             if (err < __uint_as_float(ln.wins[(4 * m + 0) * TPB6])) {
                 ln.wins[(4 * m + 0) * TPB6] = __float_as_uint(err);
                 ln.wins[(4 * m + 1) * TPB6] = (uint32_t)shape;
-                ln.wins[(4 * m + 2) * TPB6] = qb[0];
-                ln.wins[(4 * m + 3) * TPB6] = qb[1];
+                if (!LEAN) { ln.wins[(4 * m + 2) * TPB6] = qb[0]; ln.wins[(4 * m + 3) * TPB6] = qb[1]; }
             }
         }
     }
 }
 
 // Refinement of each mode's winner, then the mode competes for the block, in mode order.
+template <bool LEAN>
 __device__ __forceinline__ void finish_two_region(HLane& ln, bool slow, int nmodes, int gated, int refine)
 {
 #pragma unroll 1
@@ -379,16 +391,24 @@ __device__ __forceinline__ void finish_two_region(HLane& ln, bool slow, int nmod
         const int bshape = (int)ln.wins[(4 * m + 1) * TPB6];
         uint32_t bqb[2] = {ln.wins[(4 * m + 2) * TPB6], ln.wins[(4 * m + 3) * TPB6]};
         const Shape sh = load_shape(bshape);
-        // endpoint codes of the scan's winner: same fit, same quantiser, same bits
+        // endpoint codes and indices of the scan's winner (the scan kept only its error): same fit, same quantiser,
+        // same bits, one selection pass
         int32_t bq[2][2][4];
+        {
+            HSeg sg0[2];
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-            float ep[2][4];
-            fit_subset<3, false, true>(ep, ln.tex, subset_mask(sh, j), ln.T);
-            quant_pair(bq[j], ep, ln);
+            for (int j = 0; j < 2; j++) {
+                float ep[2][4];
+                fit_subset<3, false, true>(ep, ln.tex, subset_mask(sh, j), ln.T);
+                quant_pair(bq[j], ep, ln);
+                sg0[j] = make_hseg(ep);
+            }
+            if (LEAN) (void)select_hdr<3, 2>(bqb, ln.tex, sg0, sh.pattern);
         }
-        if (berr == __builtin_inff())               // no candidate beat +inf (cannot happen: errors are finite); keep zeros
+        if (berr == __builtin_inff()) {             // no candidate beat +inf (cannot happen: errors are finite); keep zeros
             for (int j = 0; j < 2; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) bq[j][i][p] = 0;
+            bqb[0] = bqb[1] = 0u;
+        }
         for (int it = 0; it < refine; it++) {
             ln.tex.fence();
             HSeg sg[2];
@@ -522,8 +542,8 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
         rank_shapes32(ln);
         const int count = min(max(S.fastSkipTreshold, 0), 32);
         if (count > 0) {
-            scan_two_region(ln, true, 6, 0, count);
-            finish_two_region(ln, true, 6, 0, S.refineIterations_2p);
+            scan_two_region<true>(ln, true, 6, 0, count);
+            finish_two_region<true>(ln, true, 6, 0, S.refineIterations_2p);
         }
         encode_one_region(ln, true, S.refineIterations_1p);
     } else {                                                                            // [kernel.ispc:3086-3106]
@@ -540,8 +560,8 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
             rank_shapes32(ln);
             const int count = min(S.fastSkipTreshold, 32);
             const int nmodes = S.fast_mode ? 1 : 2;
-            scan_two_region(ln, false, nmodes, gated, count);
-            finish_two_region(ln, false, nmodes, gated, S.refineIterations_2p);
+            scan_two_region<false>(ln, false, nmodes, gated, count);
+            finish_two_region<false>(ln, false, nmodes, gated, S.refineIterations_2p);
         }
         enter_mode(ln, 10, 0.f);
         enter_mode(ln, 11, 1.f);
