@@ -262,7 +262,13 @@ __device__ __forceinline__ float select_hdr(uint32_t (&qb)[2], const TexF& px, c
         const float x = q * (float)LEVELS + 0.5f;
         int32_t q1 = iclamp((int32_t)x, 1, LEVELS - 1);
         q1 = (x < 2147483648.0f) ? q1 : 1;
-        const float w0 = (float)weight_of<BITS>(q1 - 1), w1 = (float)weight_of<BITS>(q1);
+        // the format's weights (q*128 + D) / (2*D), D = LEVELS - 1, = floor(q*64/D + 1/2): the fractional parts stay at least
+        // 0.03 away from an integer for every q of both index widths (checked in tests/test_exact_forms.py), so the float
+        // form is exact and costs a convert, two FMAs and two floors instead of two integer divisions and two converts
+        const float fq = (float)q1;
+        constexpr float STEP = 64.0f / (float)(LEVELS - 1);
+        const float w1 = __builtin_floorf(__builtin_fmaf(fq, STEP, 0.5f));
+        const float w0 = __builtin_floorf(__builtin_fmaf(fq, STEP, 0.5f - STEP));
         float err0 = 0.f, err1 = 0.f;
 #pragma unroll
         for (int p = 0; p < 3; p++) {

@@ -233,3 +233,20 @@ def test_f02_schedule_is_a_valid_cache_program():
             elif act == 1:
                 slots[slot] = sub[j]
     assert loads >= 46                                    # the point of the exercise: 48 of 192 with four slots
+
+
+def test_bc6h_float_weight_form_is_exact():
+    """bc6h.hip select_hdr: the interpolation weights (q*128 + D) / (2*D) of the format (D = 7, 15) computed as
+    floor(fma(q, 64/D, 1/2)) and, for the level below, floor(fma(q, 64/D, 1/2 - 64/D)) in fp32 -- equal for every q, with a
+    margin far above the rounding error of one fma."""
+    f = np.float32
+    for bits in (3, 4):
+        d = (1 << bits) - 1
+        step = f(64.0) / f(d)
+        for q in range(1, d + 1):
+            want1, want0 = (q * 128 + d) // (2 * d), ((q - 1) * 128 + d) // (2 * d)
+            x1 = float(f(q)) * float(step) + 0.5                     # the fma evaluates this exactly before one rounding
+            x0 = float(f(q)) * float(step) + float(f(0.5) - step)
+            assert int(np.floor(f(x1))) == want1 and int(np.floor(f(x0))) == want0, (bits, q)
+            for x in (x1, x0):
+                assert min(x - np.floor(x), np.ceil(x) - x) > 0.02 or x == np.floor(x), (bits, q, x)
