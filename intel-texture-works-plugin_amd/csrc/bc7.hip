@@ -974,13 +974,16 @@ __device__ __forceinline__ void load_win(Win& w, const uint4* __restrict__ wins,
 #ifndef SWR2
 #define SWR2 3
 #endif
+#ifndef SWR27
+#define SWR27 2
+#endif
 #ifndef FW
 #define FW 3
 #endif
 #ifndef FW456
 #define FW456 2
 #endif
-__host__ __device__ constexpr int search_waves(int family, int ranked) { return ranked == 2 ? SWR2 : ranked ? SWR : (family == F_MODE7 ? SW7 : (family == F_MODES02 ? SW02 : SW13)); }
+__host__ __device__ constexpr int search_waves(int family, int ranked) { return ranked == 2 ? (family == F_MODE7 ? SWR27 : SWR2) : ranked ? SWR : (family == F_MODE7 ? SW7 : (family == F_MODES02 ? SW02 : SW13)); }
 __host__ __device__ constexpr int finish_waves(int family) { return family == F_MODES13 ? FW : FW456; }
 
 template <int FAMILY, int RANKED, bool VEC16>
