@@ -215,9 +215,11 @@ struct HSeg {
 __device__ __forceinline__ HSeg make_hseg(const float (&e)[2][4])
 {
     HSeg s;
-    s.div = 0.f;
 #pragma unroll
-    for (int p = 0; p < 3; p++) { s.a[p] = e[0][p]; s.ba[p] = e[1][p] - e[0][p]; s.div += sq(s.ba[p]); }
+    for (int p = 0; p < 3; p++) { s.a[p] = e[0][p]; s.ba[p] = e[1][p] - e[0][p]; }
+    s.div = sq(s.ba[0]);                           // the reference's 0 + b0*b0: a square is never -0
+    s.div += sq(s.ba[1]);
+    s.div += sq(s.ba[2]);
     s.rdiv = 1.0f / s.div;
     return s;
 }
@@ -253,9 +255,11 @@ __device__ __forceinline__ float select_hdr(uint32_t (&qb)[2], const TexF& px, c
         float t[3];
 #pragma unroll
         for (int p = 0; p < 3; p++) t[p] = px.get(p, k);
-        float proj = 0.f;
+        // sums start from their first term: 0 + x differs from x only for x = -0, and a zero of either sign in `proj` gives
+        // x = 0.5 (or the same NaN when rdiv is inf) below; the error sums start from squares, which are never -0
+        float proj = (t[0] - s.a[0]) * s.ba[0];
 #pragma unroll
-        for (int p = 0; p < 3; p++) proj += (t[p] - s.a[p]) * s.ba[p];
+        for (int p = 1; p < 3; p++) proj += (t[p] - s.a[p]) * s.ba[p];
         float q = proj * s.rdiv;
         const float rem = __builtin_fmaf(-q, s.div, proj);
         q = __builtin_fmaf(rem, s.rdiv, q);
@@ -269,13 +273,13 @@ __device__ __forceinline__ float select_hdr(uint32_t (&qb)[2], const TexF& px, c
         constexpr float STEP = 64.0f / (float)(LEVELS - 1);
         const float w1 = __builtin_floorf(__builtin_fmaf(fq, STEP, 0.5f));
         const float w0 = __builtin_floorf(__builtin_fmaf(fq, STEP, 0.5f - STEP));
-        float err0 = 0.f, err1 = 0.f;
+        float err0, err1;
 #pragma unroll
         for (int p = 0; p < 3; p++) {
             const float d0 = s.a[p] + __builtin_floorf((w0 * s.ba[p] + 32.0f) * 0.015625f);
             const float d1 = s.a[p] + __builtin_floorf((w1 * s.ba[p] + 32.0f) * 0.015625f);
-            err0 += sq(d0 - t[p]);
-            err1 += sq(d1 - t[p]);
+            if (p == 0) { err0 = sq(d0 - t[p]); err1 = sq(d1 - t[p]); }
+            else        { err0 += sq(d0 - t[p]); err1 += sq(d1 - t[p]); }
         }
         float e;
         if (WANT_IDX) {
@@ -286,7 +290,8 @@ __device__ __forceinline__ float select_hdr(uint32_t (&qb)[2], const TexF& px, c
         } else {
             e = __builtin_fminf(err0, err1);
         }
-        total += (float)f2i_x86(e);
+        // (float)cvttps2dq(e) for a finite e >= 0: floor(e) below 2^31, INT_MIN above
+        total += (e < 2147483648.0f) ? __builtin_floorf(e) : -2147483648.0f;
     }
     return total;
 }
