@@ -725,9 +725,11 @@ __device__ __forceinline__ int32_t weight_single(int32_t q)                     
 // Integer-exact parts: decode (int)(((64-w)*e0 + w*e1 + 32)/64) = e0 + ((w*(e1-e0)+32) >> 6), squared errors,
 // and all sums of channel_opt_endpoints (<= 16*15*255).  The projection keeps the reference's fp32 form:
 // (v - e0) is exact, * rcp(e1 - e0 + 0.001f), * LEVELS (exact) + 0.5 (one FMA = two roundings here).
+// The LEVELS decoded values of a round are written once to the lane's own palette column in LDS and a texel reads its two
+// neighbouring levels: two weights, two multiplies and six integer adds/shifts per texel become one address and one read.
 template <int BITS, int EPBITS>
 __device__ __forceinline__ int32_t encode_scalar(uint32_t (&qb)[2], int32_t (&qe)[2], const Tex& tx, int rot_ch,
-                                                 const uint32_t (&vp)[4], int iters, const SeedTables& T)
+                                                 const uint32_t (&vp)[4], int iters, const SeedTables& T, uint2* lv)
 {
     constexpr int LEVELS = 1 << BITS;
     constexpr uint32_t LM1 = LEVELS - 1;
@@ -750,20 +752,39 @@ __device__ __forceinline__ int32_t encode_scalar(uint32_t (&qb)[2], int32_t (&qe
         err = 0;
         const int32_t span = de[1] - de[0];
         const float rspan = ispc_rcp((float)span + 0.001f, T);
+        // entry l of the lane's own palette column holds the float bits of levels (l, l + 1): one 8-byte read per texel
+        // (the column is the vector palette's, dead by now; same element type, so no type-based reordering against the
+        // next candidate's palette stores; other lanes' entries belong to waves that may be anywhere)
+        {
+            float lvl[LEVELS];
+#pragma unroll
+            for (int l = 0; l < LEVELS; l++) {
+                constexpr int D = LEVELS - 1;
+                const int32_t w = (l * 128 + D) / (2 * D);                       // the format's weight of level l (compile time)
+                lvl[l] = (float)((l == 0) ? de[0] : (l == D) ? de[1] : de[0] + ((w * span + 32) >> 6));
+            }
+#pragma unroll
+            for (int l = 0; l + 1 < LEVELS; l++) lv[l * TPB] = make_uint2(__float_as_uint(lvl[l]), __float_as_uint(lvl[l + 1]));
+        }
+        // texel values, decoded levels and their differences are integers below 2^8, squares and their sum stay below
+        // 2^24: the float forms below are exact, and fp32 mul / sub issue at twice the rate of the integer multiply
+        const float de0f = (float)de[0];
+        float errf = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const int32_t v = (int32_t)((tx.w[k] >> shift) & 255u);
-            const float proj = (float)(v - de[0]) * rspan;
+            // planar words hold texels {0,2,4,6} {1,3,5,7} {8,10,12,14} {9,11,13,15}: one v_cvt_f32_ubyteN each
+            const float vf = (float)((vp[(k >> 3) * 2 + (k & 1)] >> (8 * ((k & 7) >> 1))) & 255u);
+            const float proj = (vf - de0f) * rspan;                              // (float)(v - de0) of the reference, exact
             const int32_t q1 = imed3((int32_t)__builtin_fmaf(proj, (float)LEVELS, 0.5f), 1, LEVELS - 1);
-            const int32_t w0 = weight_single<BITS>(q1 - 1), w1 = weight_single<BITS>(q1);
-            const int32_t x0 = de[0] + ((w0 * span + 32) >> 6) - v;
-            const int32_t x1 = de[0] + ((w1 * span + 32) >> 6) - v;
-            const int32_t e0 = x0 * x0, e1 = x1 * x1;
+            const uint2 pr = lv[(q1 - 1) * TPB];
+            const float x0 = __uint_as_float(pr.x) - vf, x1 = __uint_as_float(pr.y) - vf;
+            const float e0 = x0 * x0, e1 = x1 * x1;
             const bool first = e0 < e1;
             const uint32_t q = (uint32_t)(first ? q1 - 1 : q1);
             if (k < 8) qb[0] |= q << (4 * k); else qb[1] |= q << (4 * (k - 8));
-            err += min(e0, e1);
+            errf += __builtin_fminf(e0, e1);
         }
+        err = (int32_t)errf;
         if (round >= iters) break;
         const uint32_t qn[4] = {qb[0] & 0x0f0f0f0fu, (qb[0] >> 4) & 0x0f0f0f0fu, qb[1] & 0x0f0f0f0fu, (qb[1] >> 4) & 0x0f0f0f0fu};
         uint32_t sq_ = 0, sqq = 0, ssum = 0, satb = 0;                           // channel_opt_endpoints
@@ -823,7 +844,7 @@ __device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const La
     uint32_t vsel[4];
     #pragma unroll
     for (int i = 0; i < 4; i++) vsel[i] = (rotation == 0) ? vp[i] : ((rotation == 1) ? vg[i] : ((rotation == 2) ? vb[i] : va[i]));
-    err += encode_scalar<ABITS, AEPB>(aqb, aq, ln.tx, rotation, vsel, S.refineIterations_channel, ln.T);
+    err += encode_scalar<ABITS, AEPB>(aqb, aq, ln.tx, rotation, vsel, S.refineIterations_channel, ln.T, ln.pal);
 
     if (err < best_err) {
         #pragma unroll
