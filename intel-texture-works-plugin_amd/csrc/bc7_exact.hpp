@@ -502,12 +502,13 @@ __device__ __forceinline__ int32_t texel_error_pal(const PalSegment& sg, const u
     constexpr int LEVELS = 1 << BITS;
     int32_t n;
     if (CH == 4) n = dot2(t01, sg.ba01, dot2(t23, sg.ba23, sg.nc));
-    else         n = dot2(t01, sg.ba01, (int32_t)t23 * (int32_t)sg.ba23 + sg.nc);
+    else         n = dot2(t01, sg.ba01, __mul24((int32_t)t23, (int32_t)sg.ba23) + sg.nc);     // |t23|, |ba23| <= 255
     const float x = __builtin_fmaf((float)n, sg.k0, sg.k1);
     const int32_t q1 = imed3((int32_t)x, 1, LEVELS - 1);
     const uint2* p = pal + (q1 - 1) * PAL_STRIDE;
     const uint2 lo = p[0], hi = p[PAL_STRIDE];
-    const int32_t f0 = (int32_t)((udot4(lo.x, w, 0u) << 1) + lo.y), f1 = (int32_t)((udot4(hi.x, w, 0u) << 1) + hi.y);
+    const uint32_t d0 = udot4(lo.x, w, 0u), d1 = udot4(hi.x, w, 0u);
+    const int32_t f0 = (int32_t)((d0 << 1) + lo.y), f1 = (int32_t)((d1 << 1) + hi.y);
     return max(f0, f1);                                                     // = -(error - |t|^2) of the better level
 }
 
@@ -521,18 +522,39 @@ __device__ __forceinline__ void subset_error_pal(int32_t& total, const Tex& tx, 
             total -= texel_error_pal<BITS, CH, PAL_STRIDE>(sg, pal, tx.w[k], tx.pair01(k), tx.template pair23<CH == 4>(k));
 }
 
+// Two palettes (the two modes of a family) against one texel, staged so that the four dot products sit side by side: a
+// texel is its own basic block here (scalar branches on the subset mask), so the only instruction-level parallelism the
+// scheduler finds is what one texel offers, and a dot product followed at once by its consumer costs wait states.
+template <int BITSA, int BITSB, int CH, int PAL_STRIDE>
+__device__ __forceinline__ void texel_error2_pal(int32_t& ta, int32_t& tc, const PalSegment& sa, const uint2* pa,
+                                                 const PalSegment& sc, const uint2* pc, uint32_t w, uint32_t t01, uint32_t t23)
+{
+    int32_t na, nb;
+    if (CH == 4) { na = dot2(t01, sa.ba01, dot2(t23, sa.ba23, sa.nc)); nb = dot2(t01, sc.ba01, dot2(t23, sc.ba23, sc.nc)); }
+    else {                                                                  // 24-bit multiply-add: |t23| <= 255, |ba23| <= 255
+        na = dot2(t01, sa.ba01, __mul24((int32_t)t23, (int32_t)sa.ba23) + sa.nc);
+        nb = dot2(t01, sc.ba01, __mul24((int32_t)t23, (int32_t)sc.ba23) + sc.nc);
+    }
+    const float xa = __builtin_fmaf((float)na, sa.k0, sa.k1), xb = __builtin_fmaf((float)nb, sc.k0, sc.k1);
+    const int32_t qa = imed3((int32_t)xa, 1, (1 << BITSA) - 1), qb = imed3((int32_t)xb, 1, (1 << BITSB) - 1);
+    const uint2* p0 = pa + (qa - 1) * PAL_STRIDE;
+    const uint2* p1 = pc + (qb - 1) * PAL_STRIDE;
+    const uint2 la = p0[0], ha = p0[PAL_STRIDE], lb = p1[0], hb = p1[PAL_STRIDE];
+    const uint32_t d0 = udot4(la.x, w, 0u), d1 = udot4(ha.x, w, 0u), d2 = udot4(lb.x, w, 0u), d3 = udot4(hb.x, w, 0u);
+    const int32_t f0 = (int32_t)((d0 << 1) + la.y), f1 = (int32_t)((d1 << 1) + ha.y);
+    const int32_t f2 = (int32_t)((d2 << 1) + lb.y), f3 = (int32_t)((d3 << 1) + hb.y);
+    ta -= max(f0, f1);
+    tc -= max(f2, f3);
+}
+
 template <int BITSA, int BITSB, int CH, int PAL_STRIDE>
 __device__ __forceinline__ void subset_error2_pal(int32_t& ta, int32_t& tc, const Tex& tx, const PalSegment& sa, const uint2* pa,
                                                   const PalSegment& sc, const uint2* pc, uint32_t mask)
 {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        if ((mask >> k) & 1u) {
-            const uint32_t t01 = tx.pair01(k), t23 = tx.template pair23<CH == 4>(k);
-            ta -= texel_error_pal<BITSA, CH, PAL_STRIDE>(sa, pa, tx.w[k], t01, t23);
-            tc -= texel_error_pal<BITSB, CH, PAL_STRIDE>(sc, pc, tx.w[k], t01, t23);
-        }
-    }
+    for (int k = 0; k < 16; k++)
+        if ((mask >> k) & 1u)
+            texel_error2_pal<BITSA, BITSB, CH, PAL_STRIDE>(ta, tc, sa, pa, sc, pc, tx.w[k], tx.pair01(k), tx.template pair23<CH == 4>(k));
 }
 
 // Texels of one subset (wave-uniform mask) against one or two palettes; accumulates errors WITHOUT the |t|^2 terms.
