@@ -17,10 +17,14 @@
 //     (proofs in bc7_exact.hpp).  What can round (PCA, endpoint quantisation, the 2x2
 //     solve) is fp32 with the pinned x86 arithmetic;
 //   * per multi-subset mode family ({0,2} {1,3} {7}) a SEARCH kernel (the scan of the
-//     shapes, 112-128 VGPRs, 4 waves per SIMD) and a FINISH kernel (refinement of the
+//     shapes, 110-128 VGPRs, 4 waves per SIMD) and a FINISH kernel (refinement of the
 //     winners, per-lane shapes); modes 4/5/6 are one kernel.  Families run in the
 //     reference's order and only communicate through "best error so far"
 //     (kernel.ispc:1358, 1638, 1684) and the search winners, in a 36 B/block workspace;
+//   * the scans produce a candidate's ERROR and nothing else: the level a texel takes
+//     and the packed indices matter for a mode's winner alone, so the winner record is
+//     {error, shape} and the finish kernel recomputes endpoints and indices of the
+//     winner (same inputs, same bits) before refining it;
 //   * shapes are visited in a wave-uniform order wherever the candidate list is the
 //     whole table (modes 0/2 always; modes 1/3/7 when their fastSkipTreshold is >= 64,
 //     the `slow` profiles): subset masks are scalars, a texel costs work only in the
@@ -32,8 +36,9 @@
 //     subsets use 140 masks, so the scan follows a generated schedule that clusters
 //     equal masks and reloads results from a four-entry register cache;
 //   * shorter ranked lists (fast profiles) keep the per-lane order: the i-th entry of
-//     the reference's selection sort (kernel.ispc:1365-1384) is the smallest key above
-//     the previous one -- a 64-entry LDS scan, no sort, no dynamic register indexing;
+//     the reference's selection sort (kernel.ispc:1365-1384) is the i-th smallest key --
+//     the 16 smallest are kept sorted in registers while the keys are produced (every
+//     preset; longer custom lists scan 64 keys in LDS), no dynamic register indexing;
 //   * fits that do not depend on the mode are shared: shapes 64..79 serve modes 0 and
 //     2, every two-subset shape serves modes 1 and 3 (kernel.ispc:1286-1291), the last
 //     subset's moments are the block's minus the others' (exact), one rotation's fit
