@@ -93,8 +93,8 @@ __device__ __forceinline__ void refit_endpoints(int32_t pe[2], const float (&px)
         for (int p = 0; p < 3; p++) {
             const float sum = dc[p] * 16.0f;
             const float atb2 = 3.0f * sum - atb1[p];
-            c0[p] = fclamp_x86((atb1[p] * cyy - atb2 * cxy) * scale, 0.f, 255.f);
-            c1[p] = fclamp_x86((atb2 * cxx - atb1[p] * cxy) * scale, 0.f, 255.f);
+            c0[p] = fclamp_num((atb1[p] * cyy - atb2 * cxy) * scale, 0.f, 255.f);
+            c1[p] = fclamp_num((atb2 * cxx - atb1[p] * cxy) * scale, 0.f, 255.f);
         }
     }
     pe[0] = pack565(c0[0], c0[1], c0[2]);
@@ -156,8 +156,8 @@ __device__ __forceinline__ void encode_color(const float (&px)[3][16], uint32_t 
 
     float e0[3], e1[3];
     for (int p = 0; p < 3; p++) {
-        e0[p] = fclamp_x86(dc[p] + lo * rn * v[p], 0.f, 255.f);
-        e1[p] = fclamp_x86(dc[p] + hi * rn * v[p], 0.f, 255.f);
+        e0[p] = fclamp_num(dc[p] + lo * rn * v[p], 0.f, 255.f);
+        e1[p] = fclamp_num(dc[p] + hi * rn * v[p], 0.f, 255.f);
     }
 
     int32_t pe[2];
@@ -181,7 +181,7 @@ __device__ __forceinline__ void encode_alpha(const float (&a)[16], uint32_t out[
 {
     float lo = 255.f, hi = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo = fmin_x86(lo, a[k]); hi = fmax_x86(hi, a[k]); }
+    for (int k = 0; k < 16; k++) { lo = __builtin_fminf(lo, a[k]); hi = __builtin_fmaxf(hi, a[k]); }   // minps / maxps of ordinary numbers (bytes)
     if (lo == hi) hi = lo + 0.1f;
     const float scale = 7.0f * ispc_rcp(hi - lo, T);
 

@@ -105,7 +105,7 @@ __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4
             for (int p = 0; p < 4; p++) {
                 const float t = e[i][p] * INV255 * (float)L2;
                 const float v0 = __builtin_floorf(t * 0.5f + 0.5f) * 2.0f;
-                db[0][p] = (v0 < (float)(L2 - 1)) ? v0 : (float)(L2 - 1);
+                db[0][p] = __builtin_fminf(v0, (float)(L2 - 1));                   // v0 is an ordinary number here (SAFE)
                 db[1][p] = __builtin_floorf(t * 0.5f) * 2.0f + 1.0f;       // (t-1)/2 + 1/2 = t/2 exactly for t >= 0.5, floor 0 below
             }
             float err0 = 0.f, err1 = 0.f;
@@ -807,8 +807,8 @@ __device__ __forceinline__ int32_t encode_scalar(uint32_t (&qb)[2], int32_t (&qe
         const float cxy = L1 * sum_q - sum_qq;
         const float det = cxx * cyy - cxy * cxy;
         const float scale = L1 * ispc_rcp(det, T);
-        ep[0] = fclamp_x86((atb1 * cyy - atb2 * cxy) * scale, 0.f, 255.f);
-        ep[1] = fclamp_x86((atb2 * cxx - atb1 * cxy) * scale, 0.f, 255.f);
+        ep[0] = fclamp_num((atb1 * cyy - atb2 * cxy) * scale, 0.f, 255.f);
+        ep[1] = fclamp_num((atb2 * cxx - atb1 * cxy) * scale, 0.f, 255.f);
         if (fabsf(det) < 0.001f) { ep[0] = sum * 0.0625f; ep[1] = ep[0]; }
     }
     return err;

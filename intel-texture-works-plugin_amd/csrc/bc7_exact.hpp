@@ -238,8 +238,8 @@ __device__ __forceinline__ void fit_line(float (&ep)[2][4], const Tex& tx, uint3
     if (hi - lo < 1.0f) { lo -= 0.5f; hi += 0.5f; }
 #pragma unroll
     for (int p = 0; p < CH; p++) {
-        ep[0][p] = fclamp_x86(lo * axis[p] + dc[p], 0.f, 255.f);
-        ep[1][p] = fclamp_x86(hi * axis[p] + dc[p], 0.f, 255.f);
+        ep[0][p] = fclamp_num(lo * axis[p] + dc[p], 0.f, 255.f);
+        ep[1][p] = fclamp_num(hi * axis[p] + dc[p], 0.f, 255.f);
     }
 }
 

@@ -142,6 +142,11 @@ __device__ __forceinline__ int32_t cvt_i32_sat(float f)
 __device__ __forceinline__ float fmin_x86(float a, float b) { return (a < b) ? a : b; }
 __device__ __forceinline__ float fmax_x86(float a, float b) { return (a > b) ? a : b; }
 __device__ __forceinline__ float fclamp_x86(float v, float lo, float hi) { return fmin_x86(fmax_x86(v, lo), hi); }
+// The same clamp for bounds that are ordinary numbers (lo < hi): maxps(v, lo) returns lo for a NaN v, exactly like
+// v_max_f32 (maxNum), and is an ordinary maximum otherwise; its result is never NaN, so the minps that follows is an
+// ordinary minimum too.  Two instructions instead of two compare / wait / select triples.  (Only the sign of a zero
+// result can differ -- v = -0 against lo = +0 -- and every caller converts or squares the result.)
+__device__ __forceinline__ float fclamp_num(float v, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(v, lo), hi); }
 
 __device__ __forceinline__ int32_t iclamp(int32_t v, int32_t lo, int32_t hi) { return min(max(v, lo), hi); }
 __device__ __forceinline__ float sq(float v) { return v * v; }
