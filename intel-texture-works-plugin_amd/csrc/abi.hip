@@ -54,21 +54,27 @@ struct ThreadCtx {
 };
 thread_local ThreadCtx tls;
 
-void ensure_device_ctx()
+// Per-thread resources belong to the device they were created on: a host thread that switches devices (hipSetDevice)
+// drops them and starts over.
+void bind_thread_to_current_device()
 {
     int dev = 0;
     ITW_CHECK(hipGetDevice(&dev));
-    if (tls.device != dev) {
-        // buffers belong to the device they were allocated on
-        if (tls.d_in)  { (void)hipFree(tls.d_in);  tls.d_in = nullptr;  tls.in_cap = 0; }
-        if (tls.d_out) { (void)hipFree(tls.d_out); tls.d_out = nullptr; tls.out_cap = 0; }
-        if (tls.d_ws)  { (void)hipFree(tls.d_ws);  tls.d_ws = nullptr;  tls.ws_cap = 0; tls.ws_used = false; }
-        if (tls.own_stream) { (void)hipStreamDestroy(tls.own_stream); tls.own_stream = nullptr; }
-        if (tls.copy_stream) { (void)hipStreamDestroy(tls.copy_stream); tls.copy_stream = nullptr; }
-        for (auto& e : tls.ev_in) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-        for (auto& e : tls.ev_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-        tls.device = dev;
-    }
+    if (tls.device == dev) return;
+    if (tls.d_in)  { (void)hipFree(tls.d_in);  tls.d_in = nullptr;  tls.in_cap = 0; }
+    if (tls.d_out) { (void)hipFree(tls.d_out); tls.d_out = nullptr; tls.out_cap = 0; }
+    if (tls.d_ws)  { (void)hipFree(tls.d_ws);  tls.d_ws = nullptr;  tls.ws_cap = 0; tls.ws_used = false; }
+    if (tls.own_stream) { (void)hipStreamDestroy(tls.own_stream); tls.own_stream = nullptr; }
+    if (tls.copy_stream) { (void)hipStreamDestroy(tls.copy_stream); tls.copy_stream = nullptr; }
+    for (auto& e : tls.ev_in) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (auto& e : tls.ev_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    tls.device = dev;
+}
+
+// staging path: streams and events of this thread, created on first use
+void ensure_device_ctx()
+{
+    bind_thread_to_current_device();
     if (!tls.own_stream) ITW_CHECK(hipStreamCreateWithFlags(&tls.own_stream, hipStreamNonBlocking));
     if (!tls.copy_stream) ITW_CHECK(hipStreamCreateWithFlags(&tls.copy_stream, hipStreamNonBlocking));
     for (auto& e : tls.ev_in) if (!e) ITW_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -107,18 +113,7 @@ struct Job {
 // of stream waits for the previous one; calls on one stream are ordered by the stream itself.
 float* bc7_workspace(int w, int h, hipStream_t st)
 {
-    int dev = 0;
-    ITW_CHECK(hipGetDevice(&dev));
-    if (tls.device != dev) {
-        if (tls.d_in)  { (void)hipFree(tls.d_in);  tls.d_in = nullptr;  tls.in_cap = 0; }
-        if (tls.d_out) { (void)hipFree(tls.d_out); tls.d_out = nullptr; tls.out_cap = 0; }
-        if (tls.d_ws)  { (void)hipFree(tls.d_ws);  tls.d_ws = nullptr;  tls.ws_cap = 0; tls.ws_used = false; }
-        if (tls.own_stream) { (void)hipStreamDestroy(tls.own_stream); tls.own_stream = nullptr; }
-        if (tls.copy_stream) { (void)hipStreamDestroy(tls.copy_stream); tls.copy_stream = nullptr; }
-        for (auto& e : tls.ev_in) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-        for (auto& e : tls.ev_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
-        tls.device = dev;
-    }
+    bind_thread_to_current_device();
     if (tls.ws_used && tls.ws_stream != st) ITW_CHECK(hipStreamSynchronize(tls.ws_stream));
     float* ws = (float*)grow(tls.d_ws, tls.ws_cap, itw::bc7_workspace_bytes(w, h));
     tls.ws_stream = st; tls.ws_used = true;
