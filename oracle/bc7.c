@@ -386,7 +386,7 @@ float block_quant(uint32_t qblock[2], const float block[64], int bits, const flo
             div += sqf(ep_b - ep_a);
         }
 
-        proj /= div;                                  /* :1158 true IEEE divide */
+        proj = ORACLE_DIV_1158(proj, div);            /* :1158 true IEEE divide in the pinned model (x86_math.h) */
 
         int32_t q1 = f2i_x86(proj * (float)levels + 0.5f);
         q1 = iclamp(q1, 1, levels - 1);

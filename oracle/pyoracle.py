@@ -47,12 +47,8 @@ def build(force=False):
 _lib = None
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
-        L = C.CDLL(_LIB_PATH)
+def _bind(path):
+        L = C.CDLL(path)
         for n in ("oracle_rcp", "oracle_rsqrt", "oracle_rcpps", "oracle_rsqrtps"):
             getattr(L, n).restype = C.c_float
             getattr(L, n).argtypes = [C.c_float]
@@ -76,8 +72,47 @@ def lib():
         for n in ("oracle_CompressBlocksBC4", "oracle_CompressBlocksBC5", "oracle_bc4_block", "oracle_decode_bc4_float"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
             getattr(L, n).restype = None
-        _lib = L
+        return L
+
+
+def lib():
+    global _lib
+    if _override is not None:
+        return _override
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = _bind(_LIB_PATH)
     return _lib
+
+
+# Arithmetic-model variants of the oracle (x86_math.h switches; `make -C oracle variants`).  Study material only
+# (tools/arith_sensitivity.py, tests/test_arith_models.py): parity is always against the default model.
+VARIANTS = ("div1158rcp", "ieee", "fma", "ieee_fma")
+_override = None
+_variant_libs = {}
+
+
+class variant:
+    """`with pyoracle.variant("ieee"): pyoracle.encode(...)` -- run the oracle under another arithmetic model."""
+
+    def __init__(self, name):
+        assert name in VARIANTS, name
+        self.name = name
+
+    def __enter__(self):
+        global _override
+        if self.name not in _variant_libs:
+            path = os.path.join(_HERE, "_variants", f"liboracle_bcn_{self.name}.so")
+            if not os.path.exists(path):
+                subprocess.run(["make", "-C", _HERE, "-s", "variants"], check=True)
+            _variant_libs[self.name] = _bind(path)
+        self._saved, _override = _override, _variant_libs[self.name]
+        return self
+
+    def __exit__(self, *exc):
+        global _override
+        _override = self._saved
 
 
 def has(symbol):

@@ -59,6 +59,27 @@ static inline float x86_rsqrtps(float v)
     return xm_u2f(t - ((uint32_t)k << 23));
 }
 
+/*
+ * ---- arithmetic-model switches: STUDY ONLY (`make -C oracle variants`) ---------------------------
+ * The default build (no switch) is the pinned model every parity test uses.  The three assumptions nobody can verify
+ * without an ispc binary each get a compile-time switch so that their weight can be MEASURED
+ * (tools/arith_sensitivity.py -> profiles/arith_sensitivity.txt):
+ *   ORACLE_MODEL_DIV1158_RCP  `proj /= div` (kernel.ispc:1158) lowered like every other division: proj * rcp(div)
+ *   ORACLE_MODEL_IEEE         rcp(v) = 1.0f/v, rsqrt(v) = 1.0f/sqrtf(v) (correctly rounded, no table seeds, no Newton)
+ *   -ffp-contract=fast -mfma  (a compiler flag, not a macro) the avx2 target's licence to fuse a*b+c
+ *                             (IntelTextureWorks.vcxproj:388 builds sse2,sse4,avx,avx2); which sums gcc fuses need
+ *                             not be the ones ispc/LLVM would fuse -- the variant measures sensitivity, not a target.
+ */
+#ifdef ORACLE_MODEL_DIV1158_RCP
+#define ORACLE_DIV_1158(proj, div) ((proj) * ispc_rcp(div))
+#else
+#define ORACLE_DIV_1158(proj, div) ((proj) / (div))          /* true IEEE divide */
+#endif
+
+#ifdef ORACLE_MODEL_IEEE
+static inline float ispc_rcp(float v)   { return 1.0f / v; }
+static inline float ispc_rsqrt(float v) { return 1.0f / sqrtf(v); }
+#else
 /* ISPC stdlib rcp()/rsqrt() on the sse/avx targets: seed + one Newton step */
 static inline float ispc_rcp(float v)
 {
@@ -77,6 +98,7 @@ static inline float ispc_rsqrt(float v)
     a = is * a;
     return 0.5f * a;
 }
+#endif
 
 /* cvttss2si */
 static inline int32_t f2i_x86(float f)
