@@ -5,15 +5,19 @@ One "step" = one pass of the hot path over one synthetic surface resident in HBM
 the drop-in C ABI with device pointers (kernel only; no PCIe in the timed region), plus -- when world_size > 1 --
 the gather of the per-GPU output bands (the path's only exchange step).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bc7_slow] [--size 4096]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload bc7_slow] [--size S] [--scaling weak|strong]
 
 N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-(one process per GPU, RCCL).  Sharding is by block-row bands: rank r owns band r of a (size*N) x size surface, so
-per-GPU work is fixed ("weak").  Rank 0 prints ONE JSON line.
+(one process per GPU, RCCL).  Sharding is by block-row bands (itwBandForPart).  Rank 0 prints ONE JSON line.
 
-Headline workload (default): BC7 `GetProfile_slow` on synthetic 4096x4096 RGBA8 -- BASELINE.json configs[2], the
-configuration north_star's target is quoted on.  The same line carries `formats`: short measurements of
-BC1 / BC3 / BC6H on the same size (configs[1], [3]) each with its own HBM roofline.
+  N = 1 (default)  BC7 `GetProfile_slow` on synthetic 4096x4096 RGBA8 -- BASELINE.json configs[2], the configuration
+                   north_star's target is quoted on.  The same line carries `formats`: short measurements of
+                   BC1 / BC3 / BC6H on the same size (configs[1], [3]) each with its own HBM roofline.
+  N > 1 (default)  BASELINE.json configs[4]: ONE 16384x16384 RGBA8 surface (I5 = the 4096^2 surface tiled 4x4), BC7 slow,
+                   strong-sharded: rank r encodes band r of the N bands, the output bands are all-gathered over xGMI
+                   ("scaling": "strong"; --size 16384 --scaling strong at N = 1 runs the whole surface on one GPU).
+                   A short weak-scaling figure (one 4096^2 band per rank) rides along as `weak_side`.
+  --scaling weak   rank r owns band r of a size x (size*N) surface: per-GPU work fixed.
 
 cpu_baseline: the scalar C oracle (oracle/, test infrastructure) timed on this box's host cores on a bounded sample,
 rank 0, N=1 only.  It is a *port* (scalar restatement), not ISPC SIMD code: the reference cannot be built here.
@@ -52,6 +56,32 @@ def make_surface(fmt, size, rank):
     if fmt == "bc6h":
         return surfaces.hdr_smooth(size, size, seed=surfaces.SEED + 3 + 100 * rank)
     return surfaces.ldr_smooth(size, size, seed=surfaces.SEED + 100 * rank)
+
+
+def plan(scaling, size, world, rank, fmt):
+    """Geometry of the job and of this rank's share.  Pure (no GPU): tests/test_sharding_gloo.py checks it.
+    weak  : surface = size wide x (size * world) tall, rank r owns the r-th size x size band.
+    strong: surface = size x size (BASELINE configs[4] at size 16384), rank r owns block rows [R*r/N, R*(r+1)/N).
+    Returns dict(width, height, y0, rows, band_off, band_bytes, total_bytes)."""
+    from itw_amd import shard, abi
+    width, height = (size, size * world) if scaling == "weak" else (size, size)
+    y0, rows, off, nbytes = shard.band_of(width, height, fmt, rank, world)
+    total = (width // 4) * (height // 4) * abi.BYTES_PER_BLOCK[fmt]
+    return {"width": width, "height": height, "y0": y0, "rows": rows, "band_off": off, "band_bytes": nbytes, "total_bytes": total}
+
+
+def make_band(fmt, scaling, size, geo, rank):
+    """Texels of this rank's band.  weak: an independent size x size surface per rank.  strong: rows [y0, y0+rows) of
+    I5 = the 4096^2 synthetic surface tiled up to size x size -- every rank derives them from the same
+    seeded base, so the job is one well-defined image and no scatter is timed (synthetic data)."""
+    from itw_amd import surfaces
+    if scaling == "weak" or size <= 4096:
+        img = make_surface(fmt, size, rank if scaling == "weak" else 0)
+        return np.ascontiguousarray(img[geo["y0"]:geo["y0"] + geo["rows"]]) if scaling == "strong" else img
+    base = make_surface(fmt, 4096, 0)
+    rows = (np.arange(geo["y0"], geo["y0"] + geo["rows"]) % 4096)
+    cols = (np.arange(geo["width"]) % 4096)
+    return np.ascontiguousarray(base[rows][:, cols])
 
 
 def time_kernel(itw, fmt, prof, d_img, d_out, steps, warmup):
@@ -103,6 +133,26 @@ def cpu_baseline(fmt, prof, img, budget_s=15.0):
             "sample": f"first {rows} of {h} texel rows of the same {w}x{h} surface, {reps} x {dt:.3f} s, "
                       f"scalar C oracle (not ISPC SIMD), {cores} threads (= usable cores: min of cpu_count "
                       f"{os.cpu_count()}, affinity, cgroup quota), reference band rule; cpu: {model}"}
+
+
+def cpu_baseline_pair(fmt, prof, img, budget_s=2.0):
+    """Mpixels/s of the scalar C oracle on a small sample, 1 thread and all usable threads (side formats)."""
+    from oracle import pyoracle            # checker / baseline leg only
+    cores = pyoracle.usable_cores()
+    h, w = img.shape[:2]
+    out = {"unit": "Mpixels/s", "kind": "port", "cores": cores}
+    for label, n in (("threads_1", 1), ("threads_all", cores)):
+        rows = min(h, max(4 * n, 16))
+        t0 = time.perf_counter()
+        pyoracle.encode_mt(fmt, img[:rows], prof, threads=n)
+        dt = max(time.perf_counter() - t0, 1e-4)
+        rows = int(min(h, max(rows, rows * budget_s / dt))) // 4 * 4
+        t0 = time.perf_counter()
+        pyoracle.encode_mt(fmt, img[:rows], prof, threads=n)
+        dt = time.perf_counter() - t0
+        out[label] = round(rows * w / dt / 1e6, 3)
+    out["sample"] = f"up to {h} rows of a {w}-wide synthetic surface, ~{budget_s:.0f} s per leg, scalar C oracle (not ISPC SIMD)"
+    return out
 
 
 def pmc_valu(workload):
@@ -160,7 +210,9 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="bc7_slow", choices=sorted(WORKLOADS))
-    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--size", type=int, default=None, help="surface edge; default 4096 (N = 1 / weak) or 16384 (strong, N > 1)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong when N > 1 (BASELINE configs[4]: one 16384^2 surface sharded over the ranks), else weak")
     ap.add_argument("--no-formats", action="store_true", help="skip the side measurements of the other formats")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
@@ -187,65 +239,73 @@ def main():
     heavy = fmt in ("bc7", "bc6h")
     steps = args.steps if args.steps is not None else (10 if heavy else 50)
     warmup = args.warmup if args.warmup is not None else (2 if heavy else 5)
-    size = args.size
 
     from itw_amd import shard
-    # The job: one (size*world) x size surface, sharded by block-row bands (itwBandForPart); rank r holds and encodes
-    # band r (its texels are generated locally -- synthetic data -- so no scatter is timed), then the compressed
-    # bands are all-gathered so every rank ends with the whole-image block stream.
-    y0, rows, band_off, band_bytes = shard.band_of(size, size * world, fmt, rank, world)
-    assert rows == size and y0 == rank * size
-    img = make_surface(fmt, size, rank)
-    d_img = torch.from_numpy(img).to(dev)
-    bx = size // 4
-    nblocks = bx * bx
-    assert band_off == rank * band_bytes
-    # Every step = encode of this rank's band + all-gather of the output bands over xGMI (RCCL; equal bands, in place).
-    # The gather of step i runs on RCCL's stream while step i+1 encodes (two whole-image buffers, shard.BandPipeline);
-    # all gathers are waited for inside the timed region.
-    pipe = shard.BandPipeline(band_bytes, world, rank, dev, lambda out: itw_amd.compress(fmt, d_img, prof, out=out))
-    d_band = pipe.band[0]
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    size = args.size or (16384 if (scaling == "strong" and world > 1) else 4096)
 
-    for _ in range(warmup):
-        pipe.step()
-    pipe.drain()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        pipe.step()
-    pipe.drain()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run_job(scaling, size, steps, warmup):
+        """One timed job: every step = encode of this rank's band + all-gather of the output bands over xGMI (RCCL; in
+        place).  The gather of step i runs on RCCL's stream while step i+1 encodes (two whole-image buffers,
+        shard.BandPipeline); all gathers are waited for inside the timed region.  Returns (elapsed_s max over ranks, ...)."""
+        geo = plan(scaling, size, world, rank, fmt)
+        img = make_band(fmt, scaling, size, geo, rank)
+        assert img.shape[0] == geo["rows"] and img.shape[1] == geo["width"]
+        d_img = torch.from_numpy(img).to(dev)
+        equal = geo["band_bytes"] * world == geo["total_bytes"]
+        assert equal, "bench bands must be equal (in-place all-gather): pick a size whose block rows divide by N"
+        assert geo["band_off"] == rank * geo["band_bytes"]
+        pipe = shard.BandPipeline(geo["band_bytes"], world, rank, dev, lambda out: itw_amd.compress(fmt, d_img, prof, out=out))
+        for _ in range(warmup):
+            pipe.step()
+        pipe.drain()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pipe.step()
+        pipe.drain()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, geo, img, d_img, pipe
+
+    elapsed, geo, img, d_img, pipe = run_job(scaling, size, steps, warmup)
+    d_band = pipe.band[0]
+    nblocks = (geo["width"] // 4) * (geo["rows"] // 4)          # blocks this rank encodes per step
 
     # kernel-only duration on the launch stream (HIP events), for the roofline
     k_avg_ms, k_min_ms = time_kernel(itw_amd, fmt, prof, d_img, d_band, steps=max(3, min(steps, 20)), warmup=1)
 
     result = None
     if rank == 0:
-        pixels = size * size * world
+        pixels = geo["width"] * geo["height"]                  # the whole job per step, all ranks
         alg = ALG_BYTES[fmt] * nblocks
         achieved = alg / (k_avg_ms * 1e-3) / 1e9
         result = {
-            "metric": "Mpixels/s encode (BC1/BC3/BC7/BC6H) at 4k x 4k; bit-exact vs pinned-arithmetic oracle",
+            "metric": "Mpixels/s encode (BC1/BC3/BC7/BC6H) at 4k x 4k; bit-exact vs the oracle under the pinned ISPC sse/avx-target "
+                      "arithmetic model (no ispc binary exists here; sensitivity of that model: profiles/arith_sensitivity.txt)",
             "value": round(pixels * steps / elapsed / 1e6, 2), "unit": "Mpixels/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {fmt.upper()}" + (f" GetProfile_{prof}" if prof else "")
-                       + f" on synthetic {size}x{size} " + ("RGBA16F" if fmt == "bc6h" else "RGBA8")
-                       + " per GPU, surfaces resident in HBM, device-pointer C ABI call",
-                       "blocks_per_gpu": nblocks, "sharding": "block-row bands, one per rank; all_gather of output bands, overlapped with the next step's encode"
-                       if world > 1 else "single GPU", "device": itw_amd.device_info(), "lib": itw_amd.version()},
+                       + f" on ONE synthetic {geo['width']}x{geo['height']} " + ("RGBA16F" if fmt == "bc6h" else "RGBA8")
+                       + f" surface, {scaling}-sharded over {world} GPU(s) by block-row bands ({geo['rows']} texel rows per rank), "
+                         "texels resident in HBM, device-pointer C ABI call",
+                       "blocks_per_gpu": nblocks, "sharding": "block-row bands, one per rank (itwBandForPart); all_gather of output bands over "
+                       "RCCL, overlapped with the next step's encode" if world > 1 else "single GPU",
+                       "ranks_seen_by_rccl": (dist.get_world_size() if dist is not None else 1),
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist is not None else None),
+                       "device": itw_amd.device_info(), "lib": itw_amd.version()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(args.workload),
                          "kernel_ms_avg": round(k_avg_ms, 4), "kernel_ms_min": round(k_min_ms, 4),
@@ -254,12 +314,12 @@ def main():
                                  "because the contract asks for it; `valu` is the roofline that binds (DESIGN.md 3)"},
         }
         rk = rocprof_kernels(fmt)
-        if rk and world == 1 and size == 4096:
+        if rk and world == 1 and size == 4096 and scaling == "weak":
             # the call is several kernels for BC7; `achieved` uses the whole call.  For the slow / alpha_slow profiles the
             # kernels listed are exactly the call's (the ranked variants <.., 1|2, ..> belong to the faster presets).
             result["roofline"]["rocprof_kernels"] = rk
         insts = pmc_valu(args.workload)
-        if insts and world == 1 and size == 4096:
+        if insts and world == 1 and size == 4096 and scaling == "weak":
             lane_ops = insts * 64 / (k_avg_ms * 1e-3) / 1e12
             result["roofline"]["valu"] = {
                 "achieved": round(lane_ops, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": round(lane_ops / VALU_PEAK_TOPS, 4),
@@ -268,7 +328,21 @@ def main():
                         "x 32 lanes x 2.4 GHz, reached only by the 2-cycle VOP2 forms (v_mul/add_f32, v_add_u32, logic, shifts right); "
                         "cvt / cmp / fma / packed / dot forms issue at half that rate (tools/ubench)"}
 
-    if rank == 0 and world == 1 and not args.no_formats:
+    if world > 1 and scaling == "strong":
+        # side figure: weak scaling, one 4096^2 band per rank (what round 1 reported); a few steps only
+        del d_img, pipe
+        torch.cuda.empty_cache()
+        w_steps = max(3, min(steps, 5))
+        w_elapsed, w_geo, _, _, w_pipe = run_job("weak", 4096, w_steps, 1)
+        if rank == 0:
+            result["weak_side"] = {"value": round(w_geo["width"] * w_geo["height"] * w_steps / w_elapsed / 1e6, 2), "unit": "Mpixels/s",
+                                   "ms_per_step": round(w_elapsed / w_steps * 1e3, 4), "steps": w_steps,
+                                   "workload": f"{args.workload} on a 4096 x {4096 * world} surface, one 4096^2 band per rank"}
+        del w_pipe
+
+    size_side = 4096
+    if rank == 0 and world == 1 and not args.no_formats and size == 4096:
+        size, nblocks = size_side, (size_side // 4) ** 2
         side = {}
         for wl in ("bc1", "bc3", "bc4", "bc5", "bc7_basic", "bc7_slow", "bc7_alpha_slow", "bc6h_fast", "bc6h_slow"):
             if wl == args.workload:
@@ -300,6 +374,31 @@ def main():
                 del d2, o2
             except Exception as e:
                 side["@colors16m"] = {"error": repr(e)}
+            # SURVEY 8(d) input I4 / BASELINE configs[3]: the reference's monkey-32bit.hdr (RGBE -> RGBA16F, committed as a
+            # fixture: tests/golden/inputs.npz) tiled 19 x 19 and cropped to 4096^2
+            try:
+                from itw_amd import surfaces
+                mk = np.load(os.path.join(ROOT, "tests", "golden", "inputs.npz"))["monkey_hdr"]
+                d2 = torch.from_numpy(surfaces.tile_to(mk, size, size)).to(dev)
+                o2 = torch.empty(nblocks * 16, dtype=torch.uint8, device=dev)
+                for wl in ("bc6h_fast", "bc6h_slow"):
+                    f2, p2 = WORKLOADS[wl]
+                    avg, mn = time_kernel(itw_amd, f2, p2, d2, o2, steps=3, warmup=1)
+                    gbs = ALG_BYTES[f2] * nblocks / (avg * 1e-3) / 1e9
+                    side[wl + "@monkey_hdr_tiled"] = {"Mpixels/s": round(size * size / (avg * 1e-3) / 1e6, 1), "kernel_ms_avg": round(avg, 4),
+                                                      "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5)}
+                del d2, o2
+            except Exception as e:
+                side["@monkey_hdr_tiled"] = {"error": repr(e)}
+        if not args.no_cpu:
+            # the CPU path beside every format: scalar C oracle, 1 thread and all usable threads, ~2 s each
+            for wl in ("bc1", "bc3", "bc6h_slow"):
+                f2, p2 = WORKLOADS[wl]
+                if wl in side and "error" not in side[wl]:
+                    try:
+                        side[wl]["cpu_baseline"] = cpu_baseline_pair(f2, p2, make_surface(f2, 1024, 0))
+                    except Exception as e:
+                        side[wl]["cpu_baseline"] = {"error": repr(e)}
         result["formats"] = side
 
     if rank == 0 and world == 1 and not args.no_cpu:

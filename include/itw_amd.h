@@ -23,9 +23,28 @@ extern "C" {
 #endif
 
 /* Stream (hipStream_t as void*) used by this host thread's device-resident
- * calls.  Default: the NULL stream.  Thread-local. */
+ * calls.  Default: the NULL stream.  Thread-local and sticky: the handle must stay valid for as long as it is the
+ * thread's current stream (reset with itwSetStream(NULL) before destroying it).  The library keeps no other reference
+ * to caller streams: cross-stream ordering of its per-thread BC7 workspace uses library-owned events. */
 void  itwSetStream(void* hip_stream);
 void* itwGetStream(void);
+
+/* Failure handling.  The reference ABI is void and cannot fail (ispc_texcomp.h:104-107); this library needs a GPU
+ * and has, on purpose, no CPU path behind it.
+ *   itwAvailable()   1 if the calling thread's current HIP device exists and is a gfx950 (the only code object in the
+ *                    library); 0 otherwise.  Never aborts, never prints: a host decides BEFORE calling CompressBlocks*.
+ *   itwSetErrorMode  process-wide.  ITW_ON_ERROR_ABORT (default; also env ITW_ON_ERROR=abort): a HIP failure (no
+ *                    device, out of memory, invalid pointer) prints a diagnostic and abort()s -- loud, never a
+ *                    silently wrong texture.  ITW_ON_ERROR_RETURN (env ITW_ON_ERROR=return): the failing call returns
+ *                    (destination contents undefined), the message is kept for the calling host thread, the
+ *                    bool-returning dispatch entry points (CompressImageMT/ST, itwCompressImageSliced) return false.
+ *   itwLastError()   message of the last failed call on this host thread, NULL if the last ABI call succeeded
+ *                    (every CompressBlocks* call clears it on entry).  Static storage per thread. */
+enum { ITW_ON_ERROR_ABORT = 0, ITW_ON_ERROR_RETURN = 1 };
+int         itwAvailable(void);
+void        itwSetErrorMode(int mode);
+const char* itwLastError(void);
+void        itwClearError(void);
 
 /* "gfx950 / <device name> / <CU count> CUs" of the current device; static storage per thread. */
 const char* itwDeviceInfo(void);

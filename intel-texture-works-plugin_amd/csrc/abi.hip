@@ -6,25 +6,83 @@
 // plus the itw* extensions of include/itw_amd.h.  The reference forwards these
 // calls to ISPC-generated x86 code; here the device boundary (H2D / launch /
 // D2H) sits at the same line.  There is no CPU implementation behind this file:
-// a HIP failure is reported on stderr and the process aborts.
+// a HIP failure is reported on stderr and the process aborts, or -- if the host opted in with itwSetErrorMode -- the
+// call returns and the message waits in itwLastError() (host_rt.hpp).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include "../../include/itw_amd.h"
 #include "../../include/itw_bc45.h"
+#include <atomic>
+#include "host_rt.hpp"
 #include "kernels.hpp"
 #include "x86_math.hpp"
 
-namespace {
+namespace itw {
 
-[[noreturn]] void die(const char* what, hipError_t e, const char* file, int line)
+namespace {
+std::atomic<int> g_error_mode{-1};                 // -1 = not decided yet (ITW_ON_ERROR), 0 abort, 1 return
+thread_local char t_last_error[384] = {0};
+thread_local bool t_has_error = false;
+
+int error_mode() noexcept
 {
-    std::fprintf(stderr, "libispc_texcomp (itw-amd): %s failed: %s (%d) at %s:%d -- no CPU fallback, aborting\n",
-                 what, hipGetErrorString(e), (int)e, file, line);
-    std::abort();
+    int m = g_error_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = std::getenv("ITW_ON_ERROR");
+        m = (e && !std::strcmp(e, "return")) ? 1 : 0;
+        g_error_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
 }
-#define ITW_CHECK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) die(#expr, e_, __FILE__, __LINE__); } while (0)
+}
+
+void fail_hip(const char* what, hipError_t e, const char* file, int line)
+{
+    (void)hipGetLastError();                        // do not let the sticky error poison the next call
+    Failure f;
+    std::snprintf(f.msg, sizeof f.msg, "%s failed: %s (%d) at %s:%d", what, hipGetErrorString(e), (int)e, file, line);
+    throw f;
+}
+
+void fail_msg(const char* fmt, ...)
+{
+    Failure f;
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(f.msg, sizeof f.msg, fmt, ap);
+    va_end(ap);
+    throw f;
+}
+
+void report_failure(const Failure& f) noexcept
+{
+    std::snprintf(t_last_error, sizeof t_last_error, "%s", f.msg);
+    t_has_error = true;
+    if (error_mode() == 0) {
+        std::fprintf(stderr, "libispc_texcomp (itw-amd): %s -- no CPU fallback, aborting (itwSetErrorMode(ITW_ON_ERROR_RETURN) "
+                             "makes this call return instead)\n", f.msg);
+        std::abort();
+    }
+}
+
+void clear_failure() noexcept { t_has_error = false; t_last_error[0] = 0; }
+
+bool is_device_pointer(const void* p) noexcept
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    std::memset(&a, 0, sizeof(a));
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc'd memory on older runtimes
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+} // namespace itw
+
+namespace {
+using itw::is_device_pointer;
 
 // Per host thread: stream for device-resident calls and grow-only staging
 // buffers for host-pointer calls.  The reference is called from up to 64 pool
@@ -39,6 +97,7 @@ struct ThreadCtx {
     void*  d_out = nullptr; size_t out_cap = 0;
     void*  d_ws = nullptr;  size_t ws_cap = 0;      // BC7 inter-family workspace
     hipStream_t ws_stream = nullptr; bool ws_used = false;
+    hipEvent_t  ws_event = nullptr;                 // recorded after each BC7 call: orders the workspace across streams
     int    device = -1;
     char   info[256] = {0};
     ~ThreadCtx() {
@@ -50,6 +109,7 @@ struct ThreadCtx {
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
         for (auto e : ev_in) if (e) (void)hipEventDestroy(e);
         for (auto e : ev_done) if (e) (void)hipEventDestroy(e);
+        if (ws_event) (void)hipEventDestroy(ws_event);
     }
 };
 thread_local ThreadCtx tls;
@@ -68,6 +128,7 @@ void bind_thread_to_current_device()
     if (tls.copy_stream) { (void)hipStreamDestroy(tls.copy_stream); tls.copy_stream = nullptr; }
     for (auto& e : tls.ev_in) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto& e : tls.ev_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    if (tls.ws_event) { (void)hipEventDestroy(tls.ws_event); tls.ws_event = nullptr; }
     tls.device = dev;
 }
 
@@ -84,21 +145,13 @@ void ensure_device_ctx()
 void* grow(void*& buf, size_t& cap, size_t need)
 {
     if (need > cap) {
-        if (buf) ITW_CHECK(hipFree(buf));
+        if (buf) { void* old = buf; buf = nullptr; cap = 0; ITW_CHECK(hipFree(old)); }
         size_t want = need + need / 4 + 4096;
-        ITW_CHECK(hipMalloc(&buf, want));
-        cap = want;
+        void* fresh = nullptr;
+        ITW_CHECK(hipMalloc(&fresh, want));
+        buf = fresh; cap = want;
     }
     return buf;
-}
-
-bool is_device_pointer(const void* p)
-{
-    hipPointerAttribute_t a;
-    std::memset(&a, 0, sizeof(a));
-    hipError_t e = hipPointerGetAttributes(&a, p);
-    if (e != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc'd memory on older runtimes
-    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
 enum class Fmt { BC1, BC3, BC7, BC6H, BC4, BC5 };
@@ -110,11 +163,14 @@ struct Job {
 };
 
 // The BC7 workspace is per host thread.  Work already queued on another stream may still be using it, so a change
-// of stream waits for the previous one; calls on one stream are ordered by the stream itself.
+// of stream makes the new stream wait for a library-owned event recorded behind the previous call (never for the
+// caller's old stream handle, which may have been destroyed since -- ADVICE r01); calls on one stream are ordered by
+// the stream itself.  Growing the workspace frees it first, and hipFree waits for the device.
 float* bc7_workspace(int w, int h, hipStream_t st)
 {
     bind_thread_to_current_device();
-    if (tls.ws_used && tls.ws_stream != st) ITW_CHECK(hipStreamSynchronize(tls.ws_stream));
+    if (!tls.ws_event) ITW_CHECK(hipEventCreateWithFlags(&tls.ws_event, hipEventDisableTiming));
+    if (tls.ws_used && tls.ws_stream != st) ITW_CHECK(hipStreamWaitEvent(st, tls.ws_event, 0));
     float* ws = (float*)grow(tls.d_ws, tls.ws_cap, itw::bc7_workspace_bytes(w, h));
     tls.ws_stream = st; tls.ws_used = true;
     return ws;
@@ -125,7 +181,10 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
     switch (j.fmt) {
     case Fmt::BC1:  itw::launch_bc1(d_src, stride, w, h, d_dst, st); break;
     case Fmt::BC3:  itw::launch_bc3(d_src, stride, w, h, d_dst, st); break;
-    case Fmt::BC7:  itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st), st); break;
+    case Fmt::BC7:
+        itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st), st);
+        ITW_CHECK(hipEventRecord(tls.ws_event, st));
+        break;
     case Fmt::BC6H: itw::launch_bc6h(d_src, stride, w, h, d_dst, *j.s6, st); break;
     case Fmt::BC4:  itw::launch_bc4(d_src, stride, w, h, d_dst, st); break;
     case Fmt::BC5:  itw::launch_bc5(d_src, stride, w, h, d_dst, st); break;
@@ -135,16 +194,14 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
 
 void compress(const Job& j, const rgba_surface* src, uint8_t* dst)
 {
-    if (!src) { std::fprintf(stderr, "libispc_texcomp (itw-amd): null surface\n"); std::abort(); }
+    itw::clear_failure();
+    if (!src) itw::fail_msg("null surface");
     const int w = src->width, h = src->height;
     // ISPC formats drop partial blocks (kernel.ispc:600-601); the DirectXTex formats keep them (DirectXTexCompress.cpp:108-116)
     const bool keep_partial = (j.fmt == Fmt::BC4 || j.fmt == Fmt::BC5);
     const int bx = keep_partial ? (w > 0 ? (w + 3) / 4 : 0) : w / 4, by = keep_partial ? (h > 0 ? (h + 3) / 4 : 0) : h / 4;
     if (bx <= 0 || by <= 0) return;                   // nothing to encode: the reference's loops do not run either
-    if (!src->ptr || !dst) {
-        std::fprintf(stderr, "libispc_texcomp (itw-amd): null texel or destination pointer\n");
-        std::abort();
-    }
+    if (!src->ptr || !dst) itw::fail_msg("null texel or destination pointer");
     const int bpb = (j.fmt == Fmt::BC1 || j.fmt == Fmt::BC4) ? 8 : 16;
     const int texel_bytes = (j.fmt == Fmt::BC6H) ? 8 : 4;
     const size_t row_bytes = keep_partial ? (size_t)w * 4 : (size_t)bx * 4 * texel_bytes;
@@ -326,43 +383,64 @@ void GetProfile_bc6h_veryslow(bc6h_enc_settings* s) { apply(Bc6hPreset{true,  fa
 
 void CompressBlocksBC1(const rgba_surface* src, uint8_t* dst)
 {
-    Job j; j.fmt = Fmt::BC1; compress(j, src, dst);
+    itw::guarded([&] { Job j; j.fmt = Fmt::BC1; compress(j, src, dst); });
 }
 void CompressBlocksBC3(const rgba_surface* src, uint8_t* dst)
 {
-    Job j; j.fmt = Fmt::BC3; compress(j, src, dst);
+    itw::guarded([&] { Job j; j.fmt = Fmt::BC3; compress(j, src, dst); });
 }
 void CompressBlocksBC7(const rgba_surface* src, uint8_t* dst, bc7_enc_settings* settings)
 {
-    if (!settings) { std::fprintf(stderr, "libispc_texcomp (itw-amd): null bc7 settings\n"); std::abort(); }
-    Job j; j.fmt = Fmt::BC7; j.s7 = settings; compress(j, src, dst);
+    itw::guarded([&] {
+        if (!settings) itw::fail_msg("null bc7 settings");
+        Job j; j.fmt = Fmt::BC7; j.s7 = settings; compress(j, src, dst);
+    });
 }
 void CompressBlocksBC6H(const rgba_surface* src, uint8_t* dst, bc6h_enc_settings* settings)
 {
-    if (!settings) { std::fprintf(stderr, "libispc_texcomp (itw-amd): null bc6h settings\n"); std::abort(); }
-    Job j; j.fmt = Fmt::BC6H; j.s6 = settings; compress(j, src, dst);
+    itw::guarded([&] {
+        if (!settings) itw::fail_msg("null bc6h settings");
+        Job j; j.fmt = Fmt::BC6H; j.s6 = settings; compress(j, src, dst);
+    });
 }
 
 void CompressBlocksBC4(const rgba_surface* src, uint8_t* dst)
 {
-    Job j; j.fmt = Fmt::BC4; compress(j, src, dst);
+    itw::guarded([&] { Job j; j.fmt = Fmt::BC4; compress(j, src, dst); });
 }
 void CompressBlocksBC5(const rgba_surface* src, uint8_t* dst)
 {
-    Job j; j.fmt = Fmt::BC5; compress(j, src, dst);
+    itw::guarded([&] { Job j; j.fmt = Fmt::BC5; compress(j, src, dst); });
 }
 
 void  itwSetStream(void* s) { tls.user_stream = (hipStream_t)s; }
 void* itwGetStream(void)    { return (void*)tls.user_stream; }
 
+int itwAvailable(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void)hipGetLastError(); return 0; }
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return std::strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;     // the only code object this library carries
+}
+
+void itwSetErrorMode(int mode) { itw::g_error_mode.store(mode == ITW_ON_ERROR_RETURN ? 1 : 0); }
+const char* itwLastError(void) { return itw::t_has_error ? itw::t_last_error : nullptr; }
+void itwClearError(void) { itw::clear_failure(); }
+
 const char* itwDeviceInfo(void)
 {
-    int dev = 0;
-    ITW_CHECK(hipGetDevice(&dev));
-    hipDeviceProp_t p;
-    ITW_CHECK(hipGetDeviceProperties(&p, dev));
-    std::snprintf(tls.info, sizeof(tls.info), "%s / %s / %d CUs / %.0f MHz", p.gcnArchName, p.name,
-                  p.multiProcessorCount, p.clockRate / 1000.0);
+    tls.info[0] = 0;
+    itw::guarded([&] {
+        int dev = 0;
+        ITW_CHECK(hipGetDevice(&dev));
+        hipDeviceProp_t p;
+        ITW_CHECK(hipGetDeviceProperties(&p, dev));
+        std::snprintf(tls.info, sizeof(tls.info), "%s / %s / %d CUs / %.0f MHz", p.gcnArchName, p.name,
+                      p.multiProcessorCount, p.clockRate / 1000.0);
+    });
     return tls.info;
 }
 
@@ -383,19 +461,19 @@ void itwTestRcp(const float* in, float* out, int64_t n)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_test_rcp, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tls.user_stream, in, out, n);
-    ITW_CHECK(hipGetLastError());
+    itw::guarded([&] { ITW_CHECK(hipGetLastError()); });
 }
 void itwTestRsqrt(const float* in, float* out, int64_t n)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_test_rsqrt, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tls.user_stream, in, out, n);
-    ITW_CHECK(hipGetLastError());
+    itw::guarded([&] { ITW_CHECK(hipGetLastError()); });
 }
 void itwTestF2I(const float* in, int32_t* out, int64_t n)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_test_f2i, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tls.user_stream, in, out, n);
-    ITW_CHECK(hipGetLastError());
+    itw::guarded([&] { ITW_CHECK(hipGetLastError()); });
 }
 
 } // extern "C"

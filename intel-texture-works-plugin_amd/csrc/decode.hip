@@ -9,6 +9,7 @@
 #include "../../include/itw_decode.h"
 #include "../../include/itw_amd.h"
 #include "bc6h_layout.hpp"
+#include "host_rt.hpp"
 
 namespace itw {
 
@@ -302,12 +303,7 @@ decode_kernel(const uint8_t* __restrict__ blocks, int32_t blocks_x, int32_t nblo
 
 namespace {
 
-bool on_device(const void* p)
-{
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeDevice;
-}
+bool on_device(const void* p) { return itw::is_device_pointer(p); }     // device and managed memory alike
 
 #define DEC_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::fprintf(stderr, "itwDecodeBlocks: %s failed: %s; aborting\n", #x, hipGetErrorString(e_)); std::abort(); } } while (0)
 

@@ -18,14 +18,17 @@
 #include "../../include/itw_dispatch.h"
 #include "../../include/itw_amd.h"
 #include "../../include/itw_bc45.h"
+#include "host_rt.hpp"
 
 namespace {
+using itw::is_device_pointer;       // one predicate library-wide: device AND managed memory count as resident
 
 struct Job {
     rgba_surface input;
     uint8_t* output = nullptr;
     CompressionFunc* fn = nullptr;
-    int min_height = 4;         // bands shorter than one block row are skipped (win32Threads.cpp:263); 1 for BC4/BC5
+    int min_height = 4;         // bands without a whole block row are not handed out (the reference calls them anyway,
+                                // win32Threads.cpp:264, and its kernel loops over height/4 = 0 rows); 1 for BC4/BC5
     bool pending = false;
 };
 
@@ -36,6 +39,8 @@ struct Pool {
     std::vector<Job> jobs;
     int outstanding = 0;
     bool quit = false;
+    bool failed = false;        // a worker's call failed (error mode "return"): message in fail_msg
+    char fail_msg[384] = {0};
     std::mutex submit;          // one CompressImageMT at a time, like the reference's single global pool
 
     int devices = 1;
@@ -49,8 +54,18 @@ struct Pool {
             if (quit) return;
             Job j = jobs[idx];
             lk.unlock();
-            if (j.input.height >= j.min_height) j.fn(&j.input, j.output);
+            const char* err = nullptr;
+            if (j.input.height >= j.min_height) {
+                itwClearError();
+                j.fn(&j.input, j.output);
+                // The resident path of CompressBlocks* is asynchronous on this worker's stream; a band handed to a
+                // worker is only done when its kernels are (managed surfaces can take this route through callers
+                // that bypass CompressImageMT's own resident shortcut).
+                if (is_device_pointer(j.input.ptr) && is_device_pointer(j.output)) (void)hipStreamSynchronize((hipStream_t)itwGetStream());
+                err = itwLastError();
+            }
             lk.lock();
+            if (err && !failed) { failed = true; std::snprintf(fail_msg, sizeof fail_msg, "%s", err); }
             jobs[idx].pending = false;
             if (--outstanding == 0) done.notify_all();
         }
@@ -91,13 +106,6 @@ Pool* pool()
         g_pool = p;
     }
     return g_pool;
-}
-
-bool is_device_pointer(const void* p)
-{
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeDevice;
 }
 
 template <int PIXEL_WORDS>
@@ -154,8 +162,9 @@ int GetBytesPerBlock(int f)
 
 bool CompressImageST(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int)
 {
+    itwClearError();
     (*cmpFunc)(input, output);
-    return true;
+    return itwLastError() == nullptr;         // always true in the default (abort) error mode, like the reference
 }
 
 bool CompressImageMT(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format)
@@ -184,10 +193,18 @@ bool CompressImageMT(const rgba_surface* input, uint8_t* output, CompressionFunc
             j.pending = true;
         }
         p->outstanding = n;
+        p->failed = false;
     }
     p->work.notify_all();
     std::unique_lock<std::mutex> lk(p->m);
     p->done.wait(lk, [&] { return p->outstanding == 0; });
+    if (p->failed) {
+        itw::Failure f;
+        std::snprintf(f.msg, sizeof f.msg, "%s", p->fail_msg);
+        lk.unlock();
+        itw::report_failure(f);               // surfaces the worker's message on the calling thread
+        return false;
+    }
     return true;
 }
 
@@ -241,8 +258,9 @@ bool itwCompressImageSliced(const rgba_surface* source, uint8_t* target, int64_t
             input.ptr += (int64_t)input.stride * ylo;
             input.height = yhi - ylo;
             uint8_t* dst = target + block_row_pitch * (ylo >> 2);
-            if (multithreaded) CompressImageMT(&input, dst, cmpFunc, dxgi_format);
-            else               CompressImageST(&input, dst, cmpFunc, dxgi_format);
+            const bool ok = multithreaded ? CompressImageMT(&input, dst, cmpFunc, dxgi_format)
+                                          : CompressImageST(&input, dst, cmpFunc, dxgi_format);
+            if (!ok) return false;
         }
     }
     return true;

@@ -15,7 +15,8 @@ BC6H_PROFILES = ("veryfast", "fast", "basic", "slow", "veryslow")
 EXPORTED_SYMBOLS = tuple(
     ["CompressBlocksBC1", "CompressBlocksBC3", "CompressBlocksBC6H", "CompressBlocksBC7"]
     + ["GetProfile_" + p for p in BC7_PROFILES] + ["GetProfile_bc6h_" + p for p in BC6H_PROFILES]
-    + ["itwSetStream", "itwGetStream", "itwDeviceInfo", "itwVersion", "itwBandForPart",
+    + ["itwSetStream", "itwGetStream", "itwAvailable", "itwSetErrorMode", "itwLastError", "itwClearError",
+       "itwDeviceInfo", "itwVersion", "itwBandForPart",
        "itwTestRcp", "itwTestRsqrt", "itwTestF2I"]
     # include/itw_dispatch.h: the reference's dispatch layer (win32Threads.h), slice loop, pad pre-pass
     + ["GetProcessorCount", "InitWin32Threads", "DestroyThreads", "GetBytesPerBlock", "CompressImageMT", "CompressImageST",
@@ -97,6 +98,11 @@ def lib():
         L.itwSetStream.restype = None
         L.itwGetStream.restype = C.c_void_p
         L.itwDeviceInfo.restype = C.c_char_p
+        L.itwAvailable.restype = C.c_int
+        L.itwSetErrorMode.argtypes = [C.c_int]
+        L.itwSetErrorMode.restype = None
+        L.itwLastError.restype = C.c_char_p
+        L.itwClearError.restype = None
         L.itwVersion.restype = C.c_char_p
         L.itwBandForPart.argtypes = [C.c_int32] * 5 + [C.POINTER(C.c_int32)] * 2
         L.itwBandForPart.restype = C.c_int64
@@ -147,6 +153,24 @@ def lib():
 
 def version():
     return lib().itwVersion().decode()
+
+
+ON_ERROR_ABORT, ON_ERROR_RETURN = 0, 1
+
+
+def available():
+    """itwAvailable(): True if the current HIP device is a gfx950 this library can run on.  Never aborts."""
+    return bool(lib().itwAvailable())
+
+
+def set_error_mode(mode):
+    lib().itwSetErrorMode(mode)
+
+
+def last_error():
+    """Message of the last failed ABI call on this host thread, or None."""
+    e = lib().itwLastError()
+    return e.decode() if e else None
 
 
 def device_info():

@@ -11,7 +11,8 @@
  *
  *   ref_threads_caller <mt|st> <trampoline> <w> <h> <in.bin> <out.bin> [whole]
  *        trampoline = BC1 | BC3 | BC7_<profile> | BC6H_<profile>;  "whole" = one call instead of the slice loop
- *        worker count = host cores, or ITW_REF_THREADS
+ *        worker count = host cores, or ITW_REF_THREADS;  ITW_REF_REPS=n repeats the whole image n times and reports
+ *        the fastest pass (the first pass of a process pays HIP start-up: runtime init, code-object load, first hipMalloc)
  */
 #include "win32Threads.h"      /* the reference's header */
 #include <chrono>
@@ -54,9 +55,13 @@ int main(int argc, char** argv)
     source.ptr = in.data(); source.width = w; source.height = h; source.stride = w * bpp;
 
     if (mt) InitWin32Threads();
-    auto t0 = std::chrono::steady_clock::now();
+    int reps = getenv("ITW_REF_REPS") ? atoi(getenv("ITW_REF_REPS")) : 1;
+    if (reps < 1) reps = 1;
+    double ms = 1e30, first_ms = 0;
     int slices = whole ? 1 : (source.width * source.height) / 0x40000;         /* IntelPlugin.cpp:851 */
     if (slices < 1) slices = 1;
+    for (int rep = 0; rep < reps; rep++) {
+    auto t0 = std::chrono::steady_clock::now();
     for (int i = 0; i < slices; i++) {
         int ylo = (int)((long long)i * source.height / slices) & ~3;          /* IntelPlugin.cpp:860-861 */
         int yhi = (int)((long long)(i + 1) * source.height / slices) & ~3;
@@ -69,10 +74,14 @@ int main(int argc, char** argv)
         if (mt) CompressImageMT(&input, dst, fn, fmt);
         else    CompressImageST(&input, dst, fn, fmt);
     }
-    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    double pass = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rep == 0) first_ms = pass;
+    if (pass < ms) ms = pass;
+    }
+    int workers = mt ? GetProcessorCount() : 1;
     if (mt) DestroyThreads();
-    printf("{\"trampoline\": \"%s\", \"mode\": \"%s\", \"slices\": %d, \"workers\": %d, \"ms\": %.3f, \"mpix_s\": %.1f}\n",
-           argv[2], argv[1], slices, mt ? GetProcessorCount() : 1, ms, (double)w * h / ms / 1e3);
+    printf("{\"trampoline\": \"%s\", \"mode\": \"%s\", \"slices\": %d, \"workers\": %d, \"reps\": %d, \"first_pass_ms\": %.3f, "
+           "\"ms\": %.3f, \"mpix_s\": %.1f}\n", argv[2], argv[1], slices, workers, reps, first_ms, ms, (double)w * h / ms / 1e3);
 
     f = fopen(argv[6], "wb");
     if (!f || fwrite(out.data(), 1, out.size(), f) != out.size()) { perror(argv[6]); return 2; }

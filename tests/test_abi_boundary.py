@@ -115,3 +115,49 @@ def test_band_rule_partitions_block_rows(itw, h, parts):
         y += n
         off_expect += (n // 4) * (w // 4) * 16
     assert y == h // 4 * 4
+
+
+def test_host_can_probe_before_calling_and_opt_out_of_abort(itw):
+    """A plug-in host must not be killed by a missing GPU: itwAvailable() never aborts, and with
+    itwSetErrorMode(ITW_ON_ERROR_RETURN) a failing CompressBlocks* call returns with the message in itwLastError().
+    Run in a subprocess so the process-wide error mode does not leak into other tests; on a box WITH a gfx950 the same
+    script checks the success side (no error, blocks written)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import itw_amd
+ok = itw_amd.available()
+itw_amd.set_error_mode(itw_amd.ON_ERROR_RETURN)
+img = np.zeros((8, 8, 4), dtype=np.uint8)
+out = itw_amd.compress_numpy("bc1", img)          # must RETURN either way
+err = itw_amd.last_error()
+if ok:
+    assert err is None, err
+else:
+    assert err and "failed" in err, err
+    okk, _ = itw_amd.compress_image("bc1", img, multithreaded=False)
+    assert okk is False and itw_amd.last_error()
+print("available" if ok else "unavailable")
+""" % os.path.join(ROOT, "intel-texture-works-plugin_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip() in ("available", "unavailable")
+
+
+def test_default_error_mode_still_aborts_loudly_without_a_gpu(itw):
+    """Default contract: no silent fallback -- a failing call prints a diagnostic and aborts the process."""
+    import subprocess
+    import sys
+    if itw.available():
+        pytest.skip("a GPU is present: the failure side cannot be provoked this way")
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import itw_amd
+itw_amd.compress_numpy("bc1", np.zeros((8, 8, 4), dtype=np.uint8))
+print("survived")
+""" % os.path.join(ROOT, "intel-texture-works-plugin_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "survived" not in r.stdout and "no CPU fallback" in r.stderr

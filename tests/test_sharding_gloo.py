@@ -113,3 +113,65 @@ def test_pipelined_gather_double_buffering(world):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _strong_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "intel-texture-works-plugin_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    from itw_amd import shard
+    geo = bench.plan("strong", 16384, world, rank, "bc7")
+    bx = geo["width"] // 4
+    r0, nrows = geo["y0"] // 4, geo["rows"] // 4
+
+    def encode_into(out):            # stands in for the HIP encode: every 16-byte block carries its global block row
+        rows = torch.arange(r0, r0 + nrows, dtype=torch.int32).repeat_interleave(bx * 4)      # 4 int32 per block
+        out.view(torch.int32).copy_(rows)
+
+    pipe = shard.BandPipeline(geo["band_bytes"], world, rank, torch.device("cpu"), encode_into, depth=1)
+    b = pipe.step()
+    pipe.drain()
+    full = pipe.full[b].view(torch.int32).view(-1, bx * 4)
+    ok = full.shape[0] == 4096 and bool((full[:, 0] == torch.arange(4096, dtype=torch.int32)).all()) \
+        and bool((full[:, -1] == torch.arange(4096, dtype=torch.int32)).all())
+    q.put((rank, ok, geo))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_sharding_of_the_16384_surface_world_2():
+    """BASELINE configs[4] as bench.py --gpus N runs it by default: ONE 16384^2 BC7 surface, rank r encodes block rows
+    [4096 r / N, 4096 (r+1) / N) in place at its offset of the whole-image stream, bands all-gathered.  World 2 over gloo
+    with a stand-in encoder that writes each block's global row: the gathered 256 MiB stream is in raster order."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    geos = {r: g for r, _, g in res}
+    assert geos[0]["rows"] == geos[1]["rows"] == 8192 and geos[1]["y0"] == 8192
+    assert geos[0]["band_bytes"] * 2 == geos[0]["total_bytes"] == 16384 * 16384 // 16 * 16
+
+
+def test_bench_plan_weak_and_strong_geometry():
+    import bench
+    for world in (1, 2, 4, 8):
+        offs = []
+        for r in range(world):
+            g = bench.plan("strong", 16384, world, r, "bc7")
+            assert g["height"] == 16384 and g["rows"] == 16384 // world and g["y0"] == r * g["rows"]
+            offs.append((g["band_off"], g["band_bytes"]))
+            w = bench.plan("weak", 4096, world, r, "bc7")
+            assert (w["width"], w["height"], w["rows"], w["y0"]) == (4096, 4096 * world, 4096, 4096 * r)
+        assert offs == [(i * offs[0][1], offs[0][1]) for i in range(world)] and offs[0][1] * world == 16384 * 16384
