@@ -49,6 +49,14 @@ void        itwClearError(void);
 /* "gfx950 / <device name> / <CU count> CUs" of the current device; static storage per thread. */
 const char* itwDeviceInfo(void);
 
+/* Tuning / test knob: how a BC7 call is laid out on the GPU.  ITW_BC7_PATH_AUTO (default; env ITW_BC7_PATH=deep|wide
+ * presets it) picks by call size: DEEP = one lane per block, one launch pair per mode family (fills the chip on whole
+ * surfaces); WIDE = every family's scan split over several waves, winners joined by an ordered argmin (calls too small
+ * to fill the chip: the plugin's 0x40000-pixel slices, IntelPlugin.cpp:851, and the per-thread bands of
+ * win32Threads.cpp:217).  Both produce the same bytes. */
+enum { ITW_BC7_PATH_AUTO = 0, ITW_BC7_PATH_DEEP = 1, ITW_BC7_PATH_WIDE = 2 };
+void itwSetBc7Path(int path);
+
 /* Library build identification: arithmetic model and arch, e.g.
  * "itw-amd 0.1 gfx950 arith=x86-lut-nr contract=off". */
 const char* itwVersion(void);

@@ -14,7 +14,13 @@
 #include <cstring>
 #include "../../include/itw_amd.h"
 #include "../../include/itw_bc45.h"
+#include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
 #include "host_rt.hpp"
 #include "kernels.hpp"
 #include "x86_math.hpp"
@@ -192,9 +198,11 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
     ITW_CHECK(hipGetLastError());
 }
 
-void compress(const Job& j, const rgba_surface* src, uint8_t* dst)
+bool coalesce_small_call(const Job& j, const rgba_surface* src, uint8_t* dst, int64_t blocks);
+
+void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coalesce = true)
 {
-    itw::clear_failure();
+    if (may_coalesce) itw::clear_failure();
     if (!src) itw::fail_msg("null surface");
     const int w = src->width, h = src->height;
     // ISPC formats drop partial blocks (kernel.ispc:600-601); the DirectXTex formats keep them (DirectXTexCompress.cpp:108-116)
@@ -215,6 +223,8 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst)
         launch(j, src->ptr, src->stride, w, h, dst, tls.user_stream);
         return;
     }
+    // small host-pointer calls made concurrently by several host threads are joined into one (below)
+    if (may_coalesce && !src_dev && !dst_dev && coalesce_small_call(j, src, dst, (int64_t)bx * by)) return;
 
     ensure_device_ctx();
     hipStream_t st = tls.own_stream, cs = tls.copy_stream;
@@ -288,6 +298,151 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst)
         }
     }
     ITW_CHECK(hipStreamSynchronize(st));
+}
+
+// ---- joining concurrent small calls ----------------------------------------------------------------------------------
+// The reference's dispatch layer cuts every 0x40000-pixel slice into one band per pool thread and calls the ABI from all
+// of them at once (win32Threads.cpp:211-249: 64 threads -> 64 calls of 8 texel rows at 4096 wide).  Each such call alone
+// is a few workgroups plus two PCIe copies and a synchronisation -- 4096 of them per 4096^2 image.  Concurrent small
+// host-pointer calls are therefore combined ("flat combining"): a caller queues its request; whoever finds no leader
+// becomes the leader, takes everything queued for its device, merges requests that continue each other in memory (same
+// format, settings, width and stride; src and dst of the next band start where the previous one ends -- exactly what
+// win32Threads.cpp:223-230 produces), runs the merged surfaces as ordinary calls on its own stream and staging buffers,
+// marks the requests done and hands leadership on.  A single-threaded caller always finds the queue empty and pays one
+// uncontended mutex.  ITW_COALESCE=0 disables it.
+struct Pending {
+    Job job;
+    bc7_enc_settings s7;
+    bc6h_enc_settings s6;
+    rgba_surface src;
+    uint8_t* dst = nullptr;
+    bool done = false, failed = false;
+    char msg[384] = {0};
+};
+
+struct Combiner {
+    std::mutex m;
+    std::condition_variable cv;
+    std::vector<Pending*> queue;
+    bool leader = false;
+    int burst = 0;                     // requests served since the queue was last idle
+    int expected = 1;                  // size of the previous burst: the reference's pool submits the same number of bands
+                                       // for every slice (win32Threads.cpp:217-231), so the next burst will be this large too
+};
+constexpr int kMaxDevices = 64;
+Combiner g_combiner[kMaxDevices];
+constexpr int64_t kCoalesceMaxBlocks = 65536;     // larger calls fill the chip on their own
+
+bool coalescing_enabled()
+{
+    static const bool on = [] { const char* e = std::getenv("ITW_COALESCE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+bool same_settings(const Pending& a, const Pending& b)
+{
+    if (a.job.fmt != b.job.fmt) return false;
+    if (a.job.fmt == Fmt::BC7) {
+        // fields only: padding differs between stack objects, and refineIterations[7] is uninitialised storage in the RGB
+        // presets (ispc_texcomp.cpp:20-189 never write it) -- it matters only when mode 7 runs (kernel.ispc:1419)
+        const bc7_enc_settings &x = a.s7, &y = b.s7;
+        for (int i = 0; i < 4; i++) if (x.mode_selection[i] != y.mode_selection[i]) return false;
+        for (int i = 0; i < 7; i++) if (x.refineIterations[i] != y.refineIterations[i]) return false;
+        const bool mode7 = x.mode_selection[1] && x.fastSkipTreshold_mode7 > 0;
+        if (mode7 && x.refineIterations[7] != y.refineIterations[7]) return false;
+        return x.skip_mode2 == y.skip_mode2 && x.fastSkipTreshold_mode1 == y.fastSkipTreshold_mode1 &&
+               x.fastSkipTreshold_mode3 == y.fastSkipTreshold_mode3 && x.fastSkipTreshold_mode7 == y.fastSkipTreshold_mode7 &&
+               x.mode45_channel0 == y.mode45_channel0 && x.refineIterations_channel == y.refineIterations_channel && x.channels == y.channels;
+    }
+    if (a.job.fmt == Fmt::BC6H) {
+        const bc6h_enc_settings &x = a.s6, &y = b.s6;
+        return x.slow_mode == y.slow_mode && x.fast_mode == y.fast_mode && x.refineIterations_1p == y.refineIterations_1p &&
+               x.refineIterations_2p == y.refineIterations_2p && x.fastSkipTreshold == y.fastSkipTreshold;
+    }
+    return true;
+}
+
+// b continues a: next rows of the same image, next block rows of the same stream
+bool continues(const Pending& a, const Pending& b)
+{
+    if (!same_settings(a, b) || a.src.width != b.src.width || a.src.stride != b.src.stride) return false;
+    if ((a.src.height & 3) || a.src.stride <= 0) return false;
+    const int bpb = (a.job.fmt == Fmt::BC1 || a.job.fmt == Fmt::BC4) ? 8 : 16;
+    const bool keep = a.job.fmt == Fmt::BC4 || a.job.fmt == Fmt::BC5;
+    const int64_t bx = keep ? (a.src.width + 3) / 4 : a.src.width / 4;
+    return b.src.ptr == a.src.ptr + (int64_t)a.src.height * a.src.stride && b.dst == a.dst + (int64_t)(a.src.height / 4) * bx * bpb;
+}
+
+void run_batch(std::vector<Pending*>& batch)
+{
+    std::sort(batch.begin(), batch.end(), [](const Pending* a, const Pending* b) { return a->src.ptr < b->src.ptr; });
+    size_t i = 0;
+    while (i < batch.size()) {
+        size_t k = i + 1;
+        rgba_surface merged = batch[i]->src;
+        while (k < batch.size() && continues(*batch[k - 1], *batch[k]) && (int64_t)merged.height + batch[k]->src.height < (1 << 30)) {
+            merged.height += batch[k]->src.height;
+            k++;
+        }
+        Job j = batch[i]->job;
+        j.s7 = &batch[i]->s7; j.s6 = &batch[i]->s6;
+        try { compress(j, &merged, batch[i]->dst, false); }
+        catch (const itw::Failure& f) {
+            for (size_t t = i; t < k; t++) { batch[t]->failed = true; std::snprintf(batch[t]->msg, sizeof batch[t]->msg, "%s", f.msg); }
+        }
+        i = k;
+    }
+}
+
+bool coalesce_small_call(const Job& j, const rgba_surface* src, uint8_t* dst, int64_t blocks)
+{
+    if (blocks > kCoalesceMaxBlocks || !coalescing_enabled()) return false;
+    bind_thread_to_current_device();
+    if (tls.device < 0 || tls.device >= kMaxDevices) return false;
+    Combiner& c = g_combiner[tls.device];
+    Pending me;
+    me.job = j;
+    if (j.s7) me.s7 = *j.s7;
+    if (j.s6) me.s6 = *j.s6;
+    me.src = *src;
+    me.dst = dst;
+
+    std::unique_lock<std::mutex> lk(c.m);
+    c.queue.push_back(&me);
+    while (!me.done) {
+        if (c.leader) { c.cv.wait(lk); continue; }
+        c.leader = true;                                  // lead one batch (it contains this thread's request), then hand on
+        if (c.burst == 0 && c.expected > 1) {
+            // start of a burst from a pool of threads released by one event: they arrive over some tens of microseconds.
+            // Wait for as many requests as the previous burst had, as long as the queue keeps growing, so that the whole
+            // slice becomes ONE merged call instead of a first small batch and a second one with the stragglers.
+            const auto t0 = std::chrono::steady_clock::now();
+            auto grown = t0;
+            size_t seen = c.queue.size();
+            while ((int)c.queue.size() < c.expected) {
+                lk.unlock();
+                const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(8);
+                while (std::chrono::steady_clock::now() < until) std::this_thread::yield();
+                lk.lock();
+                const auto now = std::chrono::steady_clock::now();
+                if (c.queue.size() != seen) { seen = c.queue.size(); grown = now; }
+                if (now - grown > std::chrono::microseconds(80) || now - t0 > std::chrono::microseconds(600)) break;
+            }
+        }
+        std::vector<Pending*> batch;
+        batch.swap(c.queue);
+        c.burst += (int)batch.size();
+        lk.unlock();
+        run_batch(batch);
+        lk.lock();
+        for (Pending* p : batch) p->done = true;
+        if (c.queue.empty()) { c.expected = c.burst; c.burst = 0; }      // burst over
+        c.leader = false;
+        c.cv.notify_all();
+    }
+    lk.unlock();
+    if (me.failed) { itw::Failure f; std::snprintf(f.msg, sizeof f.msg, "%s", me.msg); throw f; }
+    return true;
 }
 
 // ---- quality presets (values: ispc_texcomp.cpp:20-410) ----------------------
@@ -443,6 +598,8 @@ const char* itwDeviceInfo(void)
     });
     return tls.info;
 }
+
+void itwSetBc7Path(int path) { itw::set_bc7_path(path); }
 
 const char* itwVersion(void) { return "itw-amd 0.1 gfx950 arith=x86-lut-nr contract=off"; }
 

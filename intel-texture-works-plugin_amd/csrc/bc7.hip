@@ -47,6 +47,9 @@
 //
 // VALU issue bound; nothing GEMM shaped, so no MFMA.  Bit-exactness with
 // the oracle forbids FMA contraction and any re-association of sums that can round.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 #include "bc7_exact.hpp"
 #include "kernels.hpp"
 
@@ -495,7 +498,9 @@ __device__ __forceinline__ void take(Win& w, int32_t err, int shape, int32_t key
 #define ITW_CACHE_GET(F, slot) ((slot) == 0u ? F##0 : ((slot) == 1u ? F##1 : ((slot) == 2u ? F##2 : F##3)))
 #define ITW_CACHE_PUT(F, slot, v) do { F##0 = (slot) == 0u ? (v) : F##0; F##1 = (slot) == 1u ? (v) : F##1; F##2 = (slot) == 2u ? (v) : F##2; F##3 = (slot) == 3u ? (v) : F##3; } while (0)
 
-__device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, Win& b0, Win& b2)
+// `first`/`step`: this call visits positions first, first + step, ... (the wide path splits one scan over several waves,
+// WIDE below); a split scan takes the shapes in table order without the cache (any visiting order gives the same winner).
+__device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, Win& b0, Win& b2, int first = 0, int step = 1)
 {
     reset(b0, 64); reset(b2, 64);
     IStats<3> full;
@@ -504,9 +509,9 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
     const bool do2 = !S.skip_mode2;
     const int count = do2 ? 64 : 16;
     int32_t ce0 = 0, ce1 = 0, ce2 = 0, ce3 = 0;      // cached subset results (mode 2 error of a texel mask)
-    for (int pos = 0; pos < count; pos++) {
+    for (int pos = first; pos < count; pos += step) {
         ln.tx.fence();
-        const uint32_t sched = do2 ? BC7_F02_SCHEDULE[pos] : (uint32_t)pos;     // mode 0 alone: table order, nothing cached
+        const uint32_t sched = (do2 && step == 1) ? BC7_F02_SCHEDULE[pos] : (uint32_t)pos;     // mode 0 alone / split scan: table order, nothing cached
         const int part = (int)(sched & 63u);
         const bool do0 = part < 16;
         int32_t e0 = 0, e2 = 0;
@@ -555,8 +560,10 @@ __device__ __forceinline__ void search_02(Lane& ln, const bc7_enc_settings& S, W
 // RANKED: 0 = every shape is a candidate (table-order scan); 1 = at least one of the family's lists is a proper prefix
 // of the PCA ranking (fast profiles), keys in LDS; 2 = the same with lists of at most 16 shapes (every preset of the
 // reference): the 16 smallest keys are kept sorted in registers while the keys are produced, no LDS.
+// `first`/`step`: the share of a split scan (wide path): table-order scans visit shapes first, first + step, ...; ranked
+// scans compute all 64 keys and evaluate list entries first, first + step, ...
 template <bool FAMILY7, int RANK_CH, int RANKED>
-__device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settings& S, Win& wa, Win& wb)
+__device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settings& S, Win& wa, Win& wb, int first = 0, int step = 1)
 {
     constexpr int FIT_CH = FAMILY7 ? 4 : 3;
     const int na = FAMILY7 ? S.fastSkipTreshold_mode7 : S.fastSkipTreshold_mode1;   // first mode of the family
@@ -580,7 +587,7 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
 
     if (RANKED == 0) {
         // every shape is a candidate: table order; the rank key is only needed to order shapes of equal error
-        for (int part = 0; part < 64; part++) {
+        for (int part = first; part < 64; part += step) {
             ln.tx.fence();
             int32_t ea = 0, ec = 0;
             IStats<FIT_CH> rest = full;
@@ -671,6 +678,7 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
                 #pragma unroll
                 for (int t = 0; t < 15; t++) top[t] = top[t + 1];
             }
+            if (step > 1 && (i % step) != first) continue;       // another wave's share of the list
             ln.tx.fence();
             const int shape = prev & 63;
             const Shape sh = load_shape(shape);
@@ -875,13 +883,10 @@ __device__ __forceinline__ void clear(Dual& d)
 // Here one pass over the rotations serves both: a rotation's line fit does not depend on the mode.  Mode 5's
 // winner is found independently (first strict minimum in rotation order) and admitted afterwards against the
 // error left by mode 4 -- the same block the sequential scan produces.
-__device__ __forceinline__ void modes_45(Lane& ln, const bc7_enc_settings& S)      // [kernel.ispc:1623-1655]
+// Rotations r0 .. r1-1 (the wide path gives each rotation its own wave).
+__device__ __forceinline__ void modes_45_scan(Lane& ln, const bc7_enc_settings& S, int r0, int r1, Dual& best4, int32_t& err4, Dual& best5, int32_t& err5)
 {
-    Dual best4, best5;
-    clear(best4); clear(best5);
-    int32_t err4 = ln.best_err, err5 = ERR_MAX;
-
-    for (int r = S.mode45_channel0; r < S.channels; r++) {
+    for (int r = r0; r < r1; r++) {
         // rotated colour block: channel r is replaced by alpha (RGBA profile) or 255 (RGB profile);
         // the displaced channel is coded separately
         Tex rot;
@@ -913,6 +918,14 @@ __device__ __forceinline__ void modes_45(Lane& ln, const bc7_enc_settings& S)   
         try_dual<4, 1>(best4, err4, ln, rot, fit, tt, S, r);
         try_dual<5, 0>(best5, err5, ln, rot, fit, tt, S, r);
     }
+}
+
+__device__ __forceinline__ void modes_45(Lane& ln, const bc7_enc_settings& S)      // [kernel.ispc:1623-1655]
+{
+    Dual best4, best5;
+    clear(best4); clear(best5);
+    int32_t err4 = ln.best_err, err5 = ERR_MAX;
+    modes_45_scan(ln, S, S.mode45_channel0, S.channels, best4, err4, best5, err5);
     if (err4 < ln.best_err) { ln.best_err = err4; ln.improved = true; emit_dual<4>(ln.best, best4); }
     if (err5 < ln.best_err) { ln.best_err = err5; ln.improved = true; emit_dual<5>(ln.best, best5); }
 }
@@ -1102,6 +1115,197 @@ bc7_finish_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
     }
 }
 
+// ---- WIDE path: calls too small to fill the chip -----------------------------------------------------------------
+// The kernels above give every block one lane and every mode family its own pair of launches, which is what fills
+// 1024 SIMDs for a whole surface -- and what makes a 16 384-block call (the plugin's 0x40000-pixel slice,
+// IntelPlugin.cpp:851) take a millisecond: 256 waves walk through five dependent launches while three quarters of the
+// chip idle.  The reference's own answer to small work items is to cut them into bands for more threads
+// (win32Threads.cpp:211-249); the GPU-side equivalent cuts the *search* instead:
+//   phase 1  one launch whose blockIdx.y enumerates independent tasks -- the scan of each multi-subset family split
+//            into `parts` strided shares of its candidate list (lanes stay blocks; another wave takes the other shapes),
+//            each mode 4/5 rotation, mode 6.  A split scan leaves one winner per (mode, part);
+//   phase 2  one launch, blockIdx.y = mode: an ORDERED ARGMIN over the parts' winners -- lowest error, then the
+//            reference's strict-`<` tie rule (lowest table index for modes 0/2, lowest PCA rank key for modes 1/3/7,
+//            kernel.ispc:1320, 1348, 1404-1409; keys are evaluated only on a tie) -- then the least-squares refinement;
+//   phase 3  the modes' candidates {error, block} compete in the reference's order 0,2,1,3,7,4,5,6 with strict `<`
+//            (kernel.ispc:1970-1977).
+// Every candidate is evaluated by exactly the code of the deep path (same functions, same arithmetic), only by a different
+// wave, so the emitted block is identical; tests run both paths on the same inputs (ITW_BC7_PATH=deep|wide).
+constexpr int WIDE_SLOTS = 14;            // candidate slots in commit order: m0 m2 m1 m3 m7 m4[r0..r3] m5[r0..r3] m6
+constexpr int WIDE_MAX_TASKS = 56;
+constexpr int WIDE_MAX_PARTS = 16;
+enum WideKind { WK_SCAN02 = 0, WK_SCAN13 = 1, WK_SCAN7 = 2, WK_ROT45 = 3, WK_MODE6 = 4 };
+struct WideTasks { int n; uint8_t kind[WIDE_MAX_TASKS]; uint8_t part[WIDE_MAX_TASKS]; uint8_t parts[WIDE_MAX_TASKS]; };
+struct WideModes { int n; uint8_t mode[5]; uint8_t parts[5]; uint8_t ranked[5]; uint32_t active_slots; };
+
+__host__ __device__ constexpr int wide_win_slot(int mode) { return mode == 0 ? 0 : mode == 2 ? 1 : mode == 1 ? 2 : mode == 3 ? 3 : 4; }
+
+// winners of split scans: [win_slot][part][block] x {err, shape, key, -}
+__device__ __forceinline__ void store_win_wide(uint4* __restrict__ wins, int32_t nblocks, int slot, int part, int32_t b, const Win& w)
+{
+    wins[((int64_t)slot * WIDE_MAX_PARTS + part) * nblocks + b] = make_uint4((uint32_t)w.err, (uint32_t)w.shape, (uint32_t)w.key, 0u);
+}
+__device__ __forceinline__ void load_win_wide(Win& w, const uint4* __restrict__ wins, int32_t nblocks, int slot, int part, int32_t b)
+{
+    const uint4 v = wins[((int64_t)slot * WIDE_MAX_PARTS + part) * nblocks + b];
+    w.err = (int32_t)v.x; w.shape = (int32_t)v.y; w.key = (int32_t)v.z;
+}
+__device__ __forceinline__ void store_candidate(int32_t* __restrict__ cerr, uint4* __restrict__ cblk, int32_t nblocks, int slot, int32_t b,
+                                                int32_t err, const uint32_t (&blk)[4])
+{
+    cerr[(int64_t)slot * nblocks + b] = err;
+    cblk[(int64_t)slot * nblocks + b] = make_uint4(blk[0], blk[1], blk[2], blk[3]);
+}
+
+// the ranking's view of the whole block, for rank keys evaluated at merge time (same construction as search_two_subset)
+template <int FIT_CH, int RANK_CH>
+__device__ __forceinline__ void whole_block_rank_stats(Stats<RANK_CH>& rfull, const Tex& tx)
+{
+    IStats<FIT_CH> full;
+    stats_int<FIT_CH>(full, tx.pl, whole_block());
+    IStats<RANK_CH> t;
+    #pragma unroll
+    for (int i = 0; i < 10; i++) t.m[i] = full.m[i];
+    #pragma unroll
+    for (int i = 0; i < 4; i++) t.s[i] = full.s[i];
+    t.n = 16;
+    stats_float<RANK_CH>(rfull, t);
+}
+
+template <int FIT_CH, int RANK_CH>
+__device__ __forceinline__ int32_t merge_key(const Win& w, const Tex& tx, const SeedTables& T)
+{
+    if (w.key >= 0) return w.key;
+    Stats<RANK_CH> rfull;
+    whole_block_rank_stats<FIT_CH, RANK_CH>(rfull, tx);
+    return rank_key<RANK_CH>(w.shape, tx, rfull, T);
+}
+
+// Ordered argmin over the parts of one mode's split scan.
+template <int MODE>
+__device__ __forceinline__ void merge_parts(Win& w, Lane& ln, const uint4* __restrict__ wins, int32_t nblocks, int parts, int32_t b, int channels)
+{
+    load_win_wide(w, wins, nblocks, wide_win_slot(MODE), 0, b);
+    for (int p = 1; p < parts; p++) {
+        Win x;
+        load_win_wide(x, wins, nblocks, wide_win_slot(MODE), p, b);
+        if (x.err < w.err) { w = x; continue; }
+        if (x.err != w.err || x.err == ERR_MAX) continue;
+        if (MODE == 0 || MODE == 2) {                     // table order: lowest shape index
+            if (x.shape < w.shape) w = x;
+        } else {                                          // PCA-ranked list order: lowest rank key
+            if (MODE == 7) {
+                if (channels == 4) { w.key = merge_key<4, 4>(w, ln.tx, ln.T); x.key = merge_key<4, 4>(x, ln.tx, ln.T); }
+                else               { w.key = merge_key<4, 3>(w, ln.tx, ln.T); x.key = merge_key<4, 3>(x, ln.tx, ln.T); }
+            } else { w.key = merge_key<3, 3>(w, ln.tx, ln.T); x.key = merge_key<3, 3>(x, ln.tx, ln.T); }
+            if (x.key < w.key) w = x;
+        }
+    }
+}
+
+template <bool VEC16>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+bc7_wide_phase1(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint4* __restrict__ wins,
+                int32_t* __restrict__ cerr, uint4* __restrict__ cblk, const bc7_enc_settings S, const WideTasks tasks, const int ranked13, const int ranked7)
+{
+    __shared__ unsigned short s_seed16[2048];
+    __shared__ uint32_t s_seed32[2048];
+    __shared__ uint2 s_pal[12 * TPB];
+    Lane ln;
+    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
+    __syncthreads();
+    const int32_t gid = blockIdx.x * TPB + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;
+    ln.keys = nullptr;
+    ln.pal = s_pal + threadIdx.x;
+    load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
+    ln.best_err = ERR_MAX; ln.opaque_err = 0; ln.improved = false;
+    ln.best[0] = ln.best[1] = ln.best[2] = ln.best[3] = 0u;
+
+    const int kind = tasks.kind[blockIdx.y], part = tasks.part[blockIdx.y], parts = tasks.parts[blockIdx.y];   // wave-uniform
+    if (kind == WK_SCAN02) {
+        Win w0, w2;
+        search_02(ln, S, w0, w2, part, parts);
+        if (live) { store_win_wide(wins, nblocks, wide_win_slot(0), part, b, w0); if (!S.skip_mode2) store_win_wide(wins, nblocks, wide_win_slot(2), part, b, w2); }
+    } else if (kind == WK_SCAN13) {
+        Win w1, w3;
+        if (ranked13) search_two_subset<false, 3, 2>(ln, S, w1, w3, part, parts); else search_two_subset<false, 3, 0>(ln, S, w1, w3, part, parts);
+        if (live) { store_win_wide(wins, nblocks, wide_win_slot(1), part, b, w1); store_win_wide(wins, nblocks, wide_win_slot(3), part, b, w3); }
+    } else if (kind == WK_SCAN7) {
+        Win w7, unused;
+        if (S.channels == 4) { if (ranked7) search_two_subset<true, 4, 2>(ln, S, w7, unused, part, parts); else search_two_subset<true, 4, 0>(ln, S, w7, unused, part, parts); }
+        else                 { if (ranked7) search_two_subset<true, 3, 2>(ln, S, w7, unused, part, parts); else search_two_subset<true, 3, 0>(ln, S, w7, unused, part, parts); }
+        if (live) store_win_wide(wins, nblocks, wide_win_slot(7), part, b, w7);
+    } else if (kind == WK_ROT45) {
+        Dual best4, best5;
+        clear(best4); clear(best5);
+        int32_t err4 = ERR_MAX, err5 = ERR_MAX;
+        modes_45_scan(ln, S, part, part + 1, best4, err4, best5, err5);          // part = rotation
+        uint32_t blk[4] = {0u, 0u, 0u, 0u};
+        if (err4 < ERR_MAX) emit_dual<4>(blk, best4);
+        if (live) store_candidate(cerr, cblk, nblocks, 5 + part, b, err4, blk);
+        blk[0] = blk[1] = blk[2] = blk[3] = 0u;
+        if (err5 < ERR_MAX) emit_dual<5>(blk, best5);
+        if (live) store_candidate(cerr, cblk, nblocks, 9 + part, b, err5, blk);
+    } else {
+        if (S.channels == 4) mode_6<4>(ln, S); else mode_6<3>(ln, S);
+        if (live) store_candidate(cerr, cblk, nblocks, 13, b, ln.best_err, ln.best);
+    }
+}
+
+template <bool VEC16>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+bc7_wide_phase2(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, const uint4* __restrict__ wins,
+                int32_t* __restrict__ cerr, uint4* __restrict__ cblk, const bc7_enc_settings S, const WideModes modes)
+{
+    __shared__ unsigned short s_seed16[2048];
+    __shared__ uint32_t s_seed32[2048];
+    Lane ln;
+    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
+    __syncthreads();
+    const int32_t gid = blockIdx.x * TPB + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;
+    ln.keys = nullptr;
+    ln.pal = nullptr;
+    load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
+    ln.best_err = ERR_MAX; ln.improved = false;
+    ln.best[0] = ln.best[1] = ln.best[2] = ln.best[3] = 0u;
+    ln.opaque_err = 0;                                                             // kernel.ispc:1267-1277
+    if (S.channels == 4) {
+        uint32_t e = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) { const uint32_t x = ~ln.tx.pl[3][d]; e = udot4(x, x, e); }
+        ln.opaque_err = (int32_t)e;
+    }
+    const int mode = modes.mode[blockIdx.y], parts = modes.parts[blockIdx.y];      // wave-uniform
+    Win w;
+    int slot = 0;
+    if (mode == 0)      { merge_parts<0>(w, ln, wins, nblocks, parts, b, S.channels); refine_and_commit<0>(ln, w, S.refineIterations[0], S.channels); slot = 0; }
+    else if (mode == 2) { merge_parts<2>(w, ln, wins, nblocks, parts, b, S.channels); refine_and_commit<2>(ln, w, S.refineIterations[2], S.channels); slot = 1; }
+    else if (mode == 1) { merge_parts<1>(w, ln, wins, nblocks, parts, b, S.channels); refine_and_commit<1>(ln, w, S.refineIterations[1], S.channels); slot = 2; }
+    else if (mode == 3) { merge_parts<3>(w, ln, wins, nblocks, parts, b, S.channels); refine_and_commit<3>(ln, w, S.refineIterations[3], S.channels); slot = 3; }
+    else                { merge_parts<7>(w, ln, wins, nblocks, parts, b, S.channels); refine_and_commit<7>(ln, w, S.refineIterations[7], S.channels); slot = 4; }
+    if (live) store_candidate(cerr, cblk, nblocks, slot, b, ln.best_err, ln.best);
+}
+
+__global__ void __launch_bounds__(TPB)
+bc7_wide_commit(const int32_t* __restrict__ cerr, const uint4* __restrict__ cblk, int32_t nblocks, uint32_t active_slots, uint4* __restrict__ dst, int vec16)
+{
+    const int32_t b = blockIdx.x * TPB + threadIdx.x;
+    if (b >= nblocks) return;
+    int32_t best = ERR_MAX;
+    uint4 blk = make_uint4(0u, 0u, 0u, 0u);
+    for (int slot = 0; slot < WIDE_SLOTS; slot++) {
+        if (!((active_slots >> slot) & 1u)) continue;
+        const int32_t e = cerr[(int64_t)slot * nblocks + b];
+        if (e < best) { best = e; blk = cblk[(int64_t)slot * nblocks + b]; }
+    }
+    if (vec16) dst[b] = blk;
+    else { uint32_t* d = reinterpret_cast<uint32_t*>(dst) + (int64_t)b * 4; d[0] = blk.x; d[1] = blk.y; d[2] = blk.z; d[3] = blk.w; }
+}
+
 struct Bc7Launch {
     bool vec; dim3 grid; hipStream_t st; const uint8_t* src; int64_t stride; int bx; int32_t n;
     uint8_t* dst; int32_t* err; uint4* wins; bc7_enc_settings S; int first;
@@ -1122,11 +1326,110 @@ static void launch_finish(Bc7Launch& L)
     L.first = 0;
 }
 
-// workspace: best error so far (4 B/block) + the winners of one family's two modes (2 x 16 B/block)
+// Calls of at most this many blocks take the wide path (measured crossover on MI355X, tools/bc7_path_probe.py).
+#ifndef ITW_BC7_WIDE_MAX_BLOCKS
+#define ITW_BC7_WIDE_MAX_BLOCKS 131072
+#endif
+
+// 0 = by size, 1 = deep always, 2 = wide whenever it supports the settings (itwSetBc7Path / ITW_BC7_PATH=deep|wide:
+// tests and probes)
+static std::atomic<int> g_bc7_path{-1};
+static int bc7_path_override()
+{
+    int v = g_bc7_path.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = std::getenv("ITW_BC7_PATH");
+        v = !e ? 0 : !std::strcmp(e, "deep") ? 1 : !std::strcmp(e, "wide") ? 2 : 0;
+        g_bc7_path.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+void set_bc7_path(int v) { g_bc7_path.store(v == 1 || v == 2 ? v : 0, std::memory_order_relaxed); }
+
+static bool bc7_use_wide(int64_t n, const bc7_enc_settings& S)
+{
+    // lists longer than 16 that are proper prefixes of the ranking keep their keys in 64 KiB of LDS: deep path only
+    auto long_ranked = [](int t) { return t > 16 && t < 64; };
+    if (S.mode_selection[1] && (long_ranked(S.fastSkipTreshold_mode1) || long_ranked(S.fastSkipTreshold_mode3) || long_ranked(S.fastSkipTreshold_mode7))) return false;
+    // the wide ranked scan keeps the 16 smallest keys in registers: a family with a ranked list needs all its lists <= 16
+    auto ranked = [](int t) { return t > 0 && t < 64; };
+    if (S.mode_selection[1]) {
+        const int a = S.fastSkipTreshold_mode1, c = S.fastSkipTreshold_mode3;
+        if ((ranked(a) || ranked(c)) && (a > 16 || c > 16)) return false;
+    }
+    if (S.mode45_channel0 < 0 || S.mode45_channel0 > 3) return false;
+    const int o = bc7_path_override();
+    if (o == 1) return false;
+    const int64_t hard_cap = (int64_t)1 << 20;                   // workspace bound of the wide layout (1.6 GB)
+    if (o == 2) return n <= hard_cap;
+    return n <= ITW_BC7_WIDE_MAX_BLOCKS;
+}
+
+// deep: best error so far (4 B/block) + the winners of one family's two modes (2 x 16 B/block)
+// wide: winners [5 modes][16 parts] x 16 B + candidates [14 slots] x (4 + 16) B per block
+static size_t wide_workspace_bytes(size_t n)
+{
+    return (size_t)5 * WIDE_MAX_PARTS * n * sizeof(uint4) + (((size_t)WIDE_SLOTS * n * sizeof(int32_t) + 15) & ~(size_t)15) + (size_t)WIDE_SLOTS * n * sizeof(uint4);
+}
 size_t bc7_workspace_bytes(int width, int height)
 {
     const size_t n = (size_t)(width / 4) * (size_t)(height / 4);
-    return ((n * sizeof(int32_t) + 15) & ~(size_t)15) + 2 * n * sizeof(uint4);
+    const size_t deep = ((n * sizeof(int32_t) + 15) & ~(size_t)15) + 2 * n * sizeof(uint4);
+    const bool may_wide = bc7_path_override() == 2 ? n <= ((size_t)1 << 20) : (bc7_path_override() == 0 && n <= ITW_BC7_WIDE_MAX_BLOCKS);
+    const size_t wide = may_wide ? wide_workspace_bytes(n) : 0;
+    return deep > wide ? deep : wide;
+}
+
+static void launch_bc7_wide(const uint8_t* src, int64_t stride, int bx, int64_t n, uint8_t* dst, const bc7_enc_settings& S, float* workspace, hipStream_t st)
+{
+    uint4* wins = reinterpret_cast<uint4*>(workspace);
+    int32_t* cerr = reinterpret_cast<int32_t*>(wins + (size_t)5 * WIDE_MAX_PARTS * n);
+    uint4* cblk = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(cerr) + (((size_t)WIDE_SLOTS * n * sizeof(int32_t) + 15) & ~(size_t)15));
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    auto ranked = [](int t) { return t > 0 && t < 64; };
+
+    const bool on02 = S.mode_selection[0];
+    const bool on13 = S.mode_selection[1] && (S.fastSkipTreshold_mode1 > 0 || S.fastSkipTreshold_mode3 > 0);
+    const bool on7  = S.mode_selection[1] && S.fastSkipTreshold_mode7 > 0;
+    const bool on45 = S.mode_selection[2], on6 = S.mode_selection[3];
+    const int ranked13 = on13 && (ranked(S.fastSkipTreshold_mode1) || ranked(S.fastSkipTreshold_mode3));
+    const int ranked7 = on7 && ranked(S.fastSkipTreshold_mode7);
+
+    // parts per scan: enough waves to cover the chip about four times (1024 SIMDs), within what the candidate lists offer
+    const int64_t waves = (n + 63) / 64;
+    const int families = (on02 ? 1 : 0) + (on13 ? 1 : 0) + (on7 ? 1 : 0);
+    int want = 1;
+    while (want < WIDE_MAX_PARTS && waves * families * want * 2 <= 4096) want *= 2;
+    auto cap = [&](int limit) { int p = want; while (p > limit) p /= 2; return p < 1 ? 1 : p; };
+    const int p02 = cap(S.skip_mode2 ? 16 : 16);                                  // 16 or 64 shapes
+    const int list13 = ranked13 ? (S.fastSkipTreshold_mode1 > S.fastSkipTreshold_mode3 ? S.fastSkipTreshold_mode1 : S.fastSkipTreshold_mode3) : 64;
+    const int p13 = cap(ranked13 ? (list13 >= 8 ? 4 : list13 >= 2 ? 2 : 1) : 16);   // a ranked share recomputes the 64 keys: few parts
+    const int list7 = ranked7 ? S.fastSkipTreshold_mode7 : 64;
+    const int p7 = cap(ranked7 ? (list7 >= 8 ? 4 : list7 >= 2 ? 2 : 1) : 16);
+
+    WideTasks T;
+    std::memset(&T, 0, sizeof T);
+    auto add = [&](int kind, int part, int parts) { T.kind[T.n] = (uint8_t)kind; T.part[T.n] = (uint8_t)part; T.parts[T.n] = (uint8_t)parts; T.n++; };
+    WideModes M;
+    std::memset(&M, 0, sizeof M);
+    auto add_mode = [&](int mode, int parts) { M.mode[M.n] = (uint8_t)mode; M.parts[M.n] = (uint8_t)parts; M.n++; M.active_slots |= 1u << wide_win_slot(mode); };
+    // longest tasks first: the launch drains in blockIdx order
+    if (on13) { for (int p = 0; p < p13; p++) add(WK_SCAN13, p, p13); if (S.fastSkipTreshold_mode1 > 0) add_mode(1, p13); if (S.fastSkipTreshold_mode3 > 0) add_mode(3, p13); }
+    if (on02) { for (int p = 0; p < p02; p++) add(WK_SCAN02, p, p02); add_mode(0, p02); if (!S.skip_mode2) add_mode(2, p02); }
+    if (on7)  { for (int p = 0; p < p7; p++) add(WK_SCAN7, p, p7); add_mode(7, p7); }
+    if (on45) for (int r = S.mode45_channel0; r < (S.channels == 4 ? 4 : 3); r++) { add(WK_ROT45, r, 1); M.active_slots |= (1u << (5 + r)) | (1u << (9 + r)); }
+    if (on6)  { add(WK_MODE6, 0, 1); M.active_slots |= 1u << 13; }
+
+    const unsigned gx = (unsigned)((n + TPB - 1) / TPB);
+    if (T.n > 0) {
+        if (vec) hipLaunchKernelGGL((bc7_wide_phase1<true>),  dim3(gx, (unsigned)T.n), dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, T, ranked13, ranked7);
+        else     hipLaunchKernelGGL((bc7_wide_phase1<false>), dim3(gx, (unsigned)T.n), dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, T, ranked13, ranked7);
+    }
+    if (M.n > 0) {
+        if (vec) hipLaunchKernelGGL((bc7_wide_phase2<true>),  dim3(gx, (unsigned)M.n), dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, M);
+        else     hipLaunchKernelGGL((bc7_wide_phase2<false>), dim3(gx, (unsigned)M.n), dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, M);
+    }
+    hipLaunchKernelGGL(bc7_wide_commit, dim3(gx), dim3(TPB), 0, st, cerr, cblk, (int32_t)n, M.active_slots, reinterpret_cast<uint4*>(dst), vec ? 1 : 0);
 }
 
 // Families run in the reference's order (kernel.ispc:1970-1977): {0,2} -> {1,3} -> {7} -> {4,5} -> {6}.
@@ -1139,6 +1442,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
     Bc7Launch L;
     L.S = s;
     L.S.channels = (s.channels == 4) ? 4 : 3;
+    if (bc7_use_wide(n, L.S)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st); return; }
     L.err = reinterpret_cast<int32_t*>(workspace);
     L.wins = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(workspace) + (((size_t)n * sizeof(int32_t) + 15) & ~(size_t)15));
     L.vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;

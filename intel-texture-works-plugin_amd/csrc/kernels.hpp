@@ -18,6 +18,9 @@ void launch_bc5 (const uint8_t* src, int64_t stride, int width, int height, uint
 // "best error so far" and the search winners to each other through
 // `workspace`: device memory, bc7_workspace_bytes(width, height) bytes, 16 B aligned, contents irrelevant on entry.
 size_t bc7_workspace_bytes(int width, int height);
+// BC7 launch shape: 0 = by call size (default), 1 = deep (one lane per block, a launch pair per mode family: fills the
+// chip on whole surfaces), 2 = wide (split scans + ordered argmin: small calls).  Same blocks either way.
+void set_bc7_path(int path);
 void launch_bc7 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                  const bc7_enc_settings& s, float* workspace, hipStream_t st);
 void launch_bc6h(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,

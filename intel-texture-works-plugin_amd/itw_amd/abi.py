@@ -15,7 +15,7 @@ BC6H_PROFILES = ("veryfast", "fast", "basic", "slow", "veryslow")
 EXPORTED_SYMBOLS = tuple(
     ["CompressBlocksBC1", "CompressBlocksBC3", "CompressBlocksBC6H", "CompressBlocksBC7"]
     + ["GetProfile_" + p for p in BC7_PROFILES] + ["GetProfile_bc6h_" + p for p in BC6H_PROFILES]
-    + ["itwSetStream", "itwGetStream", "itwAvailable", "itwSetErrorMode", "itwLastError", "itwClearError",
+    + ["itwSetStream", "itwGetStream", "itwAvailable", "itwSetErrorMode", "itwLastError", "itwClearError", "itwSetBc7Path",
        "itwDeviceInfo", "itwVersion", "itwBandForPart",
        "itwTestRcp", "itwTestRsqrt", "itwTestF2I"]
     # include/itw_dispatch.h: the reference's dispatch layer (win32Threads.h), slice loop, pad pre-pass
@@ -103,6 +103,8 @@ def lib():
         L.itwSetErrorMode.restype = None
         L.itwLastError.restype = C.c_char_p
         L.itwClearError.restype = None
+        L.itwSetBc7Path.argtypes = [C.c_int]
+        L.itwSetBc7Path.restype = None
         L.itwVersion.restype = C.c_char_p
         L.itwBandForPart.argtypes = [C.c_int32] * 5 + [C.POINTER(C.c_int32)] * 2
         L.itwBandForPart.restype = C.c_int64
@@ -156,6 +158,12 @@ def version():
 
 
 ON_ERROR_ABORT, ON_ERROR_RETURN = 0, 1
+BC7_PATH = {"auto": 0, "deep": 1, "wide": 2}
+
+
+def set_bc7_path(name):
+    """itwSetBc7Path: 'auto' | 'deep' | 'wide' (same bytes either way; tests and probes)."""
+    lib().itwSetBc7Path(BC7_PATH[name])
 
 
 def available():

@@ -1,12 +1,11 @@
 /*
  * oracle/ref_build/win32_shim.cpp -- TEST INFRASTRUCTURE: pthread implementation of win32_shim/windows.h.
  *
- * One process-wide mutex + condition variable serve every handle: SetEvent / thread exit broadcast, waiters re-check.
- * Wait-all consumes auto-reset events only once every handle is signalled (Win32's rule).  Two Win32 guarantees the
- * event protocol of win32Threads.cpp:211-274 relies on are kept: SetEvent on a manual-reset event satisfies every
- * thread waiting at that moment even if the event is reset right afterwards (a per-event pulse count the waiter
- * samples when it starts to wait), and SignalObjectAndWait signals and starts waiting atomically (one critical
- * section).
+ * Every handle has its own mutex + condition variable (a process-wide pair made each of the 64 workers' signals wake all
+ * the others: thousands of futile wake-ups per CompressImageMT).  Two Win32 guarantees the event protocol of
+ * win32Threads.cpp:211-274 relies on are kept: SetEvent on a manual-reset event satisfies every thread waiting at that
+ * moment even if the event is reset right afterwards (a per-event pulse count the waiter samples when it starts to wait),
+ * and SignalObjectAndWait signals and starts waiting atomically with respect to the waited object.
  */
 #include "win32_shim/windows.h"
 #include <pthread.h>
@@ -14,31 +13,42 @@
 #include <unistd.h>
 
 namespace {
-pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
-pthread_cond_t  g_cv = PTHREAD_COND_INITIALIZER;
 thread_local DWORD t_last_error = 0;
 
 struct Obj {
     enum Kind { Event, Thread } kind;
     bool manual = false, signalled = false;
     uint64_t pulses = 0;                      /* SetEvent count (manual-reset events) */
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
     pthread_t tid{};
     LPTHREAD_START_ROUTINE fn = nullptr;
     LPVOID arg = nullptr;
 };
 
+void signal_locked(Obj* o)
+{
+    o->signalled = true;
+    o->pulses++;
+    pthread_cond_broadcast(&o->cv);
+}
+
+/* o->mu held; `seen` = pulse count sampled when the wait began */
+void wait_locked(Obj* o, uint64_t seen)
+{
+    while (!(o->signalled || (o->kind == Obj::Event && o->manual && o->pulses != seen))) pthread_cond_wait(&o->cv, &o->mu);
+    if (o->kind == Obj::Event && !o->manual) o->signalled = false;          /* auto-reset: consumed by the waiter */
+}
+
 void* thread_main(void* p)
 {
     Obj* o = static_cast<Obj*>(p);
     o->fn(o->arg);
-    pthread_mutex_lock(&g_mu);
-    o->signalled = true;                       /* a thread handle becomes signalled when the thread ends */
-    pthread_cond_broadcast(&g_cv);
-    pthread_mutex_unlock(&g_mu);
+    pthread_mutex_lock(&o->mu);
+    signal_locked(o);                          /* a thread handle becomes signalled when the thread ends */
+    pthread_mutex_unlock(&o->mu);
     return nullptr;
 }
-
-void consume(Obj* o) { if (o->kind == Obj::Event && !o->manual) o->signalled = false; }
 }
 
 DWORD GetLastError() { return t_last_error; }
@@ -60,26 +70,21 @@ HANDLE CreateEvent(SECURITY_ATTRIBUTES*, BOOL manual_reset, BOOL initial_state, 
     return o;
 }
 
-static void signal_locked(Obj* o)
-{
-    o->signalled = true;
-    o->pulses++;
-    pthread_cond_broadcast(&g_cv);
-}
-
 BOOL SetEvent(HANDLE h)
 {
-    pthread_mutex_lock(&g_mu);
-    signal_locked(static_cast<Obj*>(h));
-    pthread_mutex_unlock(&g_mu);
+    Obj* o = static_cast<Obj*>(h);
+    pthread_mutex_lock(&o->mu);
+    signal_locked(o);
+    pthread_mutex_unlock(&o->mu);
     return TRUE;
 }
 
 BOOL ResetEvent(HANDLE h)
 {
-    pthread_mutex_lock(&g_mu);
-    static_cast<Obj*>(h)->signalled = false;
-    pthread_mutex_unlock(&g_mu);
+    Obj* o = static_cast<Obj*>(h);
+    pthread_mutex_lock(&o->mu);
+    o->signalled = false;
+    pthread_mutex_unlock(&o->mu);
     return TRUE;
 }
 
@@ -103,45 +108,36 @@ HANDLE CreateThread(SECURITY_ATTRIBUTES*, SIZE_T, LPTHREAD_START_ROUTINE fn, LPV
     return o;
 }
 
-static DWORD wait_locked(DWORD n, const HANDLE* hs, BOOL wait_all)
+DWORD WaitForSingleObject(HANDLE h, DWORD)
 {
-    uint64_t seen[MAXIMUM_WAIT_OBJECTS];
-    for (DWORD i = 0; i < n; i++) seen[i] = static_cast<Obj*>(hs[i])->pulses;
-    DWORD ret = WAIT_OBJECT_0;
-    for (;;) {
-        DWORD ready = 0, first = n;
-        for (DWORD i = 0; i < n; i++) {
-            Obj* o = static_cast<Obj*>(hs[i]);
-            if (o->signalled || (o->kind == Obj::Event && o->manual && o->pulses != seen[i])) { ready++; if (first == n) first = i; }
-        }
-        if (wait_all ? ready == n : ready > 0) {
-            if (wait_all) for (DWORD i = 0; i < n; i++) consume(static_cast<Obj*>(hs[i]));
-            else { consume(static_cast<Obj*>(hs[first])); ret = WAIT_OBJECT_0 + first; }
-            break;
-        }
-        pthread_cond_wait(&g_cv, &g_mu);
-    }
-    return ret;
+    Obj* o = static_cast<Obj*>(h);
+    pthread_mutex_lock(&o->mu);
+    wait_locked(o, o->pulses);
+    pthread_mutex_unlock(&o->mu);
+    return WAIT_OBJECT_0;
 }
 
-DWORD WaitForMultipleObjects(DWORD n, const HANDLE* hs, BOOL wait_all, DWORD)
+/* wait-all only (the one form win32Threads.cpp uses): the objects are waited for one after the other.  Win32 would
+ * consume the auto-reset events atomically once all are set; with a single waiter (the submitting thread) the outcome
+ * is the same. */
+DWORD WaitForMultipleObjects(DWORD n, const HANDLE* hs, BOOL wait_all, DWORD ms)
 {
-    if (n > MAXIMUM_WAIT_OBJECTS) return WAIT_FAILED;
-    pthread_mutex_lock(&g_mu);
-    DWORD ret = wait_locked(n, hs, wait_all);
-    pthread_mutex_unlock(&g_mu);
-    return ret;
+    if (!wait_all || n > MAXIMUM_WAIT_OBJECTS) return WAIT_FAILED;
+    for (DWORD i = 0; i < n; i++) WaitForSingleObject(hs[i], ms);
+    return WAIT_OBJECT_0;
 }
 
-DWORD WaitForSingleObject(HANDLE h, DWORD ms) { return WaitForMultipleObjects(1, &h, TRUE, ms); }
-
+/* atomic with respect to the waited object: its pulse count is sampled under its lock BEFORE the other object is
+ * signalled, so a SetEvent + ResetEvent pair issued by whoever the signal wakes cannot be missed */
 DWORD SignalObjectAndWait(HANDLE to_signal, HANDLE to_wait, DWORD, BOOL)
 {
-    pthread_mutex_lock(&g_mu);
-    signal_locked(static_cast<Obj*>(to_signal));
-    DWORD ret = wait_locked(1, &to_wait, TRUE);
-    pthread_mutex_unlock(&g_mu);
-    return ret;
+    Obj* w = static_cast<Obj*>(to_wait);
+    pthread_mutex_lock(&w->mu);
+    const uint64_t seen = w->pulses;
+    SetEvent(to_signal);
+    wait_locked(w, seen);
+    pthread_mutex_unlock(&w->mu);
+    return WAIT_OBJECT_0;
 }
 
 DWORD FormatMessage(DWORD, const void*, DWORD id, DWORD, LPTSTR buf, DWORD, va_list*)

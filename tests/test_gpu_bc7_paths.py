@@ -1,0 +1,94 @@
+"""BC7 launch shapes (csrc/bc7.hip): DEEP (one lane per block, a launch pair per mode family) and WIDE (every family's scan
+split over several waves, winners joined by an ordered argmin: lowest error, then the reference's strict-`<` list order,
+kernel.ispc:1320, 1348, 1404-1409).  Both must emit the oracle's bytes on the same inputs -- the wide path is what the
+plugin's 0x40000-pixel slices (IntelPlugin.cpp:851) and win32Threads' per-thread bands get by default."""
+import numpy as np
+import pytest
+
+from conftest import first_mismatch
+
+pytestmark = pytest.mark.gpu
+
+ALL = ["ultrafast", "veryfast", "fast", "basic", "slow",
+       "alpha_ultrafast", "alpha_veryfast", "alpha_fast", "alpha_basic", "alpha_slow"]
+
+
+@pytest.fixture
+def paths(itw):
+    yield itw.set_bc7_path
+    itw.set_bc7_path("auto")
+
+
+def _encode(itw, gpu, img, prof):
+    import torch
+    out = itw.compress("bc7", torch.from_numpy(img).to(gpu), prof)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _posterised(h, w, levels, seed=5):
+    from itw_amd import surfaces
+    img = surfaces.ldr_smooth(h, w, seed=surfaces.SEED + seed)
+    step = 256 // levels
+    return (img // step * step).astype(np.uint8)
+
+
+@pytest.mark.parametrize("prof", ALL)
+def test_both_paths_reproduce_the_golden_streams(itw, gpu, paths, golden_inputs, golden_blocks, prof):
+    for name in ("monkey", "edge_cases"):
+        want = golden_blocks[f"{name}.bc7.{prof}"]
+        for path in ("wide", "deep"):
+            paths(path)
+            got = _encode(itw, gpu, golden_inputs[name], prof)
+            assert first_mismatch(got, want, 16) is None, (name, path, first_mismatch(got, want, 16))
+
+
+@pytest.mark.parametrize("prof", ["basic", "slow", "alpha_basic", "alpha_slow", "veryfast"])
+@pytest.mark.parametrize("levels", [2, 4])
+def test_tie_heavy_content_ordered_argmin(itw, gpu, paths, oracle, prof, levels):
+    """Posterised blocks: many shapes reach the same error, so which part of a split scan holds the winner is decided by
+    the tie rule (table index for modes 0/2, rank key for 1/3/7) -- evaluated at merge time in the wide path."""
+    img = _posterised(128, 256, levels)
+    img[..., 3] = _posterised(128, 256, levels, seed=9)[..., 0]
+    want = oracle.encode_mt("bc7", img, prof)
+    for path in ("wide", "deep"):
+        paths(path)
+        got = _encode(itw, gpu, img, prof)
+        assert first_mismatch(got, want, 16) is None, (path, first_mismatch(got, want, 16))
+
+
+@pytest.mark.parametrize("h,w", [(4, 4), (8, 36), (64, 64), (512, 512), (1024, 1024)])
+def test_wide_path_at_every_split_width(itw, gpu, paths, oracle, h, w):
+    """1 block .. 65 536 blocks: the number of parts per scan goes 16, 16, 16, 4, 1 (launch_bc7_wide); 512 x 512 is the
+    plugin's slice."""
+    from itw_amd import surfaces
+    img = surfaces.ldr_smooth(h, w, seed=surfaces.SEED + 31)
+    for prof in ("slow", "alpha_slow", "basic"):
+        if h * w > 512 * 512 and prof != "slow":
+            continue
+        want = oracle.encode_mt("bc7", img, prof)
+        paths("wide")
+        got = _encode(itw, gpu, img, prof)
+        assert first_mismatch(got, want, 16) is None, (prof, first_mismatch(got, want, 16))
+
+
+def test_custom_settings_on_both_paths(itw, gpu, paths, oracle):
+    from itw_amd import surfaces
+    img = surfaces.ldr_smooth(64, 96, seed=surfaces.SEED + 77)
+    img[..., 3] = surfaces.ldr_uniform(64, 96)[..., 0]
+    for base, tweak in (("basic", {"fastSkipTreshold_mode7": 5}), ("basic", {"fastSkipTreshold_mode1": 0, "fastSkipTreshold_mode3": 7}),
+                        ("alpha_basic", {"mode45_channel0": 2}), ("slow", {"skip_mode2": True}),
+                        ("basic", {"fastSkipTreshold_mode1": 16, "fastSkipTreshold_mode3": 16, "fastSkipTreshold_mode7": 16}),
+                        ("basic", {"fastSkipTreshold_mode1": 17, "fastSkipTreshold_mode3": 2, "fastSkipTreshold_mode7": 17}),   # deep only (LDS keys)
+                        ("basic", {"fastSkipTreshold_mode1": 64, "fastSkipTreshold_mode3": 5}),                                # deep only
+                        ("alpha_slow", {"fastSkipTreshold_mode7": 3}), ("alpha_basic", {"fastSkipTreshold_mode1": 1, "fastSkipTreshold_mode3": 1, "fastSkipTreshold_mode7": 1})):
+        s, so = itw.bc7_profile(base), oracle.bc7_profile(base)
+        for k, v in tweak.items():
+            setattr(s, k, v)
+            setattr(so, k, v)
+        s.refineIterations[7] = so.refineIterations[7] = 2
+        want = oracle.encode("bc7", img, so)
+        for path in ("wide", "deep"):
+            paths(path)
+            got = _encode(itw, gpu, img, s)
+            assert first_mismatch(got, want, 16) is None, (base, tweak, path, first_mismatch(got, want, 16))
