@@ -104,6 +104,7 @@ struct ThreadCtx {
     void*  d_ws = nullptr;  size_t ws_cap = 0;      // BC7 inter-family workspace
     hipStream_t ws_stream = nullptr; bool ws_used = false;
     hipEvent_t  ws_event = nullptr;                 // recorded after each BC7 call: orders the workspace across streams
+    itw::Bc7Aux aux = {nullptr, nullptr, nullptr};  // second stream + fork/join events for the parallel parts of small BC7 calls
     int    device = -1;
     char   info[256] = {0};
     ~ThreadCtx() {
@@ -116,6 +117,9 @@ struct ThreadCtx {
         for (auto e : ev_in) if (e) (void)hipEventDestroy(e);
         for (auto e : ev_done) if (e) (void)hipEventDestroy(e);
         if (ws_event) (void)hipEventDestroy(ws_event);
+        if (aux.stream) (void)hipStreamDestroy(aux.stream);
+        if (aux.fork) (void)hipEventDestroy(aux.fork);
+        if (aux.join) (void)hipEventDestroy(aux.join);
     }
 };
 thread_local ThreadCtx tls;
@@ -135,6 +139,9 @@ void bind_thread_to_current_device()
     for (auto& e : tls.ev_in) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     for (auto& e : tls.ev_done) if (e) { (void)hipEventDestroy(e); e = nullptr; }
     if (tls.ws_event) { (void)hipEventDestroy(tls.ws_event); tls.ws_event = nullptr; }
+    if (tls.aux.stream) { (void)hipStreamDestroy(tls.aux.stream); tls.aux.stream = nullptr; }
+    if (tls.aux.fork) { (void)hipEventDestroy(tls.aux.fork); tls.aux.fork = nullptr; }
+    if (tls.aux.join) { (void)hipEventDestroy(tls.aux.join); tls.aux.join = nullptr; }
     tls.device = dev;
 }
 
@@ -188,7 +195,13 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
     case Fmt::BC1:  itw::launch_bc1(d_src, stride, w, h, d_dst, st); break;
     case Fmt::BC3:  itw::launch_bc3(d_src, stride, w, h, d_dst, st); break;
     case Fmt::BC7:
-        itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st), st);
+        if (!tls.aux.stream) {
+            bind_thread_to_current_device();
+            ITW_CHECK(hipStreamCreateWithFlags(&tls.aux.stream, hipStreamNonBlocking));
+            ITW_CHECK(hipEventCreateWithFlags(&tls.aux.fork, hipEventDisableTiming));
+            ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join, hipEventDisableTiming));
+        }
+        itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st), st, &tls.aux);
         ITW_CHECK(hipEventRecord(tls.ws_event, st));
         break;
     case Fmt::BC6H: itw::launch_bc6h(d_src, stride, w, h, d_dst, *j.s6, st); break;
@@ -244,27 +257,41 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     // A run must still fill the chip several times over (one block per lane: 1024 workgroups = one round of the BC7
     // scans), or the kernels' tails cost more than the copies save -- measured at 4096^2 (tools/host_chunks_probe.py):
     // BC7 slow 9.58 / 9.19 / 9.60 / 11.6 ms for 1 / 2 / 4 / 8 runs, BC6H slow 7.61 / 6.15 / 5.64 / 5.57 ms.
-    // The first run is the largest, so the BC7 workspace is sized once.  BC1/3/4/5 are PCIe-bound: one run.
+    // BC1/3/4/5 are PCIe-bound: one run.
+    // Runs need not be equal: a SHORT FIRST run starts the kernels after an eighth of the upload instead of half of it,
+    // and a shorter last run shortens the download nothing can hide (ITW_HOST_RUNS="f0,f1,.." gives the fractions).
+    int cut[9] = {0, by, 0, 0, 0, 0, 0, 0, 0};        // run c covers block rows [cut[c], cut[c+1])
     int nch = 1;
     if (!src_dev && (j.fmt == Fmt::BC7 || j.fmt == Fmt::BC6H)) {
-        const int min_rows = (j.fmt == Fmt::BC7) ? 512 : 256;     // block rows per run
-        nch = by / min_rows;
-        nch = nch < 1 ? 1 : (nch > 4 ? 4 : nch);
+        if (j.fmt == Fmt::BC7 && (int64_t)bx * by >= 524288)       { nch = 3; cut[1] = by / 8; cut[2] = by / 8 + by / 2; cut[3] = by; }
+        else if (j.fmt == Fmt::BC6H && (int64_t)bx * by >= 262144) { nch = 4; cut[1] = by / 8; cut[2] = by * 3 / 8; cut[3] = by * 11 / 16; cut[4] = by; }
     }
-    if (const char* e = std::getenv("ITW_HOST_CHUNKS")) {         // tuning / test knob (1..8 runs); 1 disables the overlap
+    if (const char* e = std::getenv("ITW_HOST_CHUNKS")) {         // tuning / test knob (1..8 equal runs); 1 disables the overlap
         const int v = std::atoi(e);
-        if (v >= 1 && v <= 8 && !src_dev && by >= 4 * v) nch = v;
+        if (v >= 1 && v <= 8 && !src_dev && by >= 4 * v) { nch = v; for (int c = 0; c <= v; c++) cut[c] = (int)((int64_t)by * c / v); }
     }
-    const int cb = (by + nch - 1) / nch;
+    if (const char* e = std::getenv("ITW_HOST_RUNS")) {           // tuning knob: cumulative fractions "0.125,0.625" -> 3 runs
+        int n = 0; double f[8];
+        for (const char* p = e; *p && n < 7;) { char* q = nullptr; f[n] = std::strtod(p, &q); if (q == p) break; n++; p = (*q == ',') ? q + 1 : q; }
+        if (n > 0 && !src_dev && by >= 64) {
+            nch = n + 1; cut[0] = 0; cut[nch] = by;
+            for (int c = 0; c < n; c++) { int r = (int)(by * f[c]); cut[c + 1] = r < cut[c] + 1 ? cut[c] + 1 : (r > by - (n - c) ? by - (n - c) : r); }
+        }
+    }
+    if (j.fmt == Fmt::BC7) {                           // size the workspace once, for the largest run (growing it frees it,
+        int big = 0;                                   // and hipFree waits for the runs in flight)
+        for (int c = 0; c < nch; c++) if (cut[c + 1] - cut[c] > big) big = cut[c + 1] - cut[c];
+        (void)bc7_workspace(w, big * 4, st);
+    }
     hipStream_t copy = (nch > 1) ? cs : st;
     int c = 0;
-    for (int row0 = 0; row0 < by; row0 += cb, c++) {
-        const int nb = (by - row0 < cb) ? by - row0 : cb;
+    for (c = 0; c < nch; c++) {
+        const int row0 = cut[c], nb = cut[c + 1] - cut[c];
         const size_t y0 = (size_t)row0 * 4;
         const size_t nrows = (rows - y0 < (size_t)nb * 4) ? rows - y0 : (size_t)nb * 4;
         if (!src_dev) {
             const uint8_t* hs = src->ptr + (int64_t)y0 * src->stride;
-            if ((int64_t)src->stride >= (int64_t)row_bytes) {
+            if ((int64_t)src->stride >= (int64_t)row_bytes) {      // (also for tight rows: measured faster than one linear pageable copy)
                 ITW_CHECK(hipMemcpy2DAsync(in + y0 * pitch, pitch, hs, (size_t)src->stride, row_bytes, nrows, hipMemcpyHostToDevice, copy));
             } else {
                 // bottom-up (negative stride) or overlapping rows: the reference just indexes ptr + y*stride with a
@@ -281,7 +308,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         if (!dst_dev && nch > 1) {
             ITW_CHECK(hipEventRecord(tls.ev_done[c], st));
             if (c > 0) {                               // download the previous run while this one computes
-                const size_t off = (size_t)(row0 - cb) * bx * bpb, len = (size_t)cb * bx * bpb;
+                const size_t off = (size_t)cut[c - 1] * bx * bpb, len = (size_t)(cut[c] - cut[c - 1]) * bx * bpb;
                 ITW_CHECK(hipStreamWaitEvent(cs, tls.ev_done[c - 1], 0));
                 ITW_CHECK(hipMemcpyAsync(dst + off, d_dst + off, len, hipMemcpyDeviceToHost, cs));
             }
@@ -289,7 +316,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     }
     if (!dst_dev) {
         if (nch > 1) {
-            const size_t off = (size_t)(c - 1) * cb * bx * bpb;
+            const size_t off = (size_t)cut[c - 1] * bx * bpb;
             ITW_CHECK(hipStreamWaitEvent(cs, tls.ev_done[c - 1], 0));
             ITW_CHECK(hipMemcpyAsync(dst + off, d_dst + off, out_bytes - off, hipMemcpyDeviceToHost, cs));
             ITW_CHECK(hipStreamSynchronize(cs));

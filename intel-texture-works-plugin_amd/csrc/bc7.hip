@@ -884,7 +884,9 @@ __device__ __forceinline__ void clear(Dual& d)
 // winner is found independently (first strict minimum in rotation order) and admitted afterwards against the
 // error left by mode 4 -- the same block the sequential scan produces.
 // Rotations r0 .. r1-1 (the wide path gives each rotation its own wave).
-__device__ __forceinline__ void modes_45_scan(Lane& ln, const bc7_enc_settings& S, int r0, int r1, Dual& best4, int32_t& err4, Dual& best5, int32_t& err5)
+// `which`: bit 0 = mode 4 without index swap, bit 1 = mode 4 swapped, bit 2 = mode 5 (the wide path runs them as separate tasks).
+__device__ __forceinline__ void modes_45_scan(Lane& ln, const bc7_enc_settings& S, int r0, int r1, Dual& best4, int32_t& err4, Dual& best5, int32_t& err5,
+                                              int which = 7)
 {
     for (int r = r0; r < r1; r++) {
         // rotated colour block: channel r is replaced by alpha (RGBA profile) or 255 (RGB profile);
@@ -914,9 +916,9 @@ __device__ __forceinline__ void modes_45_scan(Lane& ln, const bc7_enc_settings& 
         fit[0][3] = 0.f; fit[1][3] = 0.f;
         fit_line<3>(fit, rot, 0xffffu, st, rcp_of_count(16), ln.T);
         const int32_t tt = st.m[0] + st.m[4] + st.m[7];          // |texel|^2 summed over the rotated colour block
-        try_dual<4, 0>(best4, err4, ln, rot, fit, tt, S, r);
-        try_dual<4, 1>(best4, err4, ln, rot, fit, tt, S, r);
-        try_dual<5, 0>(best5, err5, ln, rot, fit, tt, S, r);
+        if (which & 1) try_dual<4, 0>(best4, err4, ln, rot, fit, tt, S, r);
+        if (which & 2) try_dual<4, 1>(best4, err4, ln, rot, fit, tt, S, r);
+        if (which & 4) try_dual<5, 0>(best5, err5, ln, rot, fit, tt, S, r);
     }
 }
 
@@ -1122,32 +1124,35 @@ bc7_finish_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
 // chip idle.  The reference's own answer to small work items is to cut them into bands for more threads
 // (win32Threads.cpp:211-249); the GPU-side equivalent cuts the *search* instead:
 //   phase 1  one launch whose blockIdx.y enumerates independent tasks -- the scan of each multi-subset family split
-//            into `parts` strided shares of its candidate list (lanes stay blocks; another wave takes the other shapes),
-//            each mode 4/5 rotation, mode 6.  A split scan leaves one winner per (mode, part);
-//   phase 2  one launch, blockIdx.y = mode: an ORDERED ARGMIN over the parts' winners -- lowest error, then the
-//            reference's strict-`<` tie rule (lowest table index for modes 0/2, lowest PCA rank key for modes 1/3/7,
-//            kernel.ispc:1320, 1348, 1404-1409; keys are evaluated only on a tie) -- then the least-squares refinement;
+//            into `parts` strided shares of its candidate list (lanes stay blocks; another wave takes the other shapes).
+//            A split scan leaves one winner per (mode, part).  Register budget of the scans: 4 waves per SIMD;
+//   phase 2  one launch, blockIdx.y = task: per multi-subset mode an ORDERED ARGMIN over the parts' winners -- lowest
+//            error, then the reference's strict-`<` tie rule (lowest table index for modes 0/2, lowest PCA rank key for
+//            modes 1/3/7, kernel.ispc:1320, 1348, 1404-1409; keys are evaluated only on a tie) -- then the least-squares
+//            refinement; next to them one task per mode 4/5 rotation and one for mode 6 (2 waves per SIMD);
 //   phase 3  the modes' candidates {error, block} compete in the reference's order 0,2,1,3,7,4,5,6 with strict `<`
 //            (kernel.ispc:1970-1977).
 // Every candidate is evaluated by exactly the code of the deep path (same functions, same arithmetic), only by a different
 // wave, so the emitted block is identical; tests run both paths on the same inputs (ITW_BC7_PATH=deep|wide).
-constexpr int WIDE_SLOTS = 14;            // candidate slots in commit order: m0 m2 m1 m3 m7 m4[r0..r3] m5[r0..r3] m6
+constexpr int WIDE_SLOTS = 18;            // candidate slots in commit order: m0 m2 m1 m3 m7 m4[r0..r3][swap 0,1] m5[r0..r3] m6
+constexpr int WIDE_SLOT_M4 = 5, WIDE_SLOT_M5 = 13, WIDE_SLOT_M6 = 17;
 constexpr int WIDE_MAX_TASKS = 56;
 constexpr int WIDE_MAX_PARTS = 16;
 enum WideKind { WK_SCAN02 = 0, WK_SCAN13 = 1, WK_SCAN7 = 2, WK_ROT45 = 3, WK_MODE6 = 4 };
 struct WideTasks { int n; uint8_t kind[WIDE_MAX_TASKS]; uint8_t part[WIDE_MAX_TASKS]; uint8_t parts[WIDE_MAX_TASKS]; };
-struct WideModes { int n; uint8_t mode[5]; uint8_t parts[5]; uint8_t ranked[5]; uint32_t active_slots; };
+struct WideModes { int n; uint8_t mode[20]; uint8_t parts[20]; };    // mode: 0,2,1,3,7 refine | 100 + 4 r + c: rotation r, candidate c (mode 4, mode 4 swapped, mode 5) | 6
 
 __host__ __device__ constexpr int wide_win_slot(int mode) { return mode == 0 ? 0 : mode == 2 ? 1 : mode == 1 ? 2 : mode == 3 ? 3 : 4; }
 
-// winners of split scans: [win_slot][part][block] x {err, shape, key, -}
-__device__ __forceinline__ void store_win_wide(uint4* __restrict__ wins, int32_t nblocks, int slot, int part, int32_t b, const Win& w)
+// winners of split scans: [win_slot][part][block] x {err, shape, key, -}, `pstride` parts per slot
+struct WideDims { int32_t nblocks; int32_t pstride; };
+__device__ __forceinline__ void store_win_wide(uint4* __restrict__ wins, WideDims d, int slot, int part, int32_t b, const Win& w)
 {
-    wins[((int64_t)slot * WIDE_MAX_PARTS + part) * nblocks + b] = make_uint4((uint32_t)w.err, (uint32_t)w.shape, (uint32_t)w.key, 0u);
+    wins[((int64_t)slot * d.pstride + part) * d.nblocks + b] = make_uint4((uint32_t)w.err, (uint32_t)w.shape, (uint32_t)w.key, 0u);
 }
-__device__ __forceinline__ void load_win_wide(Win& w, const uint4* __restrict__ wins, int32_t nblocks, int slot, int part, int32_t b)
+__device__ __forceinline__ void load_win_wide(Win& w, const uint4* __restrict__ wins, WideDims d, int slot, int part, int32_t b)
 {
-    const uint4 v = wins[((int64_t)slot * WIDE_MAX_PARTS + part) * nblocks + b];
+    const uint4 v = wins[((int64_t)slot * d.pstride + part) * d.nblocks + b];
     w.err = (int32_t)v.x; w.shape = (int32_t)v.y; w.key = (int32_t)v.z;
 }
 __device__ __forceinline__ void store_candidate(int32_t* __restrict__ cerr, uint4* __restrict__ cblk, int32_t nblocks, int slot, int32_t b,
@@ -1183,12 +1188,12 @@ __device__ __forceinline__ int32_t merge_key(const Win& w, const Tex& tx, const 
 
 // Ordered argmin over the parts of one mode's split scan.
 template <int MODE>
-__device__ __forceinline__ void merge_parts(Win& w, Lane& ln, const uint4* __restrict__ wins, int32_t nblocks, int parts, int32_t b, int channels)
+__device__ __forceinline__ void merge_parts(Win& w, Lane& ln, const uint4* __restrict__ wins, WideDims dims, int parts, int32_t b, int channels)
 {
-    load_win_wide(w, wins, nblocks, wide_win_slot(MODE), 0, b);
+    load_win_wide(w, wins, dims, wide_win_slot(MODE), 0, b);
     for (int p = 1; p < parts; p++) {
         Win x;
-        load_win_wide(x, wins, nblocks, wide_win_slot(MODE), p, b);
+        load_win_wide(x, wins, dims, wide_win_slot(MODE), p, b);
         if (x.err < w.err) { w = x; continue; }
         if (x.err != w.err || x.err == ERR_MAX) continue;
         if (MODE == 0 || MODE == 2) {                     // table order: lowest shape index
@@ -1203,11 +1208,18 @@ __device__ __forceinline__ void merge_parts(Win& w, Lane& ln, const uint4* __res
     }
 }
 
-template <bool VEC16>
-__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+#ifndef WIDE_SCAN_WAVES
+#define WIDE_SCAN_WAVES 4
+#endif
+// RANKED_LISTS: some family scans a PCA-ranked prefix (fast presets): that code keeps 16 sorted keys in registers and runs
+// at 3 waves per SIMD like its deep counterpart; the whole-table instantiation (slow presets) compiles it out.
+template <bool VEC16, bool RANKED_LISTS>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(RANKED_LISTS ? 3 : WIDE_SCAN_WAVES, RANKED_LISTS ? 3 : WIDE_SCAN_WAVES)))
 bc7_wide_phase1(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint4* __restrict__ wins,
-                int32_t* __restrict__ cerr, uint4* __restrict__ cblk, const bc7_enc_settings S, const WideTasks tasks, const int ranked13, const int ranked7)
+                int32_t* __restrict__ cerr, uint4* __restrict__ cblk, const bc7_enc_settings S, const WideTasks tasks, const int ranked13, const int ranked7,
+                const int pstride)
 {
+    const WideDims dims{nblocks, pstride};
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
     __shared__ uint2 s_pal[12 * TPB];
@@ -1227,40 +1239,30 @@ bc7_wide_phase1(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_
     if (kind == WK_SCAN02) {
         Win w0, w2;
         search_02(ln, S, w0, w2, part, parts);
-        if (live) { store_win_wide(wins, nblocks, wide_win_slot(0), part, b, w0); if (!S.skip_mode2) store_win_wide(wins, nblocks, wide_win_slot(2), part, b, w2); }
+        if (live) { store_win_wide(wins, dims, wide_win_slot(0), part, b, w0); if (!S.skip_mode2) store_win_wide(wins, dims, wide_win_slot(2), part, b, w2); }
     } else if (kind == WK_SCAN13) {
         Win w1, w3;
-        if (ranked13) search_two_subset<false, 3, 2>(ln, S, w1, w3, part, parts); else search_two_subset<false, 3, 0>(ln, S, w1, w3, part, parts);
-        if (live) { store_win_wide(wins, nblocks, wide_win_slot(1), part, b, w1); store_win_wide(wins, nblocks, wide_win_slot(3), part, b, w3); }
-    } else if (kind == WK_SCAN7) {
-        Win w7, unused;
-        if (S.channels == 4) { if (ranked7) search_two_subset<true, 4, 2>(ln, S, w7, unused, part, parts); else search_two_subset<true, 4, 0>(ln, S, w7, unused, part, parts); }
-        else                 { if (ranked7) search_two_subset<true, 3, 2>(ln, S, w7, unused, part, parts); else search_two_subset<true, 3, 0>(ln, S, w7, unused, part, parts); }
-        if (live) store_win_wide(wins, nblocks, wide_win_slot(7), part, b, w7);
-    } else if (kind == WK_ROT45) {
-        Dual best4, best5;
-        clear(best4); clear(best5);
-        int32_t err4 = ERR_MAX, err5 = ERR_MAX;
-        modes_45_scan(ln, S, part, part + 1, best4, err4, best5, err5);          // part = rotation
-        uint32_t blk[4] = {0u, 0u, 0u, 0u};
-        if (err4 < ERR_MAX) emit_dual<4>(blk, best4);
-        if (live) store_candidate(cerr, cblk, nblocks, 5 + part, b, err4, blk);
-        blk[0] = blk[1] = blk[2] = blk[3] = 0u;
-        if (err5 < ERR_MAX) emit_dual<5>(blk, best5);
-        if (live) store_candidate(cerr, cblk, nblocks, 9 + part, b, err5, blk);
+        if (RANKED_LISTS && ranked13) search_two_subset<false, 3, 2>(ln, S, w1, w3, part, parts); else search_two_subset<false, 3, 0>(ln, S, w1, w3, part, parts);
+        if (live) { store_win_wide(wins, dims, wide_win_slot(1), part, b, w1); store_win_wide(wins, dims, wide_win_slot(3), part, b, w3); }
     } else {
-        if (S.channels == 4) mode_6<4>(ln, S); else mode_6<3>(ln, S);
-        if (live) store_candidate(cerr, cblk, nblocks, 13, b, ln.best_err, ln.best);
+        Win w7, unused;
+        if (S.channels == 4) { if (RANKED_LISTS && ranked7) search_two_subset<true, 4, 2>(ln, S, w7, unused, part, parts); else search_two_subset<true, 4, 0>(ln, S, w7, unused, part, parts); }
+        else                 { if (RANKED_LISTS && ranked7) search_two_subset<true, 3, 2>(ln, S, w7, unused, part, parts); else search_two_subset<true, 3, 0>(ln, S, w7, unused, part, parts); }
+        if (live) store_win_wide(wins, dims, wide_win_slot(7), part, b, w7);
     }
 }
 
-template <bool VEC16>
+// SINGLES = false: the refine tasks (modes 0,2,1,3,7; need phase 1).  SINGLES = true: the single-subset tasks (mode 4/5
+// candidates, mode 6), which depend on nothing and run on a second stream beside phase 1 when the caller provides one.
+template <bool VEC16, bool SINGLES>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bc7_wide_phase2(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, const uint4* __restrict__ wins,
-                int32_t* __restrict__ cerr, uint4* __restrict__ cblk, const bc7_enc_settings S, const WideModes modes)
+                int32_t* __restrict__ cerr, uint4* __restrict__ cblk, const bc7_enc_settings S, const WideModes modes, const int pstride)
 {
+    const WideDims dims{nblocks, pstride};
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
+    __shared__ uint2 s_pal[SINGLES ? 8 * TPB : 1]; // one palette per lane for the mode 4/5 vector part
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
@@ -1268,7 +1270,7 @@ bc7_wide_phase2(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_
     const bool live = gid < nblocks;
     const int32_t b = live ? gid : nblocks - 1;
     ln.keys = nullptr;
-    ln.pal = nullptr;
+    ln.pal = s_pal + (SINGLES ? threadIdx.x : 0);
     load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
     ln.best_err = ERR_MAX; ln.improved = false;
     ln.best[0] = ln.best[1] = ln.best[2] = ln.best[3] = 0u;
@@ -1280,13 +1282,36 @@ bc7_wide_phase2(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_
         ln.opaque_err = (int32_t)e;
     }
     const int mode = modes.mode[blockIdx.y], parts = modes.parts[blockIdx.y];      // wave-uniform
+    if (SINGLES && mode >= 100) {                                                  // one mode 4/5 candidate of one rotation
+        const int r = (mode - 100) >> 2, c = (mode - 100) & 3;
+        Dual best4, best5;
+        clear(best4); clear(best5);
+        int32_t err4 = ERR_MAX, err5 = ERR_MAX;
+        modes_45_scan(ln, S, r, r + 1, best4, err4, best5, err5, c == 3 ? 7 : 1 << c);       // c == 3: all three in this wave
+        uint32_t blk[4] = {0u, 0u, 0u, 0u};
+        if (c != 2) {                                     // mode 4 (c == 3: the better of both swaps, first wins a tie: slot of swap 0)
+            if (err4 < ERR_MAX) emit_dual<4>(blk, best4);
+            if (live) store_candidate(cerr, cblk, nblocks, WIDE_SLOT_M4 + 2 * r + (c == 1 ? 1 : 0), b, err4, blk);
+        }
+        if (c >= 2) {
+            blk[0] = blk[1] = blk[2] = blk[3] = 0u;
+            if (err5 < ERR_MAX) emit_dual<5>(blk, best5);
+            if (live) store_candidate(cerr, cblk, nblocks, WIDE_SLOT_M5 + r, b, err5, blk);
+        }
+        return;
+    }
+    if (SINGLES) {                                                                 // mode 6
+        if (S.channels == 4) mode_6<4>(ln, S); else mode_6<3>(ln, S);
+        if (live) store_candidate(cerr, cblk, nblocks, WIDE_SLOT_M6, b, ln.best_err, ln.best);
+        return;
+    }
     Win w;
     int slot = 0;
-    if (mode == 0)      { merge_parts<0>(w, ln, wins, nblocks, parts, b, S.channels); refine_and_commit<0>(ln, w, S.refineIterations[0], S.channels); slot = 0; }
-    else if (mode == 2) { merge_parts<2>(w, ln, wins, nblocks, parts, b, S.channels); refine_and_commit<2>(ln, w, S.refineIterations[2], S.channels); slot = 1; }
-    else if (mode == 1) { merge_parts<1>(w, ln, wins, nblocks, parts, b, S.channels); refine_and_commit<1>(ln, w, S.refineIterations[1], S.channels); slot = 2; }
-    else if (mode == 3) { merge_parts<3>(w, ln, wins, nblocks, parts, b, S.channels); refine_and_commit<3>(ln, w, S.refineIterations[3], S.channels); slot = 3; }
-    else                { merge_parts<7>(w, ln, wins, nblocks, parts, b, S.channels); refine_and_commit<7>(ln, w, S.refineIterations[7], S.channels); slot = 4; }
+    if (mode == 0)      { merge_parts<0>(w, ln, wins, dims, parts, b, S.channels); refine_and_commit<0>(ln, w, S.refineIterations[0], S.channels); slot = 0; }
+    else if (mode == 2) { merge_parts<2>(w, ln, wins, dims, parts, b, S.channels); refine_and_commit<2>(ln, w, S.refineIterations[2], S.channels); slot = 1; }
+    else if (mode == 1) { merge_parts<1>(w, ln, wins, dims, parts, b, S.channels); refine_and_commit<1>(ln, w, S.refineIterations[1], S.channels); slot = 2; }
+    else if (mode == 3) { merge_parts<3>(w, ln, wins, dims, parts, b, S.channels); refine_and_commit<3>(ln, w, S.refineIterations[3], S.channels); slot = 3; }
+    else                { merge_parts<7>(w, ln, wins, dims, parts, b, S.channels); refine_and_commit<7>(ln, w, S.refineIterations[7], S.channels); slot = 4; }
     if (live) store_candidate(cerr, cblk, nblocks, slot, b, ln.best_err, ln.best);
 }
 
@@ -1328,7 +1353,7 @@ static void launch_finish(Bc7Launch& L)
 
 // Calls of at most this many blocks take the wide path (measured crossover on MI355X, tools/bc7_path_probe.py).
 #ifndef ITW_BC7_WIDE_MAX_BLOCKS
-#define ITW_BC7_WIDE_MAX_BLOCKS 131072
+#define ITW_BC7_WIDE_MAX_BLOCKS 262144
 #endif
 
 // 0 = by size, 1 = deep always, 2 = wide whenever it supports the settings (itwSetBc7Path / ITW_BC7_PATH=deep|wide:
@@ -1366,10 +1391,12 @@ static bool bc7_use_wide(int64_t n, const bc7_enc_settings& S)
 }
 
 // deep: best error so far (4 B/block) + the winners of one family's two modes (2 x 16 B/block)
-// wide: winners [5 modes][16 parts] x 16 B + candidates [14 slots] x (4 + 16) B per block
+// wide: winners [5 modes][parts] x 16 B + candidates [18 slots] x (4 + 16) B per block
+// a scan is split while that keeps all its waves resident at once (launch_bc7_wide): parts * blocks <= max(blocks, 262144)
+static size_t wide_win_entries(size_t n) { return n > 262144 ? n : 262144; }
 static size_t wide_workspace_bytes(size_t n)
 {
-    return (size_t)5 * WIDE_MAX_PARTS * n * sizeof(uint4) + (((size_t)WIDE_SLOTS * n * sizeof(int32_t) + 15) & ~(size_t)15) + (size_t)WIDE_SLOTS * n * sizeof(uint4);
+    return (size_t)5 * wide_win_entries(n) * sizeof(uint4) + (((size_t)WIDE_SLOTS * n * sizeof(int32_t) + 15) & ~(size_t)15) + (size_t)WIDE_SLOTS * n * sizeof(uint4);
 }
 size_t bc7_workspace_bytes(int width, int height)
 {
@@ -1380,10 +1407,11 @@ size_t bc7_workspace_bytes(int width, int height)
     return deep > wide ? deep : wide;
 }
 
-static void launch_bc7_wide(const uint8_t* src, int64_t stride, int bx, int64_t n, uint8_t* dst, const bc7_enc_settings& S, float* workspace, hipStream_t st)
+static void launch_bc7_wide(const uint8_t* src, int64_t stride, int bx, int64_t n, uint8_t* dst, const bc7_enc_settings& S, float* workspace,
+                            hipStream_t st, const Bc7Aux* aux)
 {
     uint4* wins = reinterpret_cast<uint4*>(workspace);
-    int32_t* cerr = reinterpret_cast<int32_t*>(wins + (size_t)5 * WIDE_MAX_PARTS * n);
+    int32_t* cerr = reinterpret_cast<int32_t*>(wins + (size_t)5 * wide_win_entries((size_t)n));
     uint4* cblk = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(cerr) + (((size_t)WIDE_SLOTS * n * sizeof(int32_t) + 15) & ~(size_t)15));
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     auto ranked = [](int t) { return t > 0 && t < 64; };
@@ -1394,47 +1422,86 @@ static void launch_bc7_wide(const uint8_t* src, int64_t stride, int bx, int64_t 
     const bool on45 = S.mode_selection[2], on6 = S.mode_selection[3];
     const int ranked13 = on13 && (ranked(S.fastSkipTreshold_mode1) || ranked(S.fastSkipTreshold_mode3));
     const int ranked7 = on7 && ranked(S.fastSkipTreshold_mode7);
+    const bool any_ranked = ranked13 || ranked7;
 
-    // parts per scan: enough waves to cover the chip about four times (1024 SIMDs), within what the candidate lists offer
+    // parts per scan: as many waves as stay resident at once (1024 SIMDs x the scan kernel's waves), within what the
+    // candidate lists offer
     const int64_t waves = (n + 63) / 64;
     const int families = (on02 ? 1 : 0) + (on13 ? 1 : 0) + (on7 ? 1 : 0);
+    const int resident = 1024 * (any_ranked ? 3 : WIDE_SCAN_WAVES);
     int want = 1;
-    while (want < WIDE_MAX_PARTS && waves * families * want * 2 <= 4096) want *= 2;
+    while (want < WIDE_MAX_PARTS && waves * families * want * 2 <= resident) want *= 2;
     auto cap = [&](int limit) { int p = want; while (p > limit) p /= 2; return p < 1 ? 1 : p; };
-    const int p02 = cap(S.skip_mode2 ? 16 : 16);                                  // 16 or 64 shapes
+    const int p02 = cap(16);                                                        // 16 or 64 shapes
     const int list13 = ranked13 ? (S.fastSkipTreshold_mode1 > S.fastSkipTreshold_mode3 ? S.fastSkipTreshold_mode1 : S.fastSkipTreshold_mode3) : 64;
     const int p13 = cap(ranked13 ? (list13 >= 8 ? 4 : list13 >= 2 ? 2 : 1) : 16);   // a ranked share recomputes the 64 keys: few parts
     const int list7 = ranked7 ? S.fastSkipTreshold_mode7 : 64;
     const int p7 = cap(ranked7 ? (list7 >= 8 ? 4 : list7 >= 2 ? 2 : 1) : 16);
+    int pstride = 1;                                                               // rows of the winners array per mode
+    if (on02 && p02 > pstride) pstride = p02;
+    if (on13 && p13 > pstride) pstride = p13;
+    if (on7 && p7 > pstride) pstride = p7;
 
     WideTasks T;
     std::memset(&T, 0, sizeof T);
     auto add = [&](int kind, int part, int parts) { T.kind[T.n] = (uint8_t)kind; T.part[T.n] = (uint8_t)part; T.parts[T.n] = (uint8_t)parts; T.n++; };
-    WideModes M;
-    std::memset(&M, 0, sizeof M);
-    auto add_mode = [&](int mode, int parts) { M.mode[M.n] = (uint8_t)mode; M.parts[M.n] = (uint8_t)parts; M.n++; M.active_slots |= 1u << wide_win_slot(mode); };
-    // longest tasks first: the launch drains in blockIdx order
-    if (on13) { for (int p = 0; p < p13; p++) add(WK_SCAN13, p, p13); if (S.fastSkipTreshold_mode1 > 0) add_mode(1, p13); if (S.fastSkipTreshold_mode3 > 0) add_mode(3, p13); }
-    if (on02) { for (int p = 0; p < p02; p++) add(WK_SCAN02, p, p02); add_mode(0, p02); if (!S.skip_mode2) add_mode(2, p02); }
-    if (on7)  { for (int p = 0; p < p7; p++) add(WK_SCAN7, p, p7); add_mode(7, p7); }
-    if (on45) for (int r = S.mode45_channel0; r < (S.channels == 4 ? 4 : 3); r++) { add(WK_ROT45, r, 1); M.active_slots |= (1u << (5 + r)) | (1u << (9 + r)); }
-    if (on6)  { add(WK_MODE6, 0, 1); M.active_slots |= 1u << 13; }
+    WideModes R, G;                                       // refine tasks (after the scans), single-subset tasks (independent)
+    std::memset(&R, 0, sizeof R);
+    std::memset(&G, 0, sizeof G);
+    uint32_t active = 0;
+    auto add_refine = [&](int mode, int parts) { R.mode[R.n] = (uint8_t)mode; R.parts[R.n] = (uint8_t)parts; R.n++; active |= 1u << wide_win_slot(mode); };
+    auto add_single = [&](int code) { G.mode[G.n] = (uint8_t)code; G.parts[G.n] = 1; G.n++; };
+    // longest tasks first: a launch drains in blockIdx order
+    if (on13) { for (int p = 0; p < p13; p++) add(WK_SCAN13, p, p13); if (S.fastSkipTreshold_mode1 > 0) add_refine(1, p13); if (S.fastSkipTreshold_mode3 > 0) add_refine(3, p13); }
+    if (on02) { for (int p = 0; p < p02; p++) add(WK_SCAN02, p, p02); add_refine(0, p02); if (!S.skip_mode2) add_refine(2, p02); }
+    if (on7)  { for (int p = 0; p < p7; p++) add(WK_SCAN7, p, p7); add_refine(7, p7); }
+    if (on45) {
+        // one wave per rotation, or one per (rotation, candidate) while all those waves (2 per SIMD) stay resident at once
+        const int rots = (S.channels == 4 ? 4 : 3) - S.mode45_channel0;
+        const bool split = waves * (3 * rots + (on6 ? 1 : 0) + (aux ? 0 : R.n)) <= 2048;
+        for (int r = S.mode45_channel0; r < (S.channels == 4 ? 4 : 3); r++) {
+            if (split) { for (int c = 0; c < 3; c++) add_single(100 + 4 * r + c); active |= 3u << (WIDE_SLOT_M4 + 2 * r); }
+            else       { add_single(100 + 4 * r + 3); active |= 1u << (WIDE_SLOT_M4 + 2 * r); }
+            active |= 1u << (WIDE_SLOT_M5 + r);
+        }
+    }
+    if (on6)  { add_single(6); active |= 1u << WIDE_SLOT_M6; }
 
     const unsigned gx = (unsigned)((n + TPB - 1) / TPB);
+    const dim3 blk(TPB);
+    // the single-subset tasks need nothing from the scans: beside them on the caller-provided second stream, else after them
+    hipStream_t gs = st;
+    if (aux && G.n > 0 && T.n > 0) {
+        (void)hipEventRecord(aux->fork, st);               // whatever feeds `src` on st (an upload) comes first
+        (void)hipStreamWaitEvent(aux->stream, aux->fork, 0);
+        gs = aux->stream;
+    }
+    if (G.n > 0) {
+        if (vec) hipLaunchKernelGGL((bc7_wide_phase2<true, true>),  dim3(gx, (unsigned)G.n), blk, 0, gs, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, G, pstride);
+        else     hipLaunchKernelGGL((bc7_wide_phase2<false, true>), dim3(gx, (unsigned)G.n), blk, 0, gs, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, G, pstride);
+        if (gs != st) (void)hipEventRecord(aux->join, gs);
+    }
     if (T.n > 0) {
-        if (vec) hipLaunchKernelGGL((bc7_wide_phase1<true>),  dim3(gx, (unsigned)T.n), dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, T, ranked13, ranked7);
-        else     hipLaunchKernelGGL((bc7_wide_phase1<false>), dim3(gx, (unsigned)T.n), dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, T, ranked13, ranked7);
+        const dim3 grid(gx, (unsigned)T.n);
+        if (any_ranked) {
+            if (vec) hipLaunchKernelGGL((bc7_wide_phase1<true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, T, ranked13, ranked7, pstride);
+            else     hipLaunchKernelGGL((bc7_wide_phase1<false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, T, ranked13, ranked7, pstride);
+        } else {
+            if (vec) hipLaunchKernelGGL((bc7_wide_phase1<true, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, T, ranked13, ranked7, pstride);
+            else     hipLaunchKernelGGL((bc7_wide_phase1<false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, T, ranked13, ranked7, pstride);
+        }
     }
-    if (M.n > 0) {
-        if (vec) hipLaunchKernelGGL((bc7_wide_phase2<true>),  dim3(gx, (unsigned)M.n), dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, M);
-        else     hipLaunchKernelGGL((bc7_wide_phase2<false>), dim3(gx, (unsigned)M.n), dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, M);
+    if (R.n > 0) {
+        if (vec) hipLaunchKernelGGL((bc7_wide_phase2<true, false>),  dim3(gx, (unsigned)R.n), blk, 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, R, pstride);
+        else     hipLaunchKernelGGL((bc7_wide_phase2<false, false>), dim3(gx, (unsigned)R.n), blk, 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, S, R, pstride);
     }
-    hipLaunchKernelGGL(bc7_wide_commit, dim3(gx), dim3(TPB), 0, st, cerr, cblk, (int32_t)n, M.active_slots, reinterpret_cast<uint4*>(dst), vec ? 1 : 0);
+    if (gs != st) (void)hipStreamWaitEvent(st, aux->join, 0);
+    hipLaunchKernelGGL(bc7_wide_commit, dim3(gx), blk, 0, st, cerr, cblk, (int32_t)n, active, reinterpret_cast<uint4*>(dst), vec ? 1 : 0);
 }
 
 // Families run in the reference's order (kernel.ispc:1970-1977): {0,2} -> {1,3} -> {7} -> {4,5} -> {6}.
 void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
-                const bc7_enc_settings& s, float* workspace, hipStream_t st)
+                const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux)
 {
     const int bx = width / 4, by = height / 4;
     const int64_t n = (int64_t)bx * by;
@@ -1442,7 +1509,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
     Bc7Launch L;
     L.S = s;
     L.S.channels = (s.channels == 4) ? 4 : 3;
-    if (bc7_use_wide(n, L.S)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st); return; }
+    if (bc7_use_wide(n, L.S)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st, aux); return; }
     L.err = reinterpret_cast<int32_t*>(workspace);
     L.wins = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(workspace) + (((size_t)n * sizeof(int32_t) + 15) & ~(size_t)15));
     L.vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
