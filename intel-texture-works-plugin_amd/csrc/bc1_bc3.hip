@@ -8,8 +8,9 @@
 // row loads is one global_load_dwordx4 per lane and 1 KiB contiguous per wave --
 // fully coalesced without an LDS transpose.  Outputs are 8 (BC1) or 16 (BC3)
 // contiguous bytes per lane.  The kernel is a stream: 64 B in, 8/16 B out and
-// ~1.5 k VALU operations per block, so it sits near the HBM/VALU ridge; there is
-// no reuse to stage in LDS and nothing matrix shaped for MFMA.
+// ~1.1 k VALU instructions per block, so it sits near the HBM/VALU ridge and is bound
+// by VALU issue; nothing matrix shaped for MFMA.  LDS holds only
+// lookup tables (reciprocal seeds, 565 quantisation), staged once per workgroup.
 //
 // Arithmetic is the pinned x86 model of x86_math.hpp; float sums run serially in
 // texel order k = 0..15 inside the lane, exactly like one ISPC program instance.
@@ -18,109 +19,229 @@
 
 namespace itw {
 
-// 8-bit -> 5/6-bit with rounding, (t + (t>>8)) >> 8 form.   [kernel.ispc:234-248]
-__device__ __forceinline__ int32_t scale8(int32_t a, int32_t b)
+// ---- per-workgroup tables in LDS ------------------------------------------------------------------------------------
+// The kernel is bound by VALU issue, not by HBM: every instruction that is not one of the reference's
+// fp32 multiplies / adds is overhead worth removing.  Three table families, staged once per workgroup (the workgroup then
+// walks several chunks of 256 blocks, so the staging is amortised):
+//   * RSQRTPS seeds pre-expanded to words (x86_math.hpp, as in the BC7 kernels);
+//   * RCPPS seeds pre-expanded the same way: a reciprocal seed of an ordinary operand is one LDS word minus the operand's
+//     exponent field (x86_rcpps_fast below), instead of ~20 bit operations and three special-case selects;
+//   * 8 bit -> 5/6 bit endpoint quantisation (kernel.ispc:234-248: (t + (t >> 8)) >> 8 with t = v*31 + 128) and the
+//     decoded value of the code (kernel.ispc:250-259: bit replication), as two byte tables each, indexed by the
+//     truncated endpoint: packing an endpoint is a conversion and a byte read per channel.
+// The expanded seed words and the 565 tables as one ready-made image (21 KiB), built at compile time from the packed
+// seed tables: a workgroup stages it with plain 16-byte copies.
+namespace tables_src {
+#define X86_LUT_QUAL static constexpr
+#include "x86_luts_packed.h"
+#undef X86_LUT_QUAL
+}
+struct Bc1Image {
+    uint32_t rsq32[2048];       // x86_rsqrtps_fast's words (x86_math.hpp stage_seed_tables_fast)
+    uint32_t rcp32[2048];       // RCPPS seed mantissa | exponent field 253
+    unsigned short rcp16[2048]; // packed RCPPS seeds for the general model
+    uint8_t q[1024];            // q5 | q6 | d5 | d6
+};
+constexpr Bc1Image make_bc1_image()
 {
-    const int32_t t = a * b + 128;
-    return (t + (t >> 8)) >> 8;
+    Bc1Image im{};
+    for (int i = 0; i < 2048; i++) {
+        im.rsq32[i] = (0x3f000000u | ((uint32_t)tables_src::X86_RSQRT_SEED16[i ^ 0x400] << 11)) + 0x20000000u;
+        im.rcp32[i] = 0x7e800000u | ((uint32_t)tables_src::X86_RCP_SEED16[i] << 11);
+        im.rcp16[i] = tables_src::X86_RCP_SEED16[i];
+    }
+    for (int v = 0; v < 256; v++) {
+        const int t5 = v * 31 + 128, t6 = v * 63 + 128;
+        const int c5 = (t5 + (t5 >> 8)) >> 8, c6 = (t6 + (t6 >> 8)) >> 8;
+        im.q[v] = (uint8_t)c5; im.q[256 + v] = (uint8_t)c6;
+        im.q[512 + v] = (uint8_t)((c5 << 3) + (c5 >> 2)); im.q[768 + v] = (uint8_t)((c6 << 2) + (c6 >> 4));
+    }
+    return im;
+}
+__device__ const Bc1Image BC1_IMAGE = make_bc1_image();
+static_assert(sizeof(Bc1Image) == 8192 + 8192 + 4096 + 1024, "Bc1Image layout");
+
+struct Bc1Tables {
+    SeedTables T;
+    const uint32_t* rcp32;      // [2048] RCPPS seed word | exponent 253, indexed by mantissa[22:12]
+    const uint8_t* q5;          // [256]  5-bit code of a byte value
+    const uint8_t* q6;          // [256]  6-bit code
+    const uint8_t* d5;          // [256]  value a decoder reconstructs from q5[v]
+    const uint8_t* d6;          // [256]
+};
+
+constexpr int BC1_LDS_BYTES = (int)sizeof(Bc1Image);
+
+__device__ __forceinline__ Bc1Tables stage_bc1_tables(unsigned char* lds, int tid, int nthreads)
+{
+    const uint4* src = reinterpret_cast<const uint4*>(&BC1_IMAGE);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    for (int i = tid; i < BC1_LDS_BYTES / 16; i += nthreads) dst[i] = src[i];
+    const Bc1Image* im = reinterpret_cast<const Bc1Image*>(lds);
+    Bc1Tables B;
+    B.T = SeedTables{im->rcp16, X86_RSQRT_SEED16, im->rsq32};
+    B.rcp32 = im->rcp32; B.q5 = im->q; B.q6 = im->q + 256; B.d5 = im->q + 512; B.d6 = im->q + 768;
+    return B;
 }
 
-// inputs are clamped to [0,255] by the callers (fclamp_x86 maps NaN to 0), so the plain conversion is cvttps2dq
-__device__ __forceinline__ int32_t pack565(float cr, float cg, float cb)
+// RCPPS of an ordinary operand (exponent field 1..252, either sign): the seed's exponent is 253 - e and its mantissa
+// comes from the table, i.e. seed = word(mantissa[22:12]) - (e << 23), sign copied.  Zero, denormal, huge, inf and NaN
+// operands take the general model (x86_math.hpp) in a divergent branch.  Same function as x86_rcpps for every input.
+__device__ __forceinline__ float x86_rcpps_fast(float v, const Bc1Tables& B)
 {
-    return ((scale8(cvt_i32_sat(cr), 31) << 11) + (scale8(cvt_i32_sat(cg), 63) << 5) + scale8(cvt_i32_sat(cb), 31)) & 0xffff;
+    const uint32_t x = __float_as_uint(v);
+    const uint32_t ax = x & 0x7fffffffu;
+    if (__builtin_expect((ax - 0x00800000u) >= 0x7e000000u, 0)) return x86_rcpps(v, B.T.rcp);
+    const uint32_t t = B.rcp32[(x >> 12) & 0x7ffu];
+    return __uint_as_float((t - (ax & 0x7f800000u)) | (x & 0x80000000u));
+}
+__device__ __forceinline__ float rcp_nr(float v, const Bc1Tables& B)               // ISPC rcp(): r * (2 - v*r)
+{
+    const float r = x86_rcpps_fast(v, B);
+    float t = v * r;
+    t = 2.0f - t;
+    return r * t;
 }
 
-__device__ __forceinline__ void unpack565(int32_t p, float c[3])        // [kernel.ispc:250-259]
+// ---- the lane's texels -------------------------------------------------------------------------------------------------
+// Kept as aligned register pairs so that the sums whose products cannot round -- the covariance of the centred texels
+// (multiples of 1/16 below 2^8: products are multiples of 1/256 below 2^16, exact in fp32) and the refit's index-weighted
+// sums (small integers) -- can run on v_pk_fma_f32, two multiply-adds per issue slot: with an exact product
+// fma(a, b, c) = round(c + a*b) is bit for bit the reference's separate multiply and add, in the same texel order.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct Texels {
+    f2 rg[16];          // (R, G) of texel k
+    f2 b2[8];           // B of texels (2j, 2j+1)
+    __device__ __forceinline__ float r(int k) const { return rg[k].x; }
+    __device__ __forceinline__ float g(int k) const { return rg[k].y; }
+    __device__ __forceinline__ float b(int k) const { return (k & 1) ? b2[k >> 1].y : b2[k >> 1].x; }
+    __device__ __forceinline__ float ch(int p, int k) const { return p == 0 ? r(k) : (p == 1 ? g(k) : b(k)); }
+};
+// c += a * b per half; SEL picks which halves of b feed the low / high result (v_pk_fma_f32 op_sel / op_sel_hi)
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { asm("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b)); return c; }
+__device__ __forceinline__ f2 pk_fma_alo_b(f2 a, f2 b, f2 c)      // (a.lo*b.lo, a.lo*b.hi)
+{ asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(c) : "v"(a), "v"(b)); return c; }
+__device__ __forceinline__ f2 pk_fma_a_bhi(f2 a, f2 b, f2 c)      // (a.lo*b.hi, a.hi*b.hi)
+{ asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(c) : "v"(a), "v"(b)); return c; }
+__device__ __forceinline__ f2 pk_fma_a_blo(f2 a, f2 b, f2 c)      // (a.lo*b.lo, a.hi*b.lo)
+{ asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(c) : "v"(a), "v"(b)); return c; }
+
+// an endpoint channel already clamped to [0,255] (NaN clamps to 0): its truncation indexes the byte tables
+__device__ __forceinline__ int32_t trunc_byte(float c) { return cvt_i32_sat(c); }
+
+struct Endpoint { int32_t code; float dec[3]; };                                  // 565 code + the colour it decodes to
+
+__device__ __forceinline__ Endpoint quantise565(float cr, float cg, float cb, const Bc1Tables& B)   // [kernel.ispc:234-259]
 {
-    const int32_t b5 = p & 31, g6 = (p >> 5) & 63, r5 = (p >> 11) & 31;
-    c[0] = (float)((r5 << 3) + (r5 >> 2));
-    c[1] = (float)((g6 << 2) + (g6 >> 4));
-    c[2] = (float)((b5 << 3) + (b5 >> 2));
+    const int32_t ir = trunc_byte(cr), ig = trunc_byte(cg), ib = trunc_byte(cb);
+    Endpoint e;
+    e.code = (int32_t)(((uint32_t)B.q5[ir] << 11) | ((uint32_t)B.q6[ig] << 5) | (uint32_t)B.q5[ib]);
+    e.dec[0] = (float)B.d5[ir]; e.dec[1] = (float)B.d6[ig]; e.dec[2] = (float)B.d5[ib];
+    return e;
 }
 
-// Project the 16 texels on the endpoint segment and emit linear 2-bit indices.
-// [kernel.ispc:308-344]
-__device__ __forceinline__ uint32_t project_indices(const float (&px)[3][16], int32_t p0, int32_t p1, const SeedTables& T)
+// keep the four-colour mode: p0 >= p1                                            [kernel.ispc:517-520, 525-528]
+__device__ __forceinline__ void order(Endpoint& a, Endpoint& b)
 {
-    float c0[3], c1[3], dir[3];
-    unpack565(p0, c0);
-    unpack565(p1, c1);
-    for (int p = 0; p < 3; p++) dir[p] = c1[p] - c0[p];
+    const bool sw = a.code < b.code;
+    const int32_t ca = sw ? b.code : a.code, cb = sw ? a.code : b.code;
+    a.code = ca; b.code = cb;
+#pragma unroll
+    for (int p = 0; p < 3; p++) { const float x = sw ? b.dec[p] : a.dec[p], y = sw ? a.dec[p] : b.dec[p]; a.dec[p] = x; b.dec[p] = y; }
+}
 
-    float sq_norm = 0.f;
-    for (int p = 0; p < 3; p++) sq_norm += sq(dir[p]);
-    const float rs3 = ispc_rcp(sq_norm, T) * 3.0f;
+// Project the 16 texels on the endpoint segment and emit linear 2-bit indices.   [kernel.ispc:308-344]
+// Also returns each texel's index as a float (the refit's weights) when WANT_Q.
+template <bool WANT_Q>
+__device__ __forceinline__ uint32_t project_indices(const Texels& px, const Endpoint& e0, const Endpoint& e1, const Bc1Tables& B,
+                                                    f2 (&qf)[8])
+{
+    float dir[3];
+    for (int p = 0; p < 3; p++) dir[p] = e1.dec[p] - e0.dec[p];
+
+    float sq_norm = sq(dir[0]);                      // 0 + x*x = x*x exactly
+    sq_norm += sq(dir[1]); sq_norm += sq(dir[2]);
+    const float rs3 = rcp_nr(sq_norm, B) * 3.0f;
     for (int p = 0; p < 3; p++) dir[p] *= rs3;
 
     float bias = 0.5f;
-    for (int p = 0; p < 3; p++) bias -= c0[p] * dir[p];
+    for (int p = 0; p < 3; p++) bias -= e0.dec[p] * dir[p];
 
     uint32_t bits = 0;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        float dot = 0.f;
-        for (int p = 0; p < 3; p++) dot += px[p][k] * dir[p];
+        float dot = px.r(k) * dir[0];                // the reference's 0 + a = a: exact (the sign of a zero cannot reach q)
+        dot += px.g(k) * dir[1]; dot += px.b(k) * dir[2];
         // finite and small (|dir| <= 3*255, texels <= 255) or NaN when p0 == p1 (rcp(0)): NaN -> 0 on both routes after the clamp
         const int32_t q = iclamp(cvt_i32_sat(dot + bias), 0, 3);
-        bits += (uint32_t)q << (2 * k);           // q*4^k, no carries: q < 4
+        bits |= (uint32_t)q << (2 * k);
+        if (WANT_Q) { if (k & 1) qf[k >> 1].y = (float)q; else qf[k >> 1].x = (float)q; }
     }
     return bits;
 }
 
 // Least-squares endpoint update for fixed indices.               [kernel.ispc:419-480]
-__device__ __forceinline__ void refit_endpoints(int32_t pe[2], const float (&px)[3][16], uint32_t bits,
-                                                const float dc[3], const SeedTables& T)
+// Exact integer identities (every partial sum below 2^24): with S_p = sum q*px and A_p = 16*dc_p = sum px, the reference's
+// atb1 = sum (3-q)*px = 3*A_p - S_p and atb2 = 3*A_p - atb1 = S_p; sum_q and sum_qq are bit counts of the index word
+// (q = 2h + l: sum q = 2*pop(H) + pop(L), sum q*q = 4*pop(H) + pop(L) + 4*pop(H & L)).
+__device__ __forceinline__ void refit_endpoints(float (&c0)[3], float (&c1)[3], const Texels& px, uint32_t bits, const f2 (&qf)[8],
+                                                const float (&acc)[3], const float (&dc)[3], const Bc1Tables& B)
 {
-    float c0[3], c1[3];
     if ((bits ^ (bits * 4u)) < 4u) {
         for (int p = 0; p < 3; p++) { c0[p] = dc[p]; c1[p] = dc[p]; }
-    } else {
-        float atb1[3] = {0.f, 0.f, 0.f};
-        float sum_q = 0.f, sum_qq = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const float q = (float)(int32_t)((bits >> (2 * k)) & 3u);
-            const float x = 3.0f - q;
-            sum_q += q;
-            sum_qq += q * q;
-            for (int p = 0; p < 3; p++) atb1[p] += x * px[p][k];
-        }
-        const float cxx = 144.0f - 6.0f * sum_q + sum_qq;
-        const float cyy = sum_qq;
-        const float cxy = 3.0f * sum_q - sum_qq;
-        const float scale = 3.0f * ispc_rcp(cxx * cyy - cxy * cxy, T);
-        for (int p = 0; p < 3; p++) {
-            const float sum = dc[p] * 16.0f;
-            const float atb2 = 3.0f * sum - atb1[p];
-            c0[p] = fclamp_num((atb1[p] * cyy - atb2 * cxy) * scale, 0.f, 255.f);
-            c1[p] = fclamp_num((atb2 * cxx - atb1[p] * cxy) * scale, 0.f, 255.f);
-        }
+        return;
     }
-    pe[0] = pack565(c0[0], c0[1], c0[2]);
-    pe[1] = pack565(c1[0], c1[1], c1[2]);
+    // S = sum q*px: integers (<= 3*255*16), so packed multiply-adds are exact whatever the order
+    f2 srg = {0.f, 0.f}, sb = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        srg = pk_fma_a_blo(px.rg[2 * j], qf[j], srg);            // (R, G) of texel 2j   times q(2j)
+        srg = pk_fma_a_bhi(px.rg[2 * j + 1], qf[j], srg);        // (R, G) of texel 2j+1 times q(2j+1)
+        sb = pk_fma(px.b2[j], qf[j], sb);                        // B of both texels, each times its q
+    }
+    const float s[3] = {srg.x, srg.y, sb.x + sb.y};
+    const uint32_t lo = bits & 0x55555555u, hi = (bits >> 1) & 0x55555555u;
+    const int32_t pl = __builtin_popcount(lo), ph = __builtin_popcount(hi), pb = __builtin_popcount(lo & hi);
+    const float sum_q = (float)(2 * ph + pl), sum_qq = (float)(4 * ph + pl + 4 * pb);
+    const float cxx = 144.0f - 6.0f * sum_q + sum_qq;
+    const float cyy = sum_qq;
+    const float cxy = 3.0f * sum_q - sum_qq;
+    const float scale = 3.0f * rcp_nr(cxx * cyy - cxy * cxy, B);
+    for (int p = 0; p < 3; p++) {
+        const float atb1 = 3.0f * acc[p] - s[p];
+        const float atb2 = s[p];
+        c0[p] = fclamp_num((atb1 * cyy - atb2 * cxy) * scale, 0.f, 255.f);
+        c1[p] = fclamp_num((atb2 * cxx - atb1 * cxy) * scale, 0.f, 255.f);
+    }
 }
 
 // Colour part: PCA axis by power iteration, endpoint pick, one refit pass.
 // [kernel.ispc:494-533]
-__device__ __forceinline__ void encode_color(const float (&px)[3][16], uint32_t out[2], const SeedTables& T)
+__device__ __forceinline__ void encode_color(const Texels& px, uint32_t out[2], const Bc1Tables& B)
 {
-    float dc[3];
+    float acc[3], dc[3];
     for (int p = 0; p < 3; p++) {
-        float acc = 0.f;
+        float a = px.ch(p, 0);
 #pragma unroll
-        for (int k = 0; k < 16; k++) acc += px[p][k];
-        dc[p] = acc * 0.0625f;
+        for (int k = 1; k < 16; k++) a += px.ch(p, k);
+        acc[p] = a;                                  // an integer <= 4080: exact
+        dc[p] = a * 0.0625f;
     }
 
     // packed symmetric covariance  [rr rg rb gg gb bb]          [kernel.ispc:377-417]
-    float cv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // centred texels are exact multiples of 1/16, their products exact: three packed multiply-adds per texel, texel order kept
+    f2 c_rr_gg = {0.f, 0.f}, c_rg_rb = {0.f, 0.f}, c_gb_bb = {0.f, 0.f};
+    const f2 dc_rg = {dc[0], dc[1]};
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const float r = px[0][k] - dc[0], g = px[1][k] - dc[1], b = px[2][k] - dc[2];
-        cv[0] += r * r; cv[1] += r * g; cv[2] += r * b;
-        cv[3] += g * g; cv[4] += g * b; cv[5] += b * b;
+        const f2 a = px.rg[k] - dc_rg;                           // (r, g)
+        f2 gb;
+        gb.x = a.y; gb.y = px.b(k) - dc[2];                     // (g, b)
+        c_rr_gg = pk_fma(a, a, c_rr_gg);
+        c_rg_rb = pk_fma_alo_b(a, gb, c_rg_rb);
+        c_gb_bb = pk_fma_a_bhi(gb, gb, c_gb_bb);
     }
+    float cv[6] = {c_rr_gg.x, c_rg_rb.x, c_rg_rb.y, c_rr_gg.y, c_gb_bb.x, c_gb_bb.y};
     cv[0] += 0.001f; cv[3] += 0.001f; cv[5] += 0.001f;
 
     // four power iterations from (1,1,1), renormalised after the 2nd and 4th  [kernel.ispc:184-205]
@@ -134,56 +255,58 @@ __device__ __forceinline__ void encode_color(const float (&px)[3][16], uint32_t 
         if (it & 1) {
             float n = 0.f;
             n += a0 * a0; n += a1 * a1; n += a2 * a2;
-            const float rn = ispc_rsqrt(n, T);
+            const float rn = ispc_rsqrt<true>(n, B.T);
             v[0] *= rn; v[1] *= rn; v[2] *= rn;
         }
     }
 
     // extreme projections -> endpoints                           [kernel.ispc:274-306]
+    // The projections are finite (the diagonal carries +0.001, so the iteration never meets a zero or overflowing norm):
+    // minps / maxps are ordinary minimum / maximum here; only the sign of a zero could differ and it is added to dc >= 0.
     float lo = 65536.0f, hi = 0.0f;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        float dot = 0.f;
-        for (int p = 0; p < 3; p++) dot += (px[p][k] - dc[p]) * v[p];
-        lo = fmin_x86(lo, dot);
-        hi = fmax_x86(hi, dot);
+        float dot = (px.r(k) - dc[0]) * v[0];
+        dot += (px.g(k) - dc[1]) * v[1]; dot += (px.b(k) - dc[2]) * v[2];
+        lo = __builtin_fminf(lo, dot);
+        hi = __builtin_fmaxf(hi, dot);
     }
     if (hi - lo < 1.0f) { lo -= 0.5f; hi += 0.5f; }
 
-    float nsq = 0.f;
-    for (int p = 0; p < 3; p++) nsq += v[p] * v[p];
-    const float rn = ispc_rcp(nsq, T);
+    float nsq = v[0] * v[0];
+    nsq += v[1] * v[1]; nsq += v[2] * v[2];
+    const float rn = rcp_nr(nsq, B);
 
-    float e0[3], e1[3];
+    float c0[3], c1[3];
     for (int p = 0; p < 3; p++) {
-        e0[p] = fclamp_num(dc[p] + lo * rn * v[p], 0.f, 255.f);
-        e1[p] = fclamp_num(dc[p] + hi * rn * v[p], 0.f, 255.f);
+        c0[p] = fclamp_num(dc[p] + lo * rn * v[p], 0.f, 255.f);
+        c1[p] = fclamp_num(dc[p] + hi * rn * v[p], 0.f, 255.f);
     }
 
-    int32_t pe[2];
-    pe[0] = pack565(e0[0], e0[1], e0[2]);
-    pe[1] = pack565(e1[0], e1[1], e1[2]);
-    if (pe[0] < pe[1]) { const int32_t t = pe[0]; pe[0] = pe[1]; pe[1] = t; }   // keep 4-colour mode
-    uint32_t idx = project_indices(px, pe[0], pe[1], T);
+    Endpoint e0 = quantise565(c0[0], c0[1], c0[2], B), e1 = quantise565(c1[0], c1[1], c1[2], B);
+    order(e0, e1);
+    f2 qf[8];
+    uint32_t idx = project_indices<true>(px, e0, e1, B, qf);
 
-    refit_endpoints(pe, px, idx, dc, T);
-    if (pe[0] < pe[1]) { const int32_t t = pe[0]; pe[0] = pe[1]; pe[1] = t; }
-    idx = project_indices(px, pe[0], pe[1], T);
+    refit_endpoints(c0, c1, px, idx, qf, acc, dc, B);
+    e0 = quantise565(c0[0], c0[1], c0[2], B); e1 = quantise565(c1[0], c1[1], c1[2], B);
+    order(e0, e1);
+    idx = project_indices<false>(px, e0, e1, B, qf);
 
-    out[0] = ((uint32_t)pe[1] << 16) + (uint32_t)pe[0];
+    out[0] = ((uint32_t)e1.code << 16) + (uint32_t)e0.code;
     // linear order {0,1,2,3} -> BC1 order {0,2,3,1}              [kernel.ispc:482-492]
     const uint32_t lo_bits = idx & 0x55555555u, hi_bits = idx & 0xAAAAAAAAu;
     out[1] = (hi_bits >> 1) + (hi_bits ^ (lo_bits << 1));
 }
 
 // Alpha part of BC3: min/max endpoints, 8-level ramp.            [kernel.ispc:535-571]
-__device__ __forceinline__ void encode_alpha(const float (&a)[16], uint32_t out[2], const SeedTables& T)
+__device__ __forceinline__ void encode_alpha(const float (&a)[16], uint32_t out[2], const Bc1Tables& B)
 {
     float lo = 255.f, hi = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; k++) { lo = __builtin_fminf(lo, a[k]); hi = __builtin_fmaxf(hi, a[k]); }   // minps / maxps of ordinary numbers (bytes)
     if (lo == hi) hi = lo + 0.1f;
-    const float scale = 7.0f * ispc_rcp(hi - lo, T);
+    const float scale = 7.0f * rcp_nr(hi - lo, B);
 
     uint32_t q0 = 0, q1 = 0;      // 8 x 3 bits each
 #pragma unroll
@@ -197,51 +320,68 @@ __device__ __forceinline__ void encode_alpha(const float (&a)[16], uint32_t out[
     out[1] = (q0 >> 16) | (q1 << 8);
 }
 
+// Workgroups are persistent: each stages the tables once and then walks chunks of 256 blocks.
+// 4 waves per SIMD (128 registers): measured best on MI355X; 3 and 5 were tried (tools/gpu_bc1.sh history in DESIGN.md 3).
 template <bool BC3, bool VEC16>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst)
 {
-    const int32_t b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= nblocks) return;
-    const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
-    const SeedTables T = global_seed_tables();
-
-    float px[3][16];
-    float al[16];
-    const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 16;
+    __shared__ __attribute__((aligned(16))) unsigned char s_tables[BC1_LDS_BYTES];
+    const Bc1Tables B = stage_bc1_tables(s_tables, threadIdx.x, 256);
+    __syncthreads();
+    for (int32_t base = blockIdx.x * 256; base < nblocks; base += gridDim.x * 256) {
+        const int32_t cur = base + threadIdx.x;
+        if (cur >= nblocks) break;
+        const int32_t yy = cur / blocks_x, xx = cur - yy * blocks_x;
+        // (requesting the next chunk's texels before encoding this one was measured: the 16 extra live registers cost more
+        // than the hidden latency gains -- four waves per SIMD already overlap each other's loads)
+        Texels px;
+        float al[16];
+        const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 16;
 #pragma unroll
-    for (int y = 0; y < 4; y++) {
-        uint32_t w[4];
-        if (VEC16) {
-            const uint4 v = *reinterpret_cast<const uint4*>(p + y * stride);
-            w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+        for (int y = 0; y < 4; y++) {
+            uint32_t w[4];
+            if (VEC16) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p + y * stride);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            } else {
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(p + y * stride);
+                w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int k = y * 4 + x;
+                px.rg[k].x = (float)(w[x] & 255u);
+                px.rg[k].y = (float)((w[x] >> 8) & 255u);
+                if (k & 1) px.b2[k >> 1].y = (float)((w[x] >> 16) & 255u); else px.b2[k >> 1].x = (float)((w[x] >> 16) & 255u);
+                if (BC3) al[k] = (float)(w[x] >> 24);
+            }
+        }
+
+        if (BC3) {
+            uint32_t o[4];
+            encode_alpha(al, &o[0], B);
+            encode_color(px, &o[2], B);
+            uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)cur * 16);
+            if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(o[0], o[1], o[2], o[3]);
+            else { d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3]; }
         } else {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(p + y * stride);
-            w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
-        }
-#pragma unroll
-        for (int x = 0; x < 4; x++) {
-            px[0][y * 4 + x] = (float)(w[x] & 255u);
-            px[1][y * 4 + x] = (float)((w[x] >> 8) & 255u);
-            px[2][y * 4 + x] = (float)((w[x] >> 16) & 255u);
-            if (BC3) al[y * 4 + x] = (float)(w[x] >> 24);
+            uint32_t o[2];
+            encode_color(px, o, B);
+            uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)cur * 8);
+            if (VEC16) *reinterpret_cast<uint2*>(d) = make_uint2(o[0], o[1]);
+            else { d[0] = o[0]; d[1] = o[1]; }
         }
     }
+}
 
-    if (BC3) {
-        uint32_t o[4];
-        encode_alpha(al, &o[0], T);
-        encode_color(px, &o[2], T);
-        uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
-        if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(o[0], o[1], o[2], o[3]);
-        else { d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3]; }
-    } else {
-        uint32_t o[2];
-        encode_color(px, o, T);
-        uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 8);
-        if (VEC16) *reinterpret_cast<uint2*>(d) = make_uint2(o[0], o[1]);
-        else { d[0] = o[0]; d[1] = o[1]; }
-    }
+// Persistent workgroups: at most 2048 (two per resident slot at 4 waves per SIMD), each walking chunks of 256 blocks, so a
+// 4096^2 surface stages the 21 KiB table image 2048 times instead of 4096 (measured: 1024 / 1536 / 2048 / 4096 workgroups
+// within 3 % of each other; 2048 best for BC3).
+static unsigned bc13_grid(int64_t n)
+{
+    const int64_t chunks = (n + 255) / 256;
+    return (unsigned)(chunks < 2048 ? chunks : 2048);
 }
 
 // VEC16 requires: src base and stride multiples of 16, dst multiple of 16 (BC3) / 8 (BC1).
@@ -251,7 +391,7 @@ void launch_bc1(const uint8_t* src, int64_t stride, int width, int height, uint8
     const int64_t n = (int64_t)bx * by;
     if (n <= 0) return;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
-    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    const dim3 grid(bc13_grid(n)), blk(256);
     if (vec) hipLaunchKernelGGL((bc13_kernel<false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
     else     hipLaunchKernelGGL((bc13_kernel<false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
 }
@@ -262,7 +402,7 @@ void launch_bc3(const uint8_t* src, int64_t stride, int width, int height, uint8
     const int64_t n = (int64_t)bx * by;
     if (n <= 0) return;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
-    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    const dim3 grid(bc13_grid(n)), blk(256);
     if (vec) hipLaunchKernelGGL((bc13_kernel<true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
     else     hipLaunchKernelGGL((bc13_kernel<true, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
 }
