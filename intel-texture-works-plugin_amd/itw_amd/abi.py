@@ -24,6 +24,8 @@ EXPORTED_SYMBOLS = tuple(
     + ["CompressImageBC7_" + p for p in BC7_PROFILES] + ["CompressImageBC6H_" + p for p in BC6H_PROFILES]
     + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
        "itwConvertToRGBA8Device", "itwConvertToRGBA16FDevice"]
+    # include/itw_multigpu.h: one surface over all GPUs, one process
+    + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwCompressImageMultiGPU"]
     # include/itw_bc45.h: the DirectXTex formats of the plugin
     + ["CompressBlocksBC4", "CompressBlocksBC5"]
     # include/itw_decode.h: device decoders
@@ -125,6 +127,10 @@ def lib():
         L.itwCompressImageSliced.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_bool,
                                              C.c_int64, C.c_void_p, C.c_void_p]
         L.itwCompressImageSliced.restype = C.c_bool
+        L.itwMultiGpuRanks.restype = C.c_int
+        L.itwMultiGpuTransport.restype = C.c_char_p
+        L.itwCompressImageMultiGPU.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.itwCompressImageMultiGPU.restype = C.c_bool
         L.itwPadToMultipleOf4.argtypes = [C.POINTER(RgbaSurface), C.c_int]
         L.itwPadToMultipleOf4.restype = RgbaSurface
         L.itwFreeSurface.argtypes = [C.POINTER(RgbaSurface)]
@@ -291,6 +297,31 @@ def compress_image(fmt, img, profile=None, multithreaded=True, slice_pixels=0, p
     ok = lib().itwCompressImageSliced(C.byref(surf), out.ctypes.data, block_count(fmt, w, 4) * BYTES_PER_BLOCK[fmt], image_func(fmt, profile),
                                       DXGI_FORMAT[fmt], multithreaded, slice_pixels, C.cast(cb, C.c_void_p) if cb else None, None)
     return bool(ok), out
+
+
+def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None):
+    """itwCompressImageMultiGPU: img is a host numpy array or a CUDA torch tensor (H, W, 4); the block stream comes back in
+    the same kind of container (or in `out`, which may be the other kind).  Synchronous."""
+    import numpy as np
+    h, w = img.shape[:2]
+    nbytes = block_count(fmt, w, h) * BYTES_PER_BLOCK[fmt]
+    on_gpu = not isinstance(img, np.ndarray)
+    if out is None:
+        if on_gpu:
+            import torch
+            out = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+        else:
+            out = np.empty(nbytes, dtype=np.uint8)
+    src_ptr, stride = (img.data_ptr(), img.stride(0) * img.element_size()) if on_gpu else (img.ctypes.data, img.strides[0])
+    dst_ptr = out.ctypes.data if isinstance(out, np.ndarray) else out.data_ptr()
+    if on_gpu:
+        import torch
+        torch.cuda.synchronize(img.device)            # the rank threads read the texels on their own streams
+    surf = RgbaSurface(src_ptr, w, h, stride)
+    ok = lib().itwCompressImageMultiGPU(C.byref(surf), dst_ptr, image_func(fmt, profile), DXGI_FORMAT[fmt], ranks)
+    if not ok:
+        raise RuntimeError(last_error() or "itwCompressImageMultiGPU failed")
+    return out
 
 
 def pad_to_multiple_of_4(img):
