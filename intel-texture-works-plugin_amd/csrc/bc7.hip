@@ -1371,7 +1371,7 @@ static int bc7_path_override()
 }
 void set_bc7_path(int v) { g_bc7_path.store(v == 1 || v == 2 ? v : 0, std::memory_order_relaxed); }
 
-static bool bc7_use_wide(int64_t n, const bc7_enc_settings& S)
+static bool bc7_use_wide(int64_t n, const bc7_enc_settings& S, int64_t wide_max)
 {
     // lists longer than 16 that are proper prefixes of the ranking keep their keys in 64 KiB of LDS: deep path only
     auto long_ranked = [](int t) { return t > 16 && t < 64; };
@@ -1387,7 +1387,7 @@ static bool bc7_use_wide(int64_t n, const bc7_enc_settings& S)
     if (o == 1) return false;
     const int64_t hard_cap = (int64_t)1 << 20;                   // workspace bound of the wide layout (1.6 GB)
     if (o == 2) return n <= hard_cap;
-    return n <= ITW_BC7_WIDE_MAX_BLOCKS;
+    return n <= (wide_max > 0 ? (wide_max < hard_cap ? wide_max : hard_cap) : ITW_BC7_WIDE_MAX_BLOCKS);
 }
 
 // deep: best error so far (4 B/block) + the winners of one family's two modes (2 x 16 B/block)
@@ -1398,11 +1398,12 @@ static size_t wide_workspace_bytes(size_t n)
 {
     return (size_t)5 * wide_win_entries(n) * sizeof(uint4) + (((size_t)WIDE_SLOTS * n * sizeof(int32_t) + 15) & ~(size_t)15) + (size_t)WIDE_SLOTS * n * sizeof(uint4);
 }
-size_t bc7_workspace_bytes(int width, int height)
+size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks)
 {
     const size_t n = (size_t)(width / 4) * (size_t)(height / 4);
     const size_t deep = ((n * sizeof(int32_t) + 15) & ~(size_t)15) + 2 * n * sizeof(uint4);
-    const bool may_wide = bc7_path_override() == 2 ? n <= ((size_t)1 << 20) : (bc7_path_override() == 0 && n <= ITW_BC7_WIDE_MAX_BLOCKS);
+    const size_t limit = bc7_path_override() == 2 ? ((size_t)1 << 20) : (wide_max_blocks > 0 ? (size_t)wide_max_blocks : (size_t)ITW_BC7_WIDE_MAX_BLOCKS);
+    const bool may_wide = bc7_path_override() != 1 && n <= limit && n <= ((size_t)1 << 20);
     const size_t wide = may_wide ? wide_workspace_bytes(n) : 0;
     return deep > wide ? deep : wide;
 }
@@ -1509,7 +1510,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
     Bc7Launch L;
     L.S = s;
     L.S.channels = (s.channels == 4) ? 4 : 3;
-    if (bc7_use_wide(n, L.S)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st, aux); return; }
+    if (bc7_use_wide(n, L.S, aux ? aux->wide_max_blocks : 0)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st, aux); return; }
     L.err = reinterpret_cast<int32_t*>(workspace);
     L.wins = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(workspace) + (((size_t)n * sizeof(int32_t) + 15) & ~(size_t)15));
     L.vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;

@@ -17,13 +17,13 @@ void launch_bc5 (const uint8_t* src, int64_t stride, int width, int height, uint
 // BC7 runs as up to seven kernels (search + finish per multi-subset mode family, one for modes 4/5/6) that hand
 // "best error so far" and the search winners to each other through
 // `workspace`: device memory, bc7_workspace_bytes(width, height) bytes, 16 B aligned, contents irrelevant on entry.
-size_t bc7_workspace_bytes(int width, int height);
+size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks = 0);   // wide_max_blocks as in Bc7Aux
 // BC7 launch shape: 0 = by call size (default), 1 = deep (one lane per block, a launch pair per mode family: fills the
 // chip on whole surfaces), 2 = wide (split scans + ordered argmin: small calls).  Same blocks either way.
 void set_bc7_path(int path);
 // `aux` (optional): a second stream of the same device plus two events the launcher may use to run independent parts of a
 // small call side by side; everything is joined back into `st` before the launcher returns.
-struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; };
+struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; };   // wide_max_blocks: 0 = the library default
 void launch_bc7 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                  const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux = nullptr);
 void launch_bc6h(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,

@@ -60,23 +60,24 @@ def classify(mn):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--blocks", type=int, default=64, help="blocks per workload (a square crop of the bench surface)")
+    ap.add_argument("--blocks", type=int, default=16, help="blocks per crop for the light formats (bc1, bc3); three crops per workload")
+    ap.add_argument("--heavy-blocks", type=int, default=4, help="blocks per crop for bc7 / bc6h (single-stepping runs at ~12 k instructions/s here)")
     ap.add_argument("--workloads", default="bc1,bc3,bc7_veryfast,bc7_basic,bc7_slow,bc7_alpha_slow,bc6h_fast,bc6h_slow")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "op_counts.json"))
     a = ap.parse_args()
     subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], check=True)
     subprocess.run(["gcc", "-O2", "-o", EXE, os.path.join(ROOT, "tools", "opcount", "opcount.c"), "-ldl"], check=True)
     ins = disassemble()
-    side = int(round(a.blocks ** 0.5)) * 4
     ldr = surfaces.ldr_smooth(4096, 4096)
     hdr = surfaces.hdr_smooth(1024, 1024)
     tmp = tempfile.mkdtemp()
     result = {"method": "ptrace single-step of the scalar C oracle (gcc -O2 -ffp-contract=off, SSE scalar) + objdump classification; "
                         "fp32 ops = mulss/addss/subss/divss/sqrtss, compares = comiss/minss/maxss, conversions = cvt*",
-              "sample": f"{side}x{side} crops (= {(side // 4) ** 2} blocks) of the bench surfaces at three positions", "workloads": {}}
+              "sample": f"three square crops of the bench surfaces per workload: {a.blocks} blocks each for bc1/bc3, {a.heavy_blocks} for bc7/bc6h", "workloads": {}}
     print(f"{'workload':<16} {'blocks':>6} {'x86 instr/blk':>14} {'fp mul':>9} {'fp add/sub':>10} {'div':>6} {'sqrt':>6} {'cmp/min/max':>11} {'cvt':>8} {'fp32 ops/blk':>13}")
     for wl in a.workloads.split(","):
         fmt, prof = WORKLOADS[wl]
+        side = int(round((a.blocks if fmt in ("bc1", "bc3") else a.heavy_blocks) ** 0.5)) * 4
         tot = collections.Counter()
         nblocks = 0
         t0 = time.time()
