@@ -53,7 +53,8 @@ const char* itwDeviceInfo(void);
  * presets it) picks by call size: DEEP = one lane per block, one launch pair per mode family (fills the chip on whole
  * surfaces); WIDE = every family's scan split over several waves, winners joined by an ordered argmin (calls too small
  * to fill the chip: the plugin's 0x40000-pixel slices, IntelPlugin.cpp:851, and the per-thread bands of
- * win32Threads.cpp:217).  Both produce the same bytes. */
+ * win32Threads.cpp:217).  Both produce the same bytes.  The same switch governs the BC6H slow profiles (one kernel / split
+ * two-region scan; env ITW_BC6H_PATH). */
 enum { ITW_BC7_PATH_AUTO = 0, ITW_BC7_PATH_DEEP = 1, ITW_BC7_PATH_WIDE = 2 };
 void itwSetBc7Path(int path);
 

@@ -209,7 +209,21 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
         itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st, tls.aux.wide_max_blocks), st, &tls.aux);
         ITW_CHECK(hipEventRecord(tls.ws_event, st));
         break;
-    case Fmt::BC6H: itw::launch_bc6h(d_src, stride, w, h, d_dst, *j.s6, st); break;
+    case Fmt::BC6H: {
+        // the wide shape's workspace shares the per-thread BC7 workspace buffer (same ordering rules)
+        const size_t need = itw::bc6h_workspace_bytes(w, h, *j.s6);
+        void* ws = nullptr;
+        if (need) {
+            bind_thread_to_current_device();
+            if (!tls.ws_event) ITW_CHECK(hipEventCreateWithFlags(&tls.ws_event, hipEventDisableTiming));
+            if (tls.ws_used && tls.ws_stream != st) ITW_CHECK(hipStreamWaitEvent(st, tls.ws_event, 0));
+            ws = grow(tls.d_ws, tls.ws_cap, need);
+            tls.ws_stream = st; tls.ws_used = true;
+        }
+        itw::launch_bc6h(d_src, stride, w, h, d_dst, *j.s6, st, ws);
+        if (need) ITW_CHECK(hipEventRecord(tls.ws_event, st));
+        break;
+    }
     case Fmt::BC4:  itw::launch_bc4(d_src, stride, w, h, d_dst, st); break;
     case Fmt::BC5:  itw::launch_bc5(d_src, stride, w, h, d_dst, st); break;
     }
@@ -631,7 +645,7 @@ const char* itwDeviceInfo(void)
     return tls.info;
 }
 
-void itwSetBc7Path(int path) { itw::set_bc7_path(path); }
+void itwSetBc7Path(int path) { itw::set_bc7_path(path); itw::set_bc6h_path(path); }
 
 const char* itwVersion(void) { return "itw-amd 0.1 gfx950 arith=x86-lut-nr contract=off"; }
 

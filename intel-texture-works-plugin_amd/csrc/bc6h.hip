@@ -23,6 +23,9 @@
 //     from the decoder's mode descriptors), one compile-time specialisation per mode,
 //     instead of the reference's per-mode arithmetic scatter (kernel.ispc:2392-2980).
 // fp32 VALU bound; no MFMA-shaped work.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 #include "bcn_core.hpp"
 #include "bc6h_layout.hpp"
 #include "kernels.hpp"
@@ -347,8 +350,10 @@ __device__ __forceinline__ int two_region_mode(bool slow, int m, int gated)
 // Scan of the `count` best ranked shapes: one pair of line fits per shape serves all `nmodes` modes. [2174-2273]
 // LEAN: the scan keeps errors only and the finish recomputes the winner's indices (pays when many candidates are scanned:
 // the slow profiles); otherwise the scan stores the indices with the winner.
+// `first`/`step`: the share of a split scan (wide path): list entries first, first + step, ... ; a winner also records
+// its position in the ranked list (the reference's strict `<` keeps the earliest entry among equal errors).
 template <bool LEAN>
-__device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes, int gated, int count)
+__device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes, int gated, int count, int first = 0, int step = 1)
 {
     for (int m = 0; m < nmodes; m++) {
         ln.wins[(4 * m + 0) * TPB6] = 0x7f800000u;      // +inf
@@ -359,6 +364,7 @@ __device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes
     int32_t prev = 0;
     for (int c = 0; c < count; c++) {
         prev = next_key32(ln, prev, c == 0);
+        if (step > 1 && (c % step) != first) continue;           // another wave's share of the list
         ln.tex.fence();
         const int shape = prev & 31;
         const Shape sh = load_shape(shape);
@@ -385,6 +391,7 @@ __device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes
                 ln.wins[(4 * m + 0) * TPB6] = __float_as_uint(err);
                 ln.wins[(4 * m + 1) * TPB6] = (uint32_t)shape;
                 if (!LEAN) { ln.wins[(4 * m + 2) * TPB6] = qb[0]; ln.wins[(4 * m + 3) * TPB6] = qb[1]; }
+                else ln.wins[(4 * m + 2) * TPB6] = (uint32_t)c;   // list position (LEAN winners carry no indices)
             }
         }
     }
@@ -392,10 +399,10 @@ __device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes
 
 // Refinement of each mode's winner, then the mode competes for the block, in mode order.
 template <bool LEAN>
-__device__ __forceinline__ void finish_two_region(HLane& ln, bool slow, int nmodes, int gated, int refine)
+__device__ __forceinline__ void finish_two_region(HLane& ln, bool slow, int nmodes, int gated, int refine, int m0 = 0)
 {
 #pragma unroll 1
-    for (int m = 0; m < nmodes; m++) {
+    for (int m = m0; m < nmodes; m++) {
         ln.tex.fence();
         enter_mode(ln, two_region_mode(slow, m, gated), 0.f);
         float berr = __uint_as_float(ln.wins[(4 * m + 0) * TPB6]);
@@ -450,13 +457,13 @@ __device__ __forceinline__ void finish_two_region(HLane& ln, bool slow, int nmod
 
 // one-region modes: the fit is the block's, whatever the mode                                   [2275-2300]
 // slow: modes 10..13 in turn; otherwise the one mode the gates left in the lane.
-__device__ __forceinline__ void encode_one_region(HLane& ln, bool slow, int refine)
+__device__ __forceinline__ void encode_one_region(HLane& ln, bool slow, int refine, int m0 = 0, int m1 = 4)
 {
     float fit[2][4];
     fit_subset<3, false, true>(fit, ln.tex, 0xffffu, ln.T);
-    const int n = slow ? 4 : 1;
+    const int n = slow ? m1 : 1;
 #pragma unroll 1
-    for (int m = 0; m < n; m++) {
+    for (int m = slow ? m0 : 0; m < n; m++) {
         ln.tex.fence();
         if (slow) enter_mode(ln, 10 + m, 0.f);
         float ep[2][4];
@@ -483,25 +490,10 @@ __device__ __forceinline__ void encode_one_region(HLane& ln, bool slow, int refi
     }
 }
 
-template <bool SLOW, bool VEC16>
-__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(2, 2)))   // measured: 2 waves with a little scratch beat 1 wave with AGPR spills by 35 %
-bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
-            uint8_t* __restrict__ dst, const bc6h_enc_settings S)
+// texels -> uf16 code space, channel bounds, widest channel, empty best                 [kernel.ispc:134-151, 3036-3067]
+template <bool VEC16>
+__device__ __forceinline__ void load_and_setup(HLane& ln, const uint8_t* __restrict__ src, int64_t stride, int32_t xx, int32_t yy)
 {
-    __shared__ unsigned short s_seed16[2048];
-    __shared__ uint32_t s_seed32[2048];
-    __shared__ int32_t s_keys[32 * TPB6];
-    __shared__ uint32_t s_wins[24 * TPB6];
-    HLane ln;
-    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB6);
-    __syncthreads();
-    const int32_t gid = blockIdx.x * TPB6 + threadIdx.x;
-    const bool live = gid < nblocks;
-    const int32_t b = live ? gid : nblocks - 1;    // idle lanes of the last workgroup redo its last block, store nothing
-    const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
-    ln.keys = s_keys + threadIdx.x;
-    ln.wins = s_wins + threadIdx.x;
-
     // load: 4 texels x 8 bytes per row; keep R,G,B half bit patterns as integers    [kernel.ispc:134-151]
     const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 32;
 #pragma unroll
@@ -547,6 +539,28 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
     ln.best_shape = -1; ln.best_mode = 10;
     ln.mode = 0; ln.epb = 0;
     for (int c = 0; c < 3; c++) { ln.qlo[c] = 0; ln.qhi[c] = 0; }
+}
+
+template <bool SLOW, bool VEC16>
+__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(2, 2)))   // measured: 2 waves with a little scratch beat 1 wave with AGPR spills by 35 %
+bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
+            uint8_t* __restrict__ dst, const bc6h_enc_settings S)
+{
+    __shared__ unsigned short s_seed16[2048];
+    __shared__ uint32_t s_seed32[2048];
+    __shared__ int32_t s_keys[32 * TPB6];
+    __shared__ uint32_t s_wins[24 * TPB6];
+    HLane ln;
+    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB6);
+    __syncthreads();
+    const int32_t gid = blockIdx.x * TPB6 + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;    // idle lanes of the last workgroup redo its last block, store nothing
+    const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
+    ln.keys = s_keys + threadIdx.x;
+    ln.wins = s_wins + threadIdx.x;
+
+    load_and_setup<VEC16>(ln, src, stride, xx, yy);
 
     if (SLOW) {                                                                         // [kernel.ispc:3073-3085]
         // every mode is encoded (margin 0 never gates); the ranking runs even when no shape is tried
@@ -591,12 +605,170 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
     }
 }
 
+// ---- WIDE path for the slow profiles: calls too small to fill the chip (see bc7.hip, same idea) ---------------------------
+//   phase A  blockIdx.y = task: `parts` strided shares of the ranked two-region list (every share ranks the 32 shapes
+//            itself: the ranking is a tenth of the scan), each leaving one winner {error, shape, list position} per mode;
+//            next to them one task per one-region mode (10..13), which depends on nothing;
+//   phase B  blockIdx.y = two-region mode: ordered argmin over the shares (lowest error, then earliest list position: the
+//            reference's strict `<`, kernel.ispc:2215), refit + refine, emit the mode's candidate block;
+//   commit   candidates compete in the reference's order 0,1,2,5,6,9,10,11,12,13 with strict `<` from +inf
+//            (kernel.ispc:3073-3085).
+// Same device functions, same arithmetic, same bytes as the one-kernel path; ITW_BC6H_PATH=deep|wide forces either.
+constexpr int W6_MAX_PARTS = 8;
+constexpr int W6_SLOTS = 10;              // 6 two-region modes + 4 one-region modes
+
+template <bool VEC16>
+__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(2, 2)))
+bc6h_wide_phaseA(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint4* __restrict__ wins,
+                 float* __restrict__ cerr, uint4* __restrict__ cblk, const bc6h_enc_settings S, const int parts, const int count)
+{
+    __shared__ unsigned short s_seed16[2048];
+    __shared__ uint32_t s_seed32[2048];
+    __shared__ int32_t s_keys[32 * TPB6];
+    __shared__ uint32_t s_wins[24 * TPB6];
+    HLane ln;
+    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB6);
+    __syncthreads();
+    const int32_t gid = blockIdx.x * TPB6 + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;
+    const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
+    ln.keys = s_keys + threadIdx.x;
+    ln.wins = s_wins + threadIdx.x;
+    load_and_setup<VEC16>(ln, src, stride, xx, yy);
+    const int task = blockIdx.y;                                   // wave-uniform
+    if (task < parts) {                                            // a share of the two-region scan
+        rank_shapes32(ln);
+        scan_two_region<true>(ln, true, 6, 0, count, task, parts);
+        if (live)
+            for (int m = 0; m < 6; m++)
+                wins[((int64_t)m * parts + task) * nblocks + b] = make_uint4(ln.wins[(4 * m + 0) * TPB6], ln.wins[(4 * m + 1) * TPB6], ln.wins[(4 * m + 2) * TPB6], 0u);
+    } else {                                                       // one one-region mode
+        const int m = task - parts;
+        encode_one_region(ln, true, S.refineIterations_1p, m, m + 1);
+        uint32_t out[4] = {0u, 0u, 0u, 0u};
+        if (ln.best_err < __builtin_inff()) emit_one_region(out, ln.best_q[0], ln.best_qb, ln.best_mode);
+        if (live) { cerr[(int64_t)(6 + m) * nblocks + b] = ln.best_err; cblk[(int64_t)(6 + m) * nblocks + b] = make_uint4(out[0], out[1], out[2], out[3]); }
+    }
+}
+
+template <bool VEC16>
+__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(2, 2)))
+bc6h_wide_phaseB(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, const uint4* __restrict__ wins,
+                 float* __restrict__ cerr, uint4* __restrict__ cblk, const bc6h_enc_settings S, const int parts)
+{
+    __shared__ unsigned short s_seed16[2048];
+    __shared__ uint32_t s_seed32[2048];
+    __shared__ uint32_t s_wins[24 * TPB6];
+    HLane ln;
+    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB6);
+    __syncthreads();
+    const int32_t gid = blockIdx.x * TPB6 + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;
+    const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
+    ln.keys = nullptr;
+    ln.wins = s_wins + threadIdx.x;
+    load_and_setup<VEC16>(ln, src, stride, xx, yy);
+    const int m = blockIdx.y;                                      // wave-uniform: index into 0,1,2,5,6,9
+    // ordered argmin over the shares: lowest error, then earliest list position (errors compare as floats, like the scan)
+    uint4 best = wins[((int64_t)m * parts) * nblocks + b];
+    for (int p = 1; p < parts; p++) {
+        const uint4 x = wins[((int64_t)m * parts + p) * nblocks + b];
+        const float ex = __uint_as_float(x.x), eb = __uint_as_float(best.x);
+        if (ex < eb || (ex == eb && ex < __builtin_inff() && x.z < best.z)) best = x;
+    }
+    ln.wins[(4 * m + 0) * TPB6] = best.x; ln.wins[(4 * m + 1) * TPB6] = best.y;
+    ln.wins[(4 * m + 2) * TPB6] = 0u; ln.wins[(4 * m + 3) * TPB6] = 0u;
+    finish_two_region<true>(ln, true, m + 1, 0, S.refineIterations_2p, m);
+    uint32_t out[4] = {0u, 0u, 0u, 0u};
+    if (ln.best_err < __builtin_inff()) emit_two_region(out, ln.best_q, ln.best_qb, ln.best_shape, ln.best_mode);
+    if (live) { cerr[(int64_t)m * nblocks + b] = ln.best_err; cblk[(int64_t)m * nblocks + b] = make_uint4(out[0], out[1], out[2], out[3]); }
+}
+
+__global__ void __launch_bounds__(TPB6)
+bc6h_wide_commit(const float* __restrict__ cerr, const uint4* __restrict__ cblk, int32_t nblocks, uint32_t active, uint4* __restrict__ dst, int vec16)
+{
+    const int32_t b = blockIdx.x * TPB6 + threadIdx.x;
+    if (b >= nblocks) return;
+    float best = __builtin_inff();
+    uint4 blk = make_uint4(0u, 0u, 0u, 0u);
+    bool any = false;
+    for (int slot = 0; slot < W6_SLOTS; slot++) {
+        if (!((active >> slot) & 1u)) continue;
+        const float e = cerr[(int64_t)slot * nblocks + b];
+        if (e < best) { best = e; blk = cblk[(int64_t)slot * nblocks + b]; any = true; }
+    }
+    if (!any) {
+        // nothing beat +inf (only with NaN errors): the one-kernel path then emits its initial state, an all-zero mode 10 block
+        int32_t q[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        uint32_t qb[2] = {0u, 0u}, out[4];
+        emit_one_region(out, q, qb, 10);
+        blk = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+    if (vec16) dst[b] = blk;
+    else { uint32_t* d = reinterpret_cast<uint32_t*>(dst) + (int64_t)b * 4; d[0] = blk.x; d[1] = blk.y; d[2] = blk.z; d[3] = blk.w; }
+}
+
+#ifndef ITW_BC6H_WIDE_MAX_BLOCKS
+#define ITW_BC6H_WIDE_MAX_BLOCKS 98304       // measured crossover on MI355X (tools/bc7_path_probe.py --bc6h)
+#endif
+static std::atomic<int> g_bc6h_path{-1};      // 0 by size, 1 deep, 2 wide
+static int bc6h_path_override()
+{
+    int v = g_bc6h_path.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* e = std::getenv("ITW_BC6H_PATH");
+        v = !e ? 0 : !std::strcmp(e, "deep") ? 1 : !std::strcmp(e, "wide") ? 2 : 0;
+        g_bc6h_path.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+void set_bc6h_path(int v) { g_bc6h_path.store(v == 1 || v == 2 ? v : 0, std::memory_order_relaxed); }
+
+static bool bc6h_use_wide(int64_t n, const bc6h_enc_settings& s)
+{
+    if (!s.slow_mode || s.fastSkipTreshold < 2) return false;      // the fast profiles try two to four shapes: nothing to split
+    const int o = bc6h_path_override();
+    if (o == 1) return false;
+    if (o == 2) return n <= ((int64_t)1 << 20);
+    return n <= ITW_BC6H_WIDE_MAX_BLOCKS;
+}
+// wide: winners [6 modes][parts] x 16 B + candidates [10 slots] x (4 + 16) B per block; the one-kernel path needs nothing
+size_t bc6h_workspace_bytes(int width, int height, const bc6h_enc_settings& s)
+{
+    const size_t n = (size_t)(width / 4) * (size_t)(height / 4);
+    if (!bc6h_use_wide((int64_t)n, s)) return 0;
+    return (size_t)6 * W6_MAX_PARTS * n * sizeof(uint4) + (((size_t)W6_SLOTS * n * sizeof(float) + 15) & ~(size_t)15) + (size_t)W6_SLOTS * n * sizeof(uint4);
+}
+
+static void launch_bc6h_wide(const uint8_t* src, int64_t stride, int bx, int64_t n, uint8_t* dst, const bc6h_enc_settings& s, void* workspace, hipStream_t st)
+{
+    uint4* wins = reinterpret_cast<uint4*>(workspace);
+    float* cerr = reinterpret_cast<float*>(wins + (size_t)6 * W6_MAX_PARTS * n);
+    uint4* cblk = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(cerr) + (((size_t)W6_SLOTS * n * sizeof(float) + 15) & ~(size_t)15));
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const int count = s.fastSkipTreshold > 32 ? 32 : s.fastSkipTreshold;
+    // shares of the ranked list: while all waves (2 per SIMD) stay resident at once; every share repeats the ranking
+    const int64_t waves = (n + 63) / 64;
+    int parts = 1;
+    while (parts < W6_MAX_PARTS && parts * 2 <= count && waves * (parts * 2 + 4) <= 2048) parts *= 2;
+    const unsigned gx = (unsigned)((n + TPB6 - 1) / TPB6);
+    const dim3 blk(TPB6);
+    if (vec) hipLaunchKernelGGL((bc6h_wide_phaseA<true>),  dim3(gx, (unsigned)(parts + 4)), blk, 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, s, parts, count);
+    else     hipLaunchKernelGGL((bc6h_wide_phaseA<false>), dim3(gx, (unsigned)(parts + 4)), blk, 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, s, parts, count);
+    if (vec) hipLaunchKernelGGL((bc6h_wide_phaseB<true>),  dim3(gx, 6u), blk, 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, s, parts);
+    else     hipLaunchKernelGGL((bc6h_wide_phaseB<false>), dim3(gx, 6u), blk, 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, s, parts);
+    hipLaunchKernelGGL(bc6h_wide_commit, dim3(gx), blk, 0, st, cerr, cblk, (int32_t)n, 0x3ffu, reinterpret_cast<uint4*>(dst), vec ? 1 : 0);
+}
+
 void launch_bc6h(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
-                 const bc6h_enc_settings& s, hipStream_t st)
+                 const bc6h_enc_settings& s, hipStream_t st, void* workspace)
 {
     const int bx = width / 4, by = height / 4;
     const int64_t n = (int64_t)bx * by;
     if (n <= 0) return;
+    if (workspace && bc6h_use_wide(n, s)) { launch_bc6h_wide(src, stride, bx, n, dst, s, workspace, st); return; }
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const dim3 grid((unsigned)((n + TPB6 - 1) / TPB6)), blk(TPB6);
     if (s.slow_mode) {

@@ -92,3 +92,47 @@ def test_custom_settings_on_both_paths(itw, gpu, paths, oracle):
             paths(path)
             got = _encode(itw, gpu, img, s)
             assert first_mismatch(got, want, 16) is None, (base, tweak, path, first_mismatch(got, want, 16))
+
+
+# ---- BC6H slow profiles: one kernel vs split two-region scan (csrc/bc6h.hip, same switch) ------------------------------
+
+def _encode6(itw, gpu, img, prof):
+    import torch
+    out = itw.compress("bc6h", torch.from_numpy(img).to(gpu), prof)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("prof", ["slow", "veryslow", "basic", "fast"])
+def test_bc6h_both_shapes_reproduce_the_golden_streams(itw, gpu, paths, golden_inputs, golden_blocks, prof):
+    for name in ("monkey_hdr", "hdr_random_bits"):
+        want = golden_blocks[f"{name}.bc6h.{prof}"]
+        for path in ("wide", "deep"):
+            paths(path)
+            got = _encode6(itw, gpu, golden_inputs[name], prof)
+            assert first_mismatch(got, want, 16) is None, (name, path, first_mismatch(got, want, 16))
+
+
+@pytest.mark.parametrize("h,w", [(4, 4), (8, 36), (64, 64), (256, 256), (512, 512)])
+def test_bc6h_wide_at_every_split_width(itw, gpu, paths, oracle, h, w):
+    from itw_amd import surfaces
+    for gen in (surfaces.hdr_smooth, surfaces.hdr_random_bits):      # random bits: NaN / Inf halves and overflowing errors (S5)
+        img = gen(h, w)
+        want = oracle.encode_mt("bc6h", img, "slow")
+        paths("wide")
+        got = _encode6(itw, gpu, img, "slow")
+        assert first_mismatch(got, want, 16) is None, (gen.__name__, first_mismatch(got, want, 16))
+
+
+def test_bc6h_custom_list_lengths_on_both_shapes(itw, gpu, paths, oracle):
+    from itw_amd import surfaces
+    img = np.concatenate([surfaces.hdr_smooth(32, 64), surfaces.hdr_random_bits(32, 64)], axis=0)
+    for n, r1, r2 in ((1, 0, 0), (2, 1, 1), (3, 2, 0), (7, 2, 2), (32, 1, 3), (40, 2, 2)):
+        s, so = itw.bc6h_profile("slow"), oracle.bc6h_profile("slow")
+        for o in (s, so):
+            o.fastSkipTreshold, o.refineIterations_1p, o.refineIterations_2p = n, r1, r2
+        want = oracle.encode("bc6h", img, so)
+        for path in ("wide", "deep"):
+            paths(path)
+            got = _encode6(itw, gpu, img, s)
+            assert first_mismatch(got, want, 16) is None, (n, r1, r2, path, first_mismatch(got, want, 16))

@@ -10,6 +10,9 @@ from itw_amd import surfaces
 dev = torch.device("cuda:0")
 base = surfaces.ldr_smooth(4096, 4096)
 profiles = sys.argv[1].split(",") if len(sys.argv) > 1 else ["slow", "basic", "alpha_basic", "veryfast", "alpha_slow"]
+fmt = sys.argv[2] if len(sys.argv) > 2 else "bc7"
+if fmt == "bc6h":
+    base = surfaces.hdr_smooth(4096, 4096)
 print(f"{'profile':<12} {'rows x 4096':>12} {'blocks':>9} {'deep ms':>9} {'wide ms':>9} {'wide Mpix/s':>12} same")
 for prof in profiles:
     for rows in (8, 32, 64, 128, 256, 384, 512, 1024, 4096):
@@ -19,13 +22,13 @@ for prof in profiles:
         ms = {}
         for path in ("deep", "wide"):
             itw_amd.set_bc7_path(path)
-            o = itw_amd.compress("bc7", img, prof)
+            o = itw_amd.compress(fmt, img, prof)
             torch.cuda.synchronize()
             reps = 5 if rows >= 1024 else 20
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             for _ in range(reps):
-                itw_amd.compress("bc7", img, prof, out=o)
+                itw_amd.compress(fmt, img, prof, out=o)
             b.record()
             torch.cuda.synchronize()
             ms[path] = a.elapsed_time(b) / reps
