@@ -170,6 +170,18 @@ def pmc_valu(workload):
     return best
 
 
+def op_counts(workload):
+    """Measured fp32 operation counts per block of the reference algorithm (profiles/op_counts.json: the CPU oracle under
+    ptrace single-stepping, tools/opcount.py) -- the ALGORITHMIC work, as opposed to the instructions this GPU
+    implementation happens to execute."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "op_counts.json")) as f:
+            j = json.load(f)
+        return j["workloads"][workload]["per_block"], j.get("method")
+    except (OSError, ValueError, KeyError):
+        return None, None
+
+
 def rocprof_kernels(fmt):
     """Per-kernel average duration (ms) of this format's kernels from the latest committed `rocprofv3 --kernel-trace --stats`
     summary (profiles/*_kernel_stats.csv), so the live HIP-event time of the call can be checked against the profiler's."""
@@ -327,6 +339,22 @@ def main():
                 "note": "SQ_INSTS_VALU of one call (committed rocprofv3 pass) x 64 lanes / live kernel time; peak = 256 CU x 4 SIMD "
                         "x 32 lanes x 2.4 GHz, reached only by the 2-cycle VOP2 forms (v_mul/add_f32, v_add_u32, logic, shifts right); "
                         "cvt / cmp / fma / packed / dot forms issue at half that rate (tools/ubench)"}
+
+    if rank == 0:
+        per_block, method = op_counts(args.workload)
+        if per_block:
+            # algorithmic roofline: the reference's own fp32 work (measured on the oracle) over this GPU's time
+            blocks_all = (geo["width"] // 4) * (geo["height"] // 4)
+            arith, full = per_block.get("fp32_arith_ops", 0.0), per_block.get("fp32_arith_cmp_cvt_ops", 0.0)
+            t = elapsed / steps
+            result["roofline"]["valu_algorithmic"] = {
+                "fp32_arith_ops_per_block": arith, "fp32_arith_cmp_cvt_ops_per_block": full,
+                "achieved_T_ops_s": round(full * blocks_all / t / 1e12, 2), "peak_T_lane_ops_s": VALU_PEAK_TOPS * world,
+                "frac": round(full * blocks_all / t / 1e12 / (VALU_PEAK_TOPS * world), 4),
+                "note": "reference algorithm's fp32 mul/add/div/sqrt + compares + conversions per block, counted by single-stepping the "
+                        "CPU oracle (profiles/op_counts.json), x blocks / measured step time / (256 CU x 128 lanes x 2.4 GHz per GPU, "
+                        "no FMA credit).  Below the executed-instruction figure where the kernels replace fp32 work by exact packed-"
+                        "integer forms (dot4: 4+ reference ops per instruction), above it where they cannot."}
 
     if world > 1 and scaling == "strong":
         # side figure: weak scaling, one 4096^2 band per rank (what round 1 reported); a few steps only

@@ -1117,6 +1117,120 @@ bc7_finish_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
     }
 }
 
+enum WideKind { WK_SCAN02 = 0, WK_SCAN13 = 1, WK_SCAN7 = 2 };          // scan tasks of the fused and the wide path
+__host__ __device__ constexpr int wide_win_slot(int mode) { return mode == 0 ? 0 : mode == 2 ? 1 : mode == 1 ? 2 : mode == 3 ? 3 : 4; }   // winner rows: m0 m2 m1 m3 m7
+
+// ---- FUSED deep path: whole surfaces in two launches --------------------------------------------------------------------
+// The kernels above run as up to seven launches, each re-reading the 64 B block from HBM and handing winners, best error
+// and the current block to the next through the workspace: 5.4x the algorithmic bytes for a `slow` call.  Nothing in
+// that chain needs a kernel boundary except the register budgets (scans: 4 waves per SIMD; refinement: 2).  So:
+//   bc7_scan_all    ONE launch for the scans of the three-channel families {0,2} and {1,3} (mode 7, whose four-channel
+//                   fits need more registers, gets its own).  Workgroup ids are mapped XCD-aware: MI355X deals consecutive
+//                   workgroups round-robin to its 8 XCDs, each with its own L2, so (chunk, family) = f(workgroup id) runs
+//                   256 chunks of one family, then the SAME chunks of the other, every chunk on the same XCD both times
+//                   -- the second family's texel loads hit that L2 instead of HBM, while a CU still runs one family's
+//                   code for long stretches.  Winners leave as 4 bytes per mode: error (< 2^23: 16 texels x 4 channels
+//                   x 255^2) << 7 | shape;
+//   bc7_finish_all  ONE launch: each lane refines its modes' winners in the reference's order 0,2,1,3,7, then modes
+//                   4,5,6, carrying best error and block in registers, and writes the block once.
+// HBM bytes per block: 64 (scans, shared through L2) + 64 (finish) + 2 x 4 x modes + 16 = ~176: 2.1x algorithmic.
+__device__ __forceinline__ uint32_t pack_win(const Win& w) { return w.err == ERR_MAX ? 0xffffffffu : (((uint32_t)w.err << 7) | ((uint32_t)w.shape & 127u)); }
+__device__ __forceinline__ void unpack_win(Win& w, uint32_t v)
+{
+    if (v == 0xffffffffu) { w.err = ERR_MAX; w.shape = 0; } else { w.err = (int32_t)(v >> 7); w.shape = (int32_t)(v & 127u); }
+    w.key = -1;
+}
+
+struct ScanTasks { int n; int kind[3]; };      // WK_SCAN02 / WK_SCAN13 / WK_SCAN7 in launch order
+
+// FAM7 = false: the three-channel families {0,2} and {1,3} (4 waves per SIMD; ranked lists 3); FAM7 = true: the mode 7 scan
+// alone (four-channel fits need the registers of 3 waves per SIMD; sharing a kernel with the others made those spill).
+__host__ __device__ constexpr int scan_all_waves(bool ranked, bool fam7) { return fam7 ? (ranked ? SWR27 : SW7) : (ranked ? SWR2 : 4); }
+template <bool VEC16, bool RANKED_LISTS, bool FAM7>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(scan_all_waves(RANKED_LISTS, FAM7), scan_all_waves(RANKED_LISTS, FAM7))))
+bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint32_t* __restrict__ wins4,
+             const bc7_enc_settings S, const ScanTasks tasks, const int ranked13, const int ranked7, const int32_t nchunks, const int32_t grain)
+{
+    __shared__ unsigned short s_seed16[2048];
+    __shared__ uint32_t s_seed32[2048];
+    __shared__ uint2 s_pal[12 * TPB];
+    // `grain` chunks of one family, then the same chunks of the next family (grain is a multiple of 8, so a chunk's
+    // families run on the same XCD: workgroup w -> XCD w % 8)
+    const uint32_t w = blockIdx.x, per = (uint32_t)grain * (uint32_t)tasks.n, group = w / per, r = w % per;
+    const int t = (int)(r / (uint32_t)grain);
+    const int32_t chunk = (int32_t)(group * (uint32_t)grain + r % (uint32_t)grain);
+    if (chunk >= nchunks) return;                                    // whole workgroup: no barrier is pending
+    Lane ln;
+    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
+    __syncthreads();
+    const int32_t gid = chunk * TPB + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;
+    ln.keys = nullptr;
+    ln.pal = s_pal + threadIdx.x;
+    load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
+    const int kind = tasks.kind[t];                                  // wave-uniform
+    Win wa, wb;
+    if (!FAM7 && kind == WK_SCAN02) {
+        search_02(ln, S, wa, wb);
+        if (live) { wins4[(int64_t)wide_win_slot(0) * nblocks + b] = pack_win(wa); if (!S.skip_mode2) wins4[(int64_t)wide_win_slot(2) * nblocks + b] = pack_win(wb); }
+    } else if (!FAM7) {
+        if (RANKED_LISTS && ranked13) search_two_subset<false, 3, 2>(ln, S, wa, wb); else search_two_subset<false, 3, 0>(ln, S, wa, wb);
+        if (live) { wins4[(int64_t)wide_win_slot(1) * nblocks + b] = pack_win(wa); wins4[(int64_t)wide_win_slot(3) * nblocks + b] = pack_win(wb); }
+    } else {
+        if (S.channels == 4) { if (RANKED_LISTS && ranked7) search_two_subset<true, 4, 2>(ln, S, wa, wb); else search_two_subset<true, 4, 0>(ln, S, wa, wb); }
+        else                 { if (RANKED_LISTS && ranked7) search_two_subset<true, 3, 2>(ln, S, wa, wb); else search_two_subset<true, 3, 0>(ln, S, wa, wb); }
+        if (live) wins4[(int64_t)wide_win_slot(7) * nblocks + b] = pack_win(wa);
+    }
+}
+
+template <bool VEC16>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst,
+               const uint32_t* __restrict__ wins4, const bc7_enc_settings S)
+{
+    __shared__ unsigned short s_seed16[2048];
+    __shared__ uint32_t s_seed32[2048];
+    __shared__ uint2 s_pal[8 * TPB];
+    Lane ln;
+    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
+    __syncthreads();
+    const int32_t gid = blockIdx.x * TPB + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;
+    ln.keys = nullptr;
+    ln.pal = s_pal + threadIdx.x;
+    load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
+    ln.best_err = ERR_MAX;
+    ln.best[0] = ln.best[1] = ln.best[2] = ln.best[3] = 0u;
+    ln.improved = false;
+    ln.opaque_err = 0;                                                             // kernel.ispc:1267-1277
+    if (S.channels == 4) {
+        uint32_t e = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) { const uint32_t x = ~ln.tx.pl[3][d]; e = udot4(x, x, e); }
+        ln.opaque_err = (int32_t)e;
+    }
+    const bool on13 = S.mode_selection[1];
+    Win w;
+    if (S.mode_selection[0]) {
+        unpack_win(w, wins4[(int64_t)wide_win_slot(0) * nblocks + b]);
+        refine_and_commit<0>(ln, w, S.refineIterations[0], S.channels);
+        if (!S.skip_mode2) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(2) * nblocks + b]); refine_and_commit<2>(ln, w, S.refineIterations[2], S.channels); }
+    }
+    if (on13 && S.fastSkipTreshold_mode1 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(1) * nblocks + b]); refine_and_commit<1>(ln, w, S.refineIterations[1], S.channels); }
+    if (on13 && S.fastSkipTreshold_mode3 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(3) * nblocks + b]); refine_and_commit<3>(ln, w, S.refineIterations[3], S.channels); }
+    if (on13 && S.fastSkipTreshold_mode7 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(7) * nblocks + b]); refine_and_commit<7>(ln, w, S.refineIterations[7], S.channels); }
+    ln.tx.fence();
+    if (S.mode_selection[2]) modes_45(ln, S);
+    if (S.mode_selection[3]) { if (S.channels == 4) mode_6<4>(ln, S); else mode_6<3>(ln, S); }
+    if (live) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
+        if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(ln.best[0], ln.best[1], ln.best[2], ln.best[3]);
+        else { d[0] = ln.best[0]; d[1] = ln.best[1]; d[2] = ln.best[2]; d[3] = ln.best[3]; }
+    }
+}
+
 // ---- WIDE path: calls too small to fill the chip -----------------------------------------------------------------
 // The kernels above give every block one lane and every mode family its own pair of launches, which is what fills
 // 1024 SIMDs for a whole surface -- and what makes a 16 384-block call (the plugin's 0x40000-pixel slice,
@@ -1138,11 +1252,9 @@ constexpr int WIDE_SLOTS = 18;            // candidate slots in commit order: m0
 constexpr int WIDE_SLOT_M4 = 5, WIDE_SLOT_M5 = 13, WIDE_SLOT_M6 = 17;
 constexpr int WIDE_MAX_TASKS = 56;
 constexpr int WIDE_MAX_PARTS = 16;
-enum WideKind { WK_SCAN02 = 0, WK_SCAN13 = 1, WK_SCAN7 = 2, WK_ROT45 = 3, WK_MODE6 = 4 };
 struct WideTasks { int n; uint8_t kind[WIDE_MAX_TASKS]; uint8_t part[WIDE_MAX_TASKS]; uint8_t parts[WIDE_MAX_TASKS]; };
 struct WideModes { int n; uint8_t mode[20]; uint8_t parts[20]; };    // mode: 0,2,1,3,7 refine | 100 + 4 r + c: rotation r, candidate c (mode 4, mode 4 swapped, mode 5) | 6
 
-__host__ __device__ constexpr int wide_win_slot(int mode) { return mode == 0 ? 0 : mode == 2 ? 1 : mode == 1 ? 2 : mode == 3 ? 3 : 4; }
 
 // winners of split scans: [win_slot][part][block] x {err, shape, key, -}, `pstride` parts per slot
 struct WideDims { int32_t nblocks; int32_t pstride; };
@@ -1519,6 +1631,60 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
     const bc7_enc_settings& S = L.S;
     auto ranked = [](int t) { return t > 0 && t < 64; };
     auto small = [](int t) { return t <= 16; };                  // non-positive thresholds disable the mode
+    {
+        // two launches (scan of all families, refinement of all modes) unless a ranked list is longer than 16 shapes (those
+        // keep their keys in 64 KiB of LDS: the per-family kernels below) or ITW_BC7_FUSED=0
+        static const bool fused_on = [] { const char* e = std::getenv("ITW_BC7_FUSED"); return !(e && e[0] == '0'); }();
+        const bool on02 = S.mode_selection[0];
+        const bool on13 = S.mode_selection[1] && (S.fastSkipTreshold_mode1 > 0 || S.fastSkipTreshold_mode3 > 0);
+        const bool on7 = S.mode_selection[1] && S.fastSkipTreshold_mode7 > 0;
+        const bool r13 = on13 && (ranked(S.fastSkipTreshold_mode1) || ranked(S.fastSkipTreshold_mode3));
+        const bool r7 = on7 && ranked(S.fastSkipTreshold_mode7);
+        const bool long13 = r13 && !(small(S.fastSkipTreshold_mode1) && small(S.fastSkipTreshold_mode3));
+        const bool long7 = r7 && !small(S.fastSkipTreshold_mode7);
+        const bool any_mode = on02 || on13 || on7 || S.mode_selection[2] || S.mode_selection[3];
+        if (fused_on && !long13 && !long7 && any_mode) {
+            uint32_t* wins4 = reinterpret_cast<uint32_t*>(workspace);          // [5 modes][n] x 4 B
+            const int32_t nchunks = (int32_t)((n + TPB - 1) / TPB);
+            // Interleave grain, measured at 4096^2 `slow` (scan time / scan FETCH_SIZE): 8 chunks 6.01 ms / 76 MB (two code paths
+            // alternate on every CU: instruction cache), 256 chunks 5.36 ms / 76 MB, 1024 chunks 5.38 ms / 166 MB (L2 no longer
+            // holds the first family's texels), family-major 5.39 ms / 154 MB; two separate launches 5.45 ms.
+            const int32_t chunks8 = ((nchunks + 7) / 8) * 8;
+            int32_t grain = 256;
+            if (grain > chunks8) grain = chunks8;
+            const int32_t groups = (chunks8 + grain - 1) / grain;
+            const int a13 = r13 ? 1 : 0, a7 = r7 ? 1 : 0;
+            ScanTasks T;
+            T.n = 0;
+            if (on13) T.kind[T.n++] = WK_SCAN13;                               // longest first
+            if (on02) T.kind[T.n++] = WK_SCAN02;
+            if (T.n > 0) {
+                const dim3 grid((unsigned)(groups * grain * T.n));
+                if (r13) {
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, false>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, false>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain);
+                } else {
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, false>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, false>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain);
+                }
+            }
+            if (on7) {
+                ScanTasks T7;
+                T7.n = 1; T7.kind[0] = WK_SCAN7;
+                const dim3 grid((unsigned)(((nchunks + 7) / 8) * 8));
+                if (r7) {
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8);
+                } else {
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8);
+                }
+            }
+            if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true>),  L.grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, dst, wins4, S);
+            else       hipLaunchKernelGGL((bc7_finish_all<false>), L.grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, dst, wins4, S);
+            return;
+        }
+    }
     if (S.mode_selection[0]) { launch_search<F_MODES02, 0>(L); launch_finish<F_MODES02>(L); }
     if (S.mode_selection[1] && (S.fastSkipTreshold_mode1 > 0 || S.fastSkipTreshold_mode3 > 0)) {
         if (ranked(S.fastSkipTreshold_mode1) || ranked(S.fastSkipTreshold_mode3)) {
