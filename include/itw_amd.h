@@ -70,6 +70,11 @@ const char* itwVersion(void);
 int64_t itwBandForPart(int32_t width, int32_t height, int32_t bytes_per_block,
                        int32_t part, int32_t parts, int32_t* first_row, int32_t* row_count);
 
+/* The same rule for the formats that keep partial blocks (BC4 / BC5, itw_bc45.h): R = ceil(height/4), ceil(width/4) blocks
+ * per row, and the band that holds the last block row ends at `height` (keep_partial_blocks = 0: identical to the above). */
+int64_t itwBandForPartEx(int32_t width, int32_t height, int32_t bytes_per_block, int32_t part, int32_t parts,
+                         int32_t keep_partial_blocks, int32_t* first_row, int32_t* row_count);
+
 /* Device-side self test hooks (used by tests/ to prove the pinned arithmetic on
  * the GPU): evaluate rcp / rsqrt / float->int of `n` floats resident in HBM. */
 void itwTestRcp  (const float* d_in, float* d_out, int64_t n);

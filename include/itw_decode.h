@@ -24,6 +24,7 @@ extern "C" {
  * all-device calls are asynchronous on the calling thread's stream, itwSetStream).
  * `modes` (optional, may be NULL): one int32 per block -- BC7: mode 0..7, -1 for the reserved all-zero-prefix block;
  * BC6H: mode 0..13 in kernel.ispc's numbering, -1 for a reserved prefix; BC1/BC3: 0.
+ * Width and height must be multiples of 4, except for BC4 / BC5, whose streams may end in partial blocks (cropped on store).
  * Returns 0, or -1 for an unsupported format / misaligned sizes. */
 int itwDecodeBlocks(int dxgi_format, const uint8_t* blocks, int width, int height, uint8_t* out, int64_t out_stride, int32_t* modes);
 

@@ -660,6 +660,19 @@ int64_t itwBandForPart(int32_t width, int32_t height, int32_t bytes_per_block,
     return r0 * bx * bytes_per_block;
 }
 
+int64_t itwBandForPartEx(int32_t width, int32_t height, int32_t bytes_per_block, int32_t part, int32_t parts, int32_t keep_partial_blocks,
+                         int32_t* first_row, int32_t* row_count)
+{
+    if (!keep_partial_blocks) return itwBandForPart(width, height, bytes_per_block, part, parts, first_row, row_count);
+    const int64_t R = ((int64_t)height + 3) / 4, bx = ((int64_t)width + 3) / 4;
+    if (parts <= 0 || part < 0 || part >= parts || height < 1 || width < 1) { if (first_row) *first_row = 0; if (row_count) *row_count = 0; return -1; }
+    const int64_t r0 = R * part / parts, r1 = R * (part + 1) / parts;
+    const int64_t y0 = r0 * 4, y1 = (r1 * 4 < height) ? r1 * 4 : height;       // the band that holds the last block row keeps its partial rows
+    if (first_row) *first_row = (int32_t)y0;
+    if (row_count) *row_count = (int32_t)(y1 > y0 ? y1 - y0 : 0);
+    return r0 * bx * bytes_per_block;
+}
+
 void itwTestRcp(const float* in, float* out, int64_t n)
 {
     if (n <= 0) return;

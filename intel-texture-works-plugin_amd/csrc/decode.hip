@@ -245,7 +245,7 @@ __device__ __forceinline__ int decode_bc6h(Bits& bs, uint32_t (&lo)[16], uint32_
 template <int FMT>
 __global__ void __launch_bounds__(256)
 decode_kernel(const uint8_t* __restrict__ blocks, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ out, int64_t stride,
-              int32_t* __restrict__ modes)
+              int32_t* __restrict__ modes, int32_t width, int32_t height)
 {
     const int32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nblocks) return;
@@ -289,11 +289,14 @@ decode_kernel(const uint8_t* __restrict__ blocks, int32_t blocks_x, int32_t nblo
             mode = decode_bc7(bs, px);
         }
         uint8_t* o = out + (int64_t)yy * 4 * stride + (int64_t)xx * 16;
+        // BC4 / BC5 streams may end in partial blocks (the encoder keeps them, itw_bc45.h): texels beyond the surface are cropped
+        const int ny = (FMT == 4 || FMT == 5) ? min(4, height - yy * 4) : 4, nx = (FMT == 4 || FMT == 5) ? min(4, width - xx * 4) : 4;
 #pragma unroll
         for (int y = 0; y < 4; y++) {
+            if (y >= ny) break;
             uint32_t* row = reinterpret_cast<uint32_t*>(o + y * stride);
 #pragma unroll
-            for (int x = 0; x < 4; x++) row[x] = px[y * 4 + x];
+            for (int x = 0; x < 4; x++) if (x < nx) row[x] = px[y * 4 + x];
         }
     }
     if (modes) modes[b] = mode;
@@ -312,8 +315,10 @@ bool on_device(const void* p) { return itw::is_device_pointer(p); }     // devic
 extern "C" int itwDecodeBlocks(int f, const uint8_t* blocks, int width, int height, uint8_t* out, int64_t out_stride, int32_t* modes)
 {
     const int kind = (f == 71 || f == 72) ? 1 : (f == 77 || f == 78) ? 3 : (f == 98 || f == 99) ? 7 : (f == 95 || f == 96) ? 6 : f == 80 ? 4 : f == 83 ? 5 : 0;
-    if (!kind || width < 4 || height < 4 || (width & 3) || (height & 3) || (out_stride & 3)) return -1;
-    const int bx = width / 4, by = height / 4;
+    const bool partial_ok = (kind == 4 || kind == 5);            // the DirectXTex formats keep partial blocks
+    if (!kind || (out_stride & 3)) return -1;
+    if (partial_ok ? (width < 1 || height < 1) : (width < 4 || height < 4 || (width & 3) || (height & 3))) return -1;
+    const int bx = (width + 3) / 4, by = (height + 3) / 4;
     const int64_t n = (int64_t)bx * by;
     const size_t in_bytes = (size_t)n * ((kind == 1 || kind == 4) ? 8 : 16), texel = kind == 6 ? 8 : 4;
     const size_t row_bytes = (size_t)width * texel;
@@ -329,12 +334,12 @@ extern "C" int itwDecodeBlocks(int f, const uint8_t* blocks, int width, int heig
     if (modes && !dmodes) DEC_CHECK(hipMalloc((void**)&d_modes, (size_t)n * 4));
     const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
     switch (kind) {
-    case 1: hipLaunchKernelGGL((itw::decode_kernel<1>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
-    case 3: hipLaunchKernelGGL((itw::decode_kernel<3>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
-    case 7: hipLaunchKernelGGL((itw::decode_kernel<7>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
-    case 4: hipLaunchKernelGGL((itw::decode_kernel<4>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
-    case 5: hipLaunchKernelGGL((itw::decode_kernel<5>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
-    default: hipLaunchKernelGGL((itw::decode_kernel<6>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes); break;
+    case 1: hipLaunchKernelGGL((itw::decode_kernel<1>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes, width, height); break;
+    case 3: hipLaunchKernelGGL((itw::decode_kernel<3>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes, width, height); break;
+    case 7: hipLaunchKernelGGL((itw::decode_kernel<7>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes, width, height); break;
+    case 4: hipLaunchKernelGGL((itw::decode_kernel<4>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes, width, height); break;
+    case 5: hipLaunchKernelGGL((itw::decode_kernel<5>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes, width, height); break;
+    default: hipLaunchKernelGGL((itw::decode_kernel<6>), grid, blk, 0, st, d_in, bx, (int32_t)n, d_out, d_stride, d_modes, width, height); break;
     }
     DEC_CHECK(hipGetLastError());
     if (!dout) DEC_CHECK(hipMemcpy2DAsync(out, (size_t)out_stride, d_out, row_bytes, row_bytes, (size_t)height, hipMemcpyDeviceToHost, st));

@@ -16,7 +16,7 @@ EXPORTED_SYMBOLS = tuple(
     ["CompressBlocksBC1", "CompressBlocksBC3", "CompressBlocksBC6H", "CompressBlocksBC7"]
     + ["GetProfile_" + p for p in BC7_PROFILES] + ["GetProfile_bc6h_" + p for p in BC6H_PROFILES]
     + ["itwSetStream", "itwGetStream", "itwAvailable", "itwSetErrorMode", "itwLastError", "itwClearError", "itwSetBc7Path",
-       "itwDeviceInfo", "itwVersion", "itwBandForPart",
+       "itwDeviceInfo", "itwVersion", "itwBandForPart", "itwBandForPartEx",
        "itwTestRcp", "itwTestRsqrt", "itwTestF2I"]
     # include/itw_dispatch.h: the reference's dispatch layer (win32Threads.h), slice loop, pad pre-pass
     + ["GetProcessorCount", "InitWin32Threads", "DestroyThreads", "GetBytesPerBlock", "CompressImageMT", "CompressImageST",
@@ -110,6 +110,8 @@ def lib():
         L.itwVersion.restype = C.c_char_p
         L.itwBandForPart.argtypes = [C.c_int32] * 5 + [C.POINTER(C.c_int32)] * 2
         L.itwBandForPart.restype = C.c_int64
+        L.itwBandForPartEx.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_int32)] * 2
+        L.itwBandForPartEx.restype = C.c_int64
         for n in ("itwTestRcp", "itwTestRsqrt", "itwTestF2I"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
             getattr(L, n).restype = None
@@ -212,7 +214,7 @@ def bc6h_profile(name):
 def band_for_part(width, height, fmt, part, parts):
     """(first_texel_row, texel_rows, output_byte_offset) of `part` among `parts` (itwBandForPart)."""
     y0, n = C.c_int32(), C.c_int32()
-    off = lib().itwBandForPart(width, height, BYTES_PER_BLOCK[fmt], part, parts, C.byref(y0), C.byref(n))
+    off = lib().itwBandForPartEx(width, height, BYTES_PER_BLOCK[fmt], part, parts, 1 if fmt in KEEPS_PARTIAL_BLOCKS else 0, C.byref(y0), C.byref(n))
     if off < 0:
         raise ValueError((part, parts))
     return y0.value, n.value, off
@@ -359,7 +361,7 @@ def decode(fmt, blocks, width, height, want_modes=False):
     (int32) when asked."""
     import numpy as np
     key = {"bc1": 71, "bc3": 77, "bc7": 98, "bc6h": 95, "bc4": 80, "bc5": 83}[fmt]
-    nb = (width // 4) * (height // 4)
+    nb = block_count(fmt, width, height)
     es = 2 if fmt == "bc6h" else 1
     if isinstance(blocks, np.ndarray):
         blk = np.ascontiguousarray(blocks, dtype=np.uint8).reshape(-1)

@@ -15,7 +15,10 @@ from . import abi
 def band_of(width, height, fmt, rank, world):
     """(first_texel_row, texel_rows, out_byte_offset, out_byte_len) of `rank`'s band."""
     y0, rows, off = abi.band_for_part(width, height, fmt, rank, world)
-    nbytes = (rows // 4) * (width // 4) * abi.BYTES_PER_BLOCK[fmt]
+    if fmt in abi.KEEPS_PARTIAL_BLOCKS:                        # BC4 / BC5: partial last block row and column are encoded
+        nbytes = ((rows + 3) // 4) * ((width + 3) // 4) * abi.BYTES_PER_BLOCK[fmt]
+    else:
+        nbytes = (rows // 4) * (width // 4) * abi.BYTES_PER_BLOCK[fmt]
     return y0, rows, off, nbytes
 
 

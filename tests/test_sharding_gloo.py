@@ -175,3 +175,22 @@ def test_bench_plan_weak_and_strong_geometry():
             w = bench.plan("weak", 4096, world, r, "bc7")
             assert (w["width"], w["height"], w["rows"], w["y0"]) == (4096, 4096 * world, 4096, 4096 * r)
         assert offs == [(i * offs[0][1], offs[0][1]) for i in range(world)] and offs[0][1] * world == 16384 * 16384
+
+
+@pytest.mark.parametrize("fmt,h,w,parts", [("bc5", 62, 61, 3), ("bc4", 9, 5, 2), ("bc5", 64, 64, 5), ("bc4", 3, 3, 4)])
+def test_band_rule_keeps_partial_blocks_for_bc4_bc5(fmt, h, w, parts):
+    """BC4 / BC5 keep the partial last block row and column (itw_bc45.h), so their bands follow ceil rules
+    (itwBandForPartEx): band streams of the CPU oracle concatenate to the whole-surface stream."""
+    from oracle import pyoracle
+    from itw_amd import shard, surfaces
+    img = np.ascontiguousarray(surfaces.ldr_smooth(64, 64)[:h, :w])
+    whole = pyoracle.encode(fmt, img).reshape(-1)
+    got = np.zeros_like(whole)
+    covered = 0
+    for r in range(parts):
+        y0, rows, off, nbytes = shard.band_of(w, h, fmt, r, parts)
+        assert off == covered
+        if rows > 0:
+            got[off:off + nbytes] = pyoracle.encode(fmt, np.ascontiguousarray(img[y0:y0 + rows])).reshape(-1)
+        covered += nbytes
+    assert covered == whole.size and np.array_equal(got, whole)
