@@ -199,7 +199,7 @@ def rocprof_kernels(fmt):
         with open(os.path.join(ROOT, "profiles", names[-1])) as f:
             for r in csv.DictReader(f):
                 if pat in r["Name"]:
-                    m = re.search(r"(bc\w+_kernel<[^>]*>)", r["Name"])
+                    m = re.search(r"(bc\w+<[^>]*>)", r["Name"])
                     out[m.group(1) if m else r["Name"][:48]] = round(float(r["AverageNs"]) / 1e6, 4)
         return {"source": "profiles/" + names[-1], "avg_ms": out} if out else None
     except (OSError, ValueError, KeyError):

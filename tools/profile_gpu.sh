@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-KERNELS='bc7_search_kernel|bc7_finish_kernel|bc13_kernel|bc6h_|bc45_kernel'
+KERNELS='bc7_|bc13_kernel|bc6h_|bc45_kernel'
 
 # 1. kernel trace + stats of the headline workload alone (the timed region of the default bench command: BC7 slow), so the
 #    per-kernel averages are those of one workload; then of the whole default command (all side formats)
