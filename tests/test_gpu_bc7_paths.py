@@ -136,3 +136,56 @@ def test_bc6h_custom_list_lengths_on_both_shapes(itw, gpu, paths, oracle):
             paths(path)
             got = _encode6(itw, gpu, img, s)
             assert first_mismatch(got, want, 16) is None, (n, r1, r2, path, first_mismatch(got, want, 16))
+
+
+@pytest.mark.parametrize("path", ["deep", "wide"])
+def test_random_settings_fuzz_on_each_shape(itw, gpu, paths, oracle, path):
+    """The settings struct is a caller-owned POD: 96 random structs (mode families on/off, refine counts, thresholds at the
+    16|17 and 64 boundaries, every mode45_channel0, both channel counts) forced through each launch shape -- "deep" is the
+    fused two-launch path (or the per-family kernels when a ranked list is longer than 16 shapes), "wide" the split scans
+    (falling back to deep where it does not support the settings)."""
+    from itw_amd import surfaces
+    rng = np.random.default_rng(2026 + (1 if path == "wide" else 0))
+    img = np.ascontiguousarray(np.concatenate([surfaces.ldr_smooth(32, 64, seed=surfaces.SEED + 5), surfaces.ldr_uniform(16, 64),
+                                               _posterised(16, 64, 4)], axis=0))
+    img[..., 3] = surfaces.ldr_smooth(64, 64, seed=surfaces.SEED + 6)[..., 0]
+    thresholds = [0, 1, 2, 5, 12, 16, 17, 40, 63, 64, 70]
+    paths(path)
+    for trial in range(96):
+        s, so = itw.Bc7Settings(), oracle.Bc7Settings()
+        vals = {"skip_mode2": bool(rng.integers(0, 2)), "fastSkipTreshold_mode1": int(rng.choice(thresholds)),
+                "fastSkipTreshold_mode3": int(rng.choice(thresholds)), "fastSkipTreshold_mode7": int(rng.choice(thresholds)),
+                "mode45_channel0": int(rng.integers(0, 4)), "refineIterations_channel": int(rng.integers(0, 6)),
+                "channels": int(rng.choice([3, 4]))}
+        sel = [bool(rng.integers(0, 2)) for _ in range(4)]
+        if not any(sel):
+            sel[int(rng.integers(0, 4))] = True
+        ref = [int(rng.integers(0, 6)) for _ in range(8)]
+        for t in (s, so):
+            for k, v in vals.items():
+                setattr(t, k, v)
+            for i in range(4):
+                t.mode_selection[i] = sel[i]
+            for i in range(8):
+                t.refineIterations[i] = ref[i]
+        got = _encode(itw, gpu, img, s)
+        want = oracle.encode("bc7", img, so)
+        assert first_mismatch(got, want, 16) is None, (path, trial, vals, sel, ref, first_mismatch(got, want, 16))
+
+
+def test_bc6h_random_settings_on_each_shape(itw, gpu, paths, oracle):
+    from itw_amd import surfaces
+    rng = np.random.default_rng(606)
+    img = np.ascontiguousarray(np.concatenate([surfaces.hdr_smooth(32, 64), surfaces.hdr_random_bits(32, 64)], axis=0))
+    for trial in range(48):
+        s, so = itw.Bc6hSettings(), oracle.Bc6hSettings()
+        vals = {"slow_mode": bool(rng.integers(0, 2)), "fast_mode": bool(rng.integers(0, 2)), "refineIterations_1p": int(rng.integers(0, 4)),
+                "refineIterations_2p": int(rng.integers(0, 4)), "fastSkipTreshold": int(rng.choice([0, 1, 2, 3, 8, 10, 31, 32, 33, 64]))}
+        for t in (s, so):
+            for k, v in vals.items():
+                setattr(t, k, v)
+        want = oracle.encode("bc6h", img, so)
+        for path in ("wide", "deep"):
+            paths(path)
+            got = _encode6(itw, gpu, img, s)
+            assert first_mismatch(got, want, 16) is None, (path, trial, vals, first_mismatch(got, want, 16))
