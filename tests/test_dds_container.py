@@ -117,3 +117,25 @@ def test_bc4_bc5_legacy_fourcc_read_both_spellings(itw):
         alt = f.copy()
         alt[84:88] = np.frombuffer(cc, dtype=np.uint8)                 # ddspf.dwFourCC
         assert itw.lib().itwDdsReadHeader(alt.ctypes.data, alt.size, C.byref(d)) == 128 and d.dxgi_format == fmt
+
+
+@pytest.mark.parametrize("key,expect,mips,cube,arr", [("bc1", "DXT1", 1, False, 1), ("bc3", "DXT5", 5, False, 1), ("bc4", "BC4U", 1, False, 1),
+                                                      ("bc5", "BC5U", 3, False, 1), ("bc7", "DX10", 1, False, 1), ("bc7_srgb", "DX10", 9, True, 1),
+                                                      ("bc6h", "DX10", 4, False, 3), ("bc1_srgb", "DX10", 1, False, 1)])
+def test_headers_read_back_through_the_references_own_dds_definitions(itw, tmp_path, key, expect, mips, cube, arr):
+    """oracle/_ref/ref_dds_check is built on DirectXTex/DDS.h compiled unmodified from the reference: struct DDS_HEADER /
+    DDS_HEADER_DXT10, the DDSPF_* pixel formats and the flag macros come from there, not from this repo."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "ref_dds_check")
+    if not os.path.exists(exe):
+        if not os.path.exists("/root/reference/3rdParty/DirectXTex/DirectXTex/DDS.h"):
+            pytest.skip("oracle/_ref/ref_dds_check not prebuilt and /root/reference absent")
+        subprocess.run(["make", "-C", os.path.join(root, "oracle", "ref_build")], check=True)
+    d, buf = _hdr(itw, key, 256, 128, mips=mips, cube=cube, arr=arr)
+    path = tmp_path / "h.dds"
+    buf.tofile(path)
+    r = subprocess.run([exe, str(path), expect, str(itw.DXGI_FORMAT[key]), "256", "128", str(mips), "1" if cube else "0", str(arr)],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == "OK", r.stdout + r.stderr
