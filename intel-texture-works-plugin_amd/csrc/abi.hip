@@ -479,7 +479,11 @@ bool coalesce_small_call(const Job& j, const rgba_surface* src, uint8_t* dst, in
         batch.swap(c.queue);
         c.burst += (int)batch.size();
         lk.unlock();
-        run_batch(batch);
+        try { run_batch(batch); }
+        catch (...) {                                     // anything but an itw::Failure (those are caught per merged call):
+            for (Pending* p : batch)                      // the requests must still be released and leadership handed on
+                if (!p->failed) { p->failed = true; std::snprintf(p->msg, sizeof p->msg, "unexpected C++ exception while running a combined call"); }
+        }
         lk.lock();
         for (Pending* p : batch) p->done = true;
         if (c.queue.empty()) { c.expected = c.burst; c.burst = 0; }      // burst over
