@@ -431,7 +431,7 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
         Segment sg0[3];
         #pragma unroll 1
         for (int j = 0; j < M.pairs; j++) {
-            const SubsetMask s = (j == 0) ? sm[0] : ((j == 1) ? sm[1] : sm[2]);
+            const SubsetMask s = subset_of(w.shape, j);       // (selecting among sm[0..2] here made the compiler index them in scratch)
             IStats<M.ch> st;
             stats_int<M.ch>(st, ln.tx.pl, s);
             float ep[2][4];
