@@ -16,11 +16,14 @@
 //     palettes in LDS (one v_dot4 per candidate), least-squares sums are dot4 chains
 //     (proofs in bc7_exact.hpp).  What can round (PCA, endpoint quantisation, the 2x2
 //     solve) is fp32 with the pinned x86 arithmetic;
-//   * per multi-subset mode family ({0,2} {1,3} {7}) a SEARCH kernel (the scan of the
-//     shapes, 110-128 VGPRs, 4 waves per SIMD) and a FINISH kernel (refinement of the
-//     winners, per-lane shapes); modes 4/5/6 are one kernel.  Families run in the
-//     reference's order and only communicate through "best error so far"
-//     (kernel.ispc:1358, 1638, 1684) and the search winners, in a 36 B/block workspace;
+//   * the SCANS of the shapes (110-128 VGPRs, 4 waves per SIMD) and the REFINEMENT of each mode's winner (per-lane shapes,
+//     2 waves per SIMD) have different register budgets and therefore live in different kernels; how many launches a call
+//     takes depends on its size (bottom of this file): whole surfaces run FUSED (bc7_scan_all: the scans of families {0,2}
+//     and {1,3} in one launch, XCD-aware so the second family reads its texels from L2; bc7_finish_all: every mode's
+//     refinement + modes 4/5/6 in one launch), calls too small to fill the chip run WIDE (each scan split over several
+//     waves, winners joined by an ordered argmin, single-subset modes on a second stream).  Families run in the
+//     reference's order and only communicate through "best error so far" (kernel.ispc:1358, 1638, 1684) and the search
+//     winners; the per-family search / finish kernel pairs of round 1 remain for ranked lists longer than 16 shapes;
 //   * the scans produce a candidate's ERROR and nothing else: the level a texel takes
 //     and the packed indices matter for a mode's winner alone, so the winner record is
 //     {error, shape} and the finish kernel recomputes endpoints and indices of the
