@@ -84,8 +84,21 @@ def make_band(fmt, scaling, size, geo, rank):
     return np.ascontiguousarray(base[rows][:, cols])
 
 
+# ITW_BENCH_CONTROL_FLOW_TEST=1: no GPU, gloo instead of RCCL, the encode replaced by a memset.  NOT a measurement: it exists
+# so that tests/test_sharding_gloo.py can execute the N > 1 control flow of this file (plan, bands, pipelined gather, max over
+# ranks, weak side figure, the JSON line) on CPU before the driver runs it on eight GPUs.
+FAKE = os.environ.get("ITW_BENCH_CONTROL_FLOW_TEST") == "1"
+
+
+def _sync():
+    if not FAKE:
+        torch.cuda.synchronize()
+
+
 def time_kernel(itw, fmt, prof, d_img, d_out, steps, warmup):
     """Average launch duration (ms) from HIP events recorded on the stream the kernel runs on."""
+    if FAKE:
+        return 1.0, 1.0
     for _ in range(warmup):
         itw.compress(fmt, d_img, prof, out=d_out)
     torch.cuda.synchronize()
@@ -234,18 +247,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
     import itw_amd
     itw_amd.lib()                                   # fail loudly if the HIP library is missing
+    if FAKE:
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
 
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if FAKE:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     fmt, prof = WORKLOADS[args.workload]
     heavy = fmt in ("bc7", "bc6h")
@@ -267,21 +285,22 @@ def main():
         equal = geo["band_bytes"] * world == geo["total_bytes"]
         assert equal, "bench bands must be equal (in-place all-gather): pick a size whose block rows divide by N"
         assert geo["band_off"] == rank * geo["band_bytes"]
-        pipe = shard.BandPipeline(geo["band_bytes"], world, rank, dev, lambda out: itw_amd.compress(fmt, d_img, prof, out=out))
+        encode_into = (lambda out: out.zero_()) if FAKE else (lambda out: itw_amd.compress(fmt, d_img, prof, out=out))
+        pipe = shard.BandPipeline(geo["band_bytes"], world, rank, dev, encode_into)
         for _ in range(warmup):
             pipe.step()
         pipe.drain()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             pipe.step()
         pipe.drain()
-        torch.cuda.synchronize()
+        _sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync()
         elapsed = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -316,8 +335,8 @@ def main():
                        "blocks_per_gpu": nblocks, "sharding": "block-row bands, one per rank (itwBandForPart); all_gather of output bands over "
                        "RCCL, overlapped with the next step's encode" if world > 1 else "single GPU",
                        "ranks_seen_by_rccl": (dist.get_world_size() if dist is not None else 1),
-                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if dist is not None else None),
-                       "device": itw_amd.device_info(), "lib": itw_amd.version()},
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if (dist is not None and not FAKE) else None),
+                       "device": ("CONTROL-FLOW TEST ON CPU -- not a measurement" if FAKE else itw_amd.device_info()), "lib": itw_amd.version()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": pmc_traffic(args.workload) if (world == 1 and size == 4096) else None,   # PMC passes were taken at 4096^2
@@ -360,7 +379,8 @@ def main():
     if world > 1 and scaling == "strong":
         # side figure: weak scaling, one 4096^2 band per rank (what round 1 reported); a few steps only
         del d_img, pipe
-        torch.cuda.empty_cache()
+        if not FAKE:
+            torch.cuda.empty_cache()
         w_steps = max(3, min(steps, 5))
         w_elapsed, w_geo, _, _, w_pipe = run_job("weak", 4096, w_steps, 1)
         if rank == 0:

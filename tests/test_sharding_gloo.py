@@ -194,3 +194,25 @@ def test_band_rule_keeps_partial_blocks_for_bc4_bc5(fmt, h, w, parts):
             got[off:off + nbytes] = pyoracle.encode(fmt, np.ascontiguousarray(img[y0:y0 + rows])).reshape(-1)
         covered += nbytes
     assert covered == whole.size and np.array_equal(got, whole)
+
+
+def test_bench_n_gt_1_control_flow_runs_end_to_end_on_cpu():
+    """bench.py --gpus 2 as the driver launches it (one process per rank, env rendezvous), with ITW_BENCH_CONTROL_FLOW_TEST=1:
+    gloo instead of RCCL and a memset instead of the encode.  Not a measurement -- it executes every Python line of the N > 1
+    path (strong plan of one surface, bands, pipelined in-place all-gather, max over ranks, weak side figure, the JSON line)."""
+    import json
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, ITW_BENCH_CONTROL_FLOW_TEST="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--size", "512", "--no-formats", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    line = [l for l in outs[0][0].splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 2 and j["config"]["ranks_seen_by_rccl"] == 2
+    assert "512x512" in j["config"]["workload"] and j["weak_side"]["steps"] >= 3 and j["value"] > 0
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]          # only rank 0 prints
