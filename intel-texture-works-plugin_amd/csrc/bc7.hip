@@ -1152,7 +1152,8 @@ __host__ __device__ constexpr int scan_all_waves(bool ranked, bool fam7) { retur
 template <bool VEC16, bool RANKED_LISTS, bool FAM7>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(scan_all_waves(RANKED_LISTS, FAM7), scan_all_waves(RANKED_LISTS, FAM7))))
 bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint32_t* __restrict__ wins4,
-             const bc7_enc_settings S, const ScanTasks tasks, const int ranked13, const int ranked7, const int32_t nchunks, const int32_t grain)
+             const bc7_enc_settings S, const ScanTasks tasks, const int ranked13, const int ranked7, const int32_t nchunks, const int32_t grain,
+             const int32_t* __restrict__ alpha_err)
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
@@ -1172,6 +1173,15 @@ bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, 
     ln.keys = nullptr;
     ln.pal = s_pal + threadIdx.x;
     load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
+    if (!FAM7 && alpha_err) {
+        // RGBA profile, alpha-capable modes already encoded (bc7_finish_all<.., 1>): an RGB-only mode's error includes
+        // sum (alpha - 255)^2 (kernel.ispc:1267-1277, 1356), so where that term alone exceeds the alpha modes' best error no
+        // three-channel mode can win or tie.  Whole waves of such blocks skip their scans (exact: the block is unchanged).
+        uint32_t e = 0;
+#pragma unroll
+        for (int d = 0; d < 4; d++) { const uint32_t x = ~ln.tx.pl[3][d]; e = udot4(x, x, e); }
+        if (__all((int32_t)e > alpha_err[b])) return;
+    }
     const int kind = tasks.kind[t];                                  // wave-uniform
     Win wa, wb;
     if (!FAM7 && kind == WK_SCAN02) {
@@ -1187,10 +1197,14 @@ bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, 
     }
 }
 
-template <bool VEC16>
+// PHASE 0: every mode, reference order (RGB profiles).  RGBA profiles run in two phases so that the three-channel modes can be
+// skipped where they cannot win: PHASE 1 = the alpha-capable modes 7,4,5,6 (their relative order kept), leaves the block and
+// its error; PHASE 2 = modes 0,2,1,3 for the waves that still need them, then the reference's choice between the two groups:
+// the first strict minimum over 0,2,1,3,7,4,5,6 is the RGB group's winner iff its error <= the alpha group's.
+template <bool VEC16, int PHASE>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst,
-               const uint32_t* __restrict__ wins4, const bc7_enc_settings S)
+               const uint32_t* __restrict__ wins4, const bc7_enc_settings S, int32_t* __restrict__ alpha_err)
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
@@ -1215,18 +1229,29 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
         ln.opaque_err = (int32_t)e;
     }
     const bool on13 = S.mode_selection[1];
-    Win w;
-    if (S.mode_selection[0]) {
-        unpack_win(w, wins4[(int64_t)wide_win_slot(0) * nblocks + b]);
-        refine_and_commit<0>(ln, w, S.refineIterations[0], S.channels);
-        if (!S.skip_mode2) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(2) * nblocks + b]); refine_and_commit<2>(ln, w, S.refineIterations[2], S.channels); }
+    int32_t e_alpha = ERR_MAX;
+    if (PHASE == 2) {
+        e_alpha = alpha_err[b];
+        if (__all(ln.opaque_err > e_alpha)) return;          // same predicate as the scans: these waves have no winners to refine
     }
-    if (on13 && S.fastSkipTreshold_mode1 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(1) * nblocks + b]); refine_and_commit<1>(ln, w, S.refineIterations[1], S.channels); }
-    if (on13 && S.fastSkipTreshold_mode3 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(3) * nblocks + b]); refine_and_commit<3>(ln, w, S.refineIterations[3], S.channels); }
-    if (on13 && S.fastSkipTreshold_mode7 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(7) * nblocks + b]); refine_and_commit<7>(ln, w, S.refineIterations[7], S.channels); }
-    ln.tx.fence();
-    if (S.mode_selection[2]) modes_45(ln, S);
-    if (S.mode_selection[3]) { if (S.channels == 4) mode_6<4>(ln, S); else mode_6<3>(ln, S); }
+    Win w;
+    if (PHASE != 1) {
+        if (S.mode_selection[0]) {
+            unpack_win(w, wins4[(int64_t)wide_win_slot(0) * nblocks + b]);
+            refine_and_commit<0>(ln, w, S.refineIterations[0], S.channels);
+            if (!S.skip_mode2) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(2) * nblocks + b]); refine_and_commit<2>(ln, w, S.refineIterations[2], S.channels); }
+        }
+        if (on13 && S.fastSkipTreshold_mode1 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(1) * nblocks + b]); refine_and_commit<1>(ln, w, S.refineIterations[1], S.channels); }
+        if (on13 && S.fastSkipTreshold_mode3 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(3) * nblocks + b]); refine_and_commit<3>(ln, w, S.refineIterations[3], S.channels); }
+    }
+    if (PHASE != 2) {
+        if (on13 && S.fastSkipTreshold_mode7 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(7) * nblocks + b]); refine_and_commit<7>(ln, w, S.refineIterations[7], S.channels); }
+        ln.tx.fence();
+        if (S.mode_selection[2]) modes_45(ln, S);
+        if (S.mode_selection[3]) { if (S.channels == 4) mode_6<4>(ln, S); else mode_6<3>(ln, S); }
+    }
+    if (PHASE == 1 && live) alpha_err[b] = ln.best_err;
+    if (PHASE == 2 && !(ln.best_err <= e_alpha)) return;     // the alpha group's block stands (ties go to the earlier, RGB, group)
     if (live) {
         uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
         if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(ln.best[0], ln.best[1], ln.best[2], ln.best[3]);
@@ -1657,6 +1682,8 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             if (grain > chunks8) grain = chunks8;
             const int32_t groups = (chunks8 + grain - 1) / grain;
             const int a13 = r13 ? 1 : 0, a7 = r7 ? 1 : 0;
+            int32_t* alpha_err = reinterpret_cast<int32_t*>(wins4 + (size_t)5 * n);            // [n] x 4 B behind the winner rows
+            auto scan_rgb = [&](const int32_t* prune) {
             ScanTasks T;
             T.n = 0;
             if (on13) T.kind[T.n++] = WK_SCAN13;                               // longest first
@@ -1664,27 +1691,54 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             if (T.n > 0) {
                 const dim3 grid((unsigned)(groups * grain * T.n));
                 if (r13) {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, false>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, false>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, false>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, prune);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, false>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, prune);
                 } else {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, false>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, false>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, false>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, prune);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, false>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, prune);
                 }
             }
+            };
+            auto scan_7 = [&]() {
             if (on7) {
                 ScanTasks T7;
                 T7.n = 1; T7.kind[0] = WK_SCAN7;
                 const dim3 grid((unsigned)(((nchunks + 7) / 8) * 8));
                 if (r7) {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr);
                 } else {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr);
                 }
             }
-            if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true>),  L.grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, dst, wins4, S);
-            else       hipLaunchKernelGGL((bc7_finish_all<false>), L.grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, dst, wins4, S);
+            };
+            auto finish = [&](int phase) {
+                if (phase == 0)      { if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true, 0>), L.grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err);
+                                       else       hipLaunchKernelGGL((bc7_finish_all<false, 0>), L.grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err); }
+                else if (phase == 1) { if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true, 1>), L.grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err);
+                                       else       hipLaunchKernelGGL((bc7_finish_all<false, 1>), L.grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err); }
+                else                 { if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true, 2>), L.grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err);
+                                       else       hipLaunchKernelGGL((bc7_finish_all<false, 2>), L.grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err); }
+            };
+            // RGBA profile with both groups of modes: alpha-capable modes first, then the three-channel modes only where they can
+            // still win (see bc7_finish_all); otherwise everything in the reference's order
+            static const bool prune_on = [] { const char* e = std::getenv("ITW_BC7_ALPHA_PRUNE"); return !(e && e[0] == '0'); }();
+            const bool rgb_group = on02 || on13;
+            const bool alpha_group = on7 || S.mode_selection[2] || S.mode_selection[3];
+            auto launch_scans_and_finish = [&]() {
+                if (prune_on && S.channels == 4 && rgb_group && alpha_group) {
+                    if (on7) scan_7();
+                    finish(1);
+                    scan_rgb(alpha_err);
+                    finish(2);
+                } else {
+                    if (rgb_group) scan_rgb(nullptr);
+                    if (on7) scan_7();
+                    finish(0);
+                }
+            };
+            launch_scans_and_finish();
             return;
         }
     }

@@ -189,3 +189,33 @@ def test_bc6h_random_settings_on_each_shape(itw, gpu, paths, oracle):
             paths(path)
             got = _encode6(itw, gpu, img, s)
             assert first_mismatch(got, want, 16) is None, (path, trial, vals, first_mismatch(got, want, 16))
+
+
+@pytest.mark.parametrize("prof", ["alpha_fast", "alpha_basic", "alpha_slow"])
+def test_alpha_first_order_and_skipped_rgb_modes(itw, gpu, paths, oracle, prof):
+    """RGBA profiles in the fused shape run modes 7,4,5,6 first and skip modes 0-3 for waves (64 consecutive blocks) whose
+    every block has sum (255 - alpha)^2 above the alpha modes' error (bc7_finish_all, kernel.ispc:1267-1277, 1356).  Rows of
+    blocks here are built per wave: opaque (nothing skipped, RGB modes win or tie), translucent (whole waves skipped),
+    alpha 254 speckles (opaque-error of a few units against alpha-mode errors of the same size: ties and near ties), and
+    waves mixing all of them block by block."""
+    from itw_amd import surfaces
+    h, w = 64, 1024                                           # 256 blocks per block row = 4 waves; 16 block rows
+    rng = np.random.default_rng(77)
+    img = surfaces.ldr_smooth(h, w, seed=surfaces.SEED + 21).copy()
+    img[16:32] = _posterised(16, w, 4, seed=3)                # flat colours: zero-error fits, exact ties between the groups
+    a = np.full((h, w), 255, np.uint8)
+    a[:, 256:512] = rng.integers(90, 170, (h, 256))           # translucent waves
+    speck = rng.random((h, 256)) < 0.08
+    a[:, 512:768] = np.where(speck, 254, 255)                 # nearly opaque
+    blk = rng.integers(0, 4, (h // 4, 64))                    # mixed wave: per block opaque / 254 / smooth ramp / noise
+    kinds = np.repeat(np.repeat(blk, 4, 0), 4, 1)
+    ramp = np.broadcast_to(np.linspace(0, 255, 256).astype(np.uint8), (h, 256))
+    a[:, 768:] = np.select([kinds == 0, kinds == 1, kinds == 2], [255, 254, ramp], rng.integers(0, 256, (h, 256)))
+    img[..., 3] = a
+    want = oracle.encode_mt("bc7", img, prof)
+    for path in ("deep", "wide"):
+        paths(path)
+        got = _encode(itw, gpu, img, prof)
+        assert first_mismatch(got, want, 16) is None, (path, first_mismatch(got, want, 16))
+    modes = np.array([int(b[0]).bit_length() and (int(b[0]) & -int(b[0])).bit_length() - 1 for b in want.reshape(-1, 16)])
+    assert (modes <= 3).any() and (modes >= 4).any()          # both groups of modes win somewhere
