@@ -423,6 +423,21 @@ def main():
                 del d2, o2
             except Exception as e:
                 side["@colors16m"] = {"error": repr(e)}
+            # BC1 / BC3 are the HBM-side kernels: the same kernel on the 16384^2 surface of configs[4], where the launch ramp and
+            # tail (about 6 us) stop mattering -- the steady-state fraction of the HBM roofline
+            try:
+                big = 16384
+                d2 = torch.from_numpy(make_surface("bc1", 4096, 0)).to(dev).repeat(big // 4096, big // 4096, 1).contiguous()   # I5 = I3 tiled
+                o2 = torch.empty((big // 4) ** 2 * 16, dtype=torch.uint8, device=dev)
+                for wl in ("bc1", "bc3"):
+                    avg, mn = time_kernel(itw_amd, wl, None, d2, o2, steps=10, warmup=1)
+                    gbs = ALG_BYTES[wl] * (big // 4) ** 2 / (avg * 1e-3) / 1e9
+                    side[wl + "@16384"] = {"Mpixels/s": round(big * big / (avg * 1e-3) / 1e6, 1), "kernel_ms_avg": round(avg, 4),
+                                           "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5)}
+                del d2, o2
+                torch.cuda.empty_cache()
+            except Exception as e:
+                side["@16384"] = {"error": repr(e)}
             # SURVEY 8(d) input I4 / BASELINE configs[3]: the reference's monkey-32bit.hdr (RGBE -> RGBA16F, committed as a
             # fixture: tests/golden/inputs.npz) tiled 19 x 19 and cropped to 4096^2
             try:

@@ -1009,6 +1009,9 @@ __device__ __forceinline__ void load_win(Win& w, const uint4* __restrict__ wins,
 #ifndef SW13
 #define SW13 4
 #endif
+#ifndef SWALL
+#define SWALL 4
+#endif
 #ifndef SW7
 #define SW7 3
 #endif
@@ -1148,7 +1151,7 @@ struct ScanTasks { int n; int kind[3]; };      // WK_SCAN02 / WK_SCAN13 / WK_SCA
 
 // FAM7 = false: the three-channel families {0,2} and {1,3} (4 waves per SIMD; ranked lists 3); FAM7 = true: the mode 7 scan
 // alone (four-channel fits need the registers of 3 waves per SIMD; sharing a kernel with the others made those spill).
-__host__ __device__ constexpr int scan_all_waves(bool ranked, bool fam7) { return fam7 ? (ranked ? SWR27 : SW7) : (ranked ? SWR2 : 4); }
+__host__ __device__ constexpr int scan_all_waves(bool ranked, bool fam7) { return fam7 ? (ranked ? SWR27 : SW7) : (ranked ? SWR2 : SWALL); }
 template <bool VEC16, bool RANKED_LISTS, bool FAM7>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(scan_all_waves(RANKED_LISTS, FAM7), scan_all_waves(RANKED_LISTS, FAM7))))
 bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint32_t* __restrict__ wins4,

@@ -23,8 +23,15 @@ def posterised(h, w, levels):
 
 def mixed_ldr(h, w):
     q = h // 4 // 4 * 4
-    parts = [surfaces.ldr_smooth(q, w, seed=surfaces.SEED + 31), rng.integers(0, 256, size=(q, w, 4), dtype=np.uint8),
+    parts = [surfaces.ldr_smooth(q, w, seed=surfaces.SEED + 31).copy(), rng.integers(0, 256, size=(q, w, 4), dtype=np.uint8),
              posterised(q, w, 4), posterised(h - 3 * q, w, 2)]
+    # alpha of the smooth quarter: real alpha | opaque | 254/255 speckles | per-block mix -- the RGBA profiles' order of
+    # mode groups and the skipped RGB scans (bc7_finish_all) see whole waves of each kind and mixed ones
+    a = parts[0][..., 3]
+    a[:, w // 4:w // 2] = 255
+    a[:, w // 2:3 * w // 4] = np.where(rng.random((q, w // 4)) < 0.06, 254, 255)
+    kinds = np.repeat(np.repeat(rng.integers(0, 3, (q // 4, w // 16)), 4, 0), 4, 1)
+    a[:, 3 * w // 4:] = np.select([kinds == 0, kinds == 1], [255, 254], a[:, 3 * w // 4:])
     return np.ascontiguousarray(np.concatenate(parts, axis=0))
 
 def mixed_hdr(h, w):
