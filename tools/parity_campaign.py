@@ -29,9 +29,9 @@ def mixed_ldr(h, w):
     # mode groups and the skipped RGB scans (bc7_finish_all) see whole waves of each kind and mixed ones
     a = parts[0][..., 3]
     a[:, w // 4:w // 2] = 255
-    a[:, w // 2:3 * w // 4] = np.where(rng.random((q, w // 4)) < 0.06, 254, 255)
+    a[:, w // 2:3 * w // 4] = np.where(rng.random((q, w // 4)) < 0.06, 254, 255).astype(np.uint8)
     kinds = np.repeat(np.repeat(rng.integers(0, 3, (q // 4, w // 16)), 4, 0), 4, 1)
-    a[:, 3 * w // 4:] = np.select([kinds == 0, kinds == 1], [255, 254], a[:, 3 * w // 4:])
+    a[:, 3 * w // 4:] = np.where(kinds == 0, 255, np.where(kinds == 1, 254, a[:, 3 * w // 4:])).astype(np.uint8)
     return np.ascontiguousarray(np.concatenate(parts, axis=0))
 
 def mixed_hdr(h, w):
