@@ -239,6 +239,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
                     help="default: strong when N > 1 (BASELINE configs[4]: one 16384^2 surface sharded over the ranks), else weak")
     ap.add_argument("--no-formats", action="store_true", help="skip the side measurements of the other formats")
+    ap.add_argument("--no-16k", action="store_true", help="skip the 16384^2 BC1/BC3 side figures (tools/profile_gpu.sh: keeps the "
+                    "per-kernel-name averages of rocprofv3 --stats those of the 4096^2 launches)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
@@ -426,6 +428,8 @@ def main():
             # BC1 / BC3 are the HBM-side kernels: the same kernel on the 16384^2 surface of configs[4], where the launch ramp and
             # tail (about 6 us) stop mattering -- the steady-state fraction of the HBM roofline
             try:
+                if args.no_16k:
+                    raise StopIteration
                 big = 16384
                 d2 = torch.from_numpy(make_surface("bc1", 4096, 0)).to(dev).repeat(big // 4096, big // 4096, 1).contiguous()   # I5 = I3 tiled
                 o2 = torch.empty((big // 4) ** 2 * 16, dtype=torch.uint8, device=dev)
@@ -436,6 +440,8 @@ def main():
                                            "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5)}
                 del d2, o2
                 torch.cuda.empty_cache()
+            except StopIteration:
+                pass
             except Exception as e:
                 side["@16384"] = {"error": repr(e)}
             # SURVEY 8(d) input I4 / BASELINE configs[3]: the reference's monkey-32bit.hdr (RGBE -> RGBA16F, committed as a

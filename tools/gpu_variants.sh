@@ -1,3 +1,6 @@
+# A/B of kernel build variants on the GPU box: every gpurun_variants/lib_<name>.so (built in the container, e.g.
+#   hipcc <Makefile FLAGS> -DSWALL=2 -c csrc/bc7.hip -o /tmp/bc7_sw2.o && hipcc --offload-arch=gfx950 -shared -fPIC -o gpurun_variants/lib_sw2.so /tmp/bc7_sw2.o <the other build/*.o>
+# ) replaces the library in turn; prints the preset table rows.  Used for DESIGN.md 3.2: scan at 4 / 3 / 2 waves per SIMD.
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/variants
 L=intel-texture-works-plugin_amd/lib/libispc_texcomp.so

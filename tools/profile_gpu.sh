@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- p
 find $OUT/trace -name '*kernel_stats*.csv' -exec cp {} $OUT/kernel_stats.csv \;
 find $OUT/trace -name '*kernel_trace*.csv' | head -1 | xargs -I{} sh -c "head -1 {} > $OUT/kernel_trace_head.csv; grep -m10 bc7_ {} >> $OUT/kernel_trace_head.csv"
 rm -rf $OUT/trace
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py --no-cpu > $OUT/bench_all_formats_under_rocprof.json 2> $OUT/trace_all.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $ROOT/bench.py --no-cpu --no-16k > $OUT/bench_all_formats_under_rocprof.json 2> $OUT/trace_all.log
 find $OUT/trace -name '*kernel_stats*.csv' -exec cp {} $OUT/kernel_stats_all_formats.csv \;
 find $OUT/trace -name '*kernel_trace*.csv' | head -1 | xargs -I{} sh -c "grep -m3 bc13_kernel {} >> $OUT/kernel_trace_head.csv; grep -m3 bc6h_ {} >> $OUT/kernel_trace_head.csv; grep -m3 bc45_ {} >> $OUT/kernel_trace_head.csv"
 rm -rf $OUT/trace
