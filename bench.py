@@ -123,23 +123,39 @@ def time_kernel(itw, fmt, prof, d_img, d_out, steps, warmup, back_to_back=False)
     return float(np.mean(ts)), float(np.min(ts))
 
 
-def cpu_baseline(fmt, prof, img, budget_s=15.0):
-    """Oracle on host cores, bounded sample of the same surface: grow the band until ~budget_s of CPU work."""
+def _cpu_encoder():
+    """(encode_mt, kind, description) of the CPU leg: the reference's own kernel.ispc built as a scalar program
+    (oracle/_ref/libispc_texcomp_ref_full.so, oracle/ref_build/ispc_as_cpp/: kind "reference") when that prebuilt library
+    is there, else the oracle's C restatement (kind "port").  Same algorithm, same bytes, both scalar -- neither is ISPC SIMD."""
     from oracle import pyoracle            # checker / baseline leg only
     pyoracle.build()
+    try:
+        from oracle import pyref
+        if pyref.available():
+            pyref.lib()
+            return pyref.encode_mt, "reference", "the reference's kernel.ispc compiled as ONE scalar program instance (clang -O2, no ispc: not ISPC SIMD)"
+    except OSError:
+        pass
+    return pyoracle.encode_mt, "port", "scalar C oracle (not ISPC SIMD)"
+
+
+def cpu_baseline(fmt, prof, img, budget_s=15.0):
+    """CPU path on host cores, bounded sample of the same surface: grow the band until ~budget_s of CPU work."""
+    from oracle import pyoracle            # checker / baseline leg only
+    encode_mt, kind, what = _cpu_encoder()
     cores = pyoracle.usable_cores()           # honours the cgroup CPU quota of the box
     h, w = img.shape[:2]
     rows = min(h, max(4 * cores, 16))
-    pyoracle.encode_mt(fmt, img[:rows], prof, threads=cores)          # warm the thread pool / caches
+    encode_mt(fmt, img[:rows], prof, threads=cores)          # warm the thread pool / caches
     t0 = time.perf_counter()
-    pyoracle.encode_mt(fmt, img[:rows], prof, threads=cores)
+    encode_mt(fmt, img[:rows], prof, threads=cores)
     dt = time.perf_counter() - t0
     if dt < budget_s / 4 and rows < h:                                 # grow the band towards the budget
         rows = int(min(h, max(rows, rows * (budget_s * 0.8) / max(dt, 1e-3)))) // 4 * 4
     reps, dt = 0, 0.0
     t0 = time.perf_counter()
     while dt < min(budget_s, 5.0) or reps == 0:                        # short formats: repeat the sample
-        pyoracle.encode_mt(fmt, img[:rows], prof, threads=cores)
+        encode_mt(fmt, img[:rows], prof, threads=cores)
         reps += 1
         dt = time.perf_counter() - t0
         if dt > budget_s:
@@ -153,29 +169,30 @@ def cpu_baseline(fmt, prof, img, budget_s=15.0):
                 break
     except OSError:
         pass
-    return {"value": round(rows * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": "port",
+    return {"value": round(rows * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": cores, "kind": kind,
             "sample": f"first {rows} of {h} texel rows of the same {w}x{h} surface, {reps} x {dt:.3f} s, "
-                      f"scalar C oracle (not ISPC SIMD), {cores} threads (= usable cores: min of cpu_count "
+                      f"{what}, {cores} threads (= usable cores: min of cpu_count "
                       f"{os.cpu_count()}, affinity, cgroup quota), reference band rule; cpu: {model}"}
 
 
 def cpu_baseline_pair(fmt, prof, img, budget_s=2.0):
-    """Mpixels/s of the scalar C oracle on a small sample, 1 thread and all usable threads (side formats)."""
+    """Mpixels/s of the CPU path (see _cpu_encoder) on a small sample, 1 thread and all usable threads (side formats)."""
     from oracle import pyoracle            # checker / baseline leg only
+    encode_mt, kind, what = _cpu_encoder()
     cores = pyoracle.usable_cores()
     h, w = img.shape[:2]
-    out = {"unit": "Mpixels/s", "kind": "port", "cores": cores}
+    out = {"unit": "Mpixels/s", "kind": kind, "cores": cores}
     for label, n in (("threads_1", 1), ("threads_all", cores)):
         rows = min(h, max(4 * n, 16))
         t0 = time.perf_counter()
-        pyoracle.encode_mt(fmt, img[:rows], prof, threads=n)
+        encode_mt(fmt, img[:rows], prof, threads=n)
         dt = max(time.perf_counter() - t0, 1e-4)
         rows = int(min(h, max(rows, rows * budget_s / dt))) // 4 * 4
         t0 = time.perf_counter()
-        pyoracle.encode_mt(fmt, img[:rows], prof, threads=n)
+        encode_mt(fmt, img[:rows], prof, threads=n)
         dt = time.perf_counter() - t0
         out[label] = round(rows * w / dt / 1e6, 3)
-    out["sample"] = f"up to {h} rows of a {w}-wide synthetic surface, ~{budget_s:.0f} s per leg, scalar C oracle (not ISPC SIMD)"
+    out["sample"] = f"up to {h} rows of a {w}-wide synthetic surface, ~{budget_s:.0f} s per leg, {what}"
     return out
 
 

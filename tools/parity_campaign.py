@@ -1,8 +1,9 @@
 """Large GPU-vs-oracle parity campaign (run on the GPU box): every format / profile on several megapixels of mixed
 content -- smooth + noise, uniform random bytes, posterised (tie-heavy), real alpha, adversarial half bits -- compared
 bit for bit with the multi-threaded scalar oracle.  Prints one line per case and a summary; exit code 1 on any mismatch.
-Usage: python tools/parity_campaign.py [megapixels_per_case]   (default 2; the oracle needs ~1 s per Mpix of BC7 slow
-on 16 cores)."""
+Usage: python tools/parity_campaign.py [megapixels_per_case] [oracle|ref]   (default 2, oracle; the oracle needs ~1 s per
+Mpix of BC7 slow on 16 cores).  `ref`: the checker is the reference's own kernel.ispc built as a scalar program
+(oracle/_ref/libispc_texcomp_ref_full.so) instead of the oracle's restatement; BC4/BC5, which kernel.ispc does not have, stay on the oracle."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "intel-texture-works-plugin_amd"))
@@ -12,6 +13,9 @@ from itw_amd import surfaces
 from oracle import pyoracle          # checker
 
 mp = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
+CHECKER = sys.argv[2] if len(sys.argv) > 2 else "oracle"
+if CHECKER == "ref":
+    from oracle import pyref
 W = 2048
 H = max(4, int(mp * 1e6 / W) // 4 * 4)
 rng = np.random.default_rng(2026)
@@ -51,12 +55,13 @@ for fmt, prof in cases:
     torch.cuda.synchronize()
     got = got.cpu().numpy()
     t1 = time.perf_counter()
-    want = pyoracle.encode_mt(fmt, img, prof).reshape(-1)
+    use_ref = CHECKER == "ref" and fmt not in ("bc4", "bc5")
+    want = (pyref.encode_mt(fmt, img, prof) if use_ref else pyoracle.encode_mt(fmt, img, prof)).reshape(-1)
     t2 = time.perf_counter()
     bpb = itw_amd.BYTES_PER_BLOCK[fmt]
     bad = int((got.reshape(-1, bpb) != want.reshape(-1, bpb)).any(axis=1).sum())
     n = got.size // bpb
     bad_total += bad; blocks_total += n
-    print(f"{fmt:5s} {prof or '-':16s} {n:8d} blocks  mismatches {bad:6d}   gpu {1e3*(t1-t0):8.1f} ms  oracle {t2-t1:6.1f} s", flush=True)
-print(f"TOTAL {blocks_total} blocks, {bad_total} mismatches")
+    print(f"{fmt:5s} {prof or '-':16s} {n:8d} blocks  mismatches {bad:6d}   gpu {1e3*(t1-t0):8.1f} ms  {'kernel.ispc' if use_ref else 'oracle'} {t2-t1:6.1f} s", flush=True)
+print(f"TOTAL {blocks_total} blocks, {bad_total} mismatches (checker: {'the reference kernel.ispc, scalar build' if CHECKER == 'ref' else 'oracle'})")
 sys.exit(1 if bad_total else 0)
