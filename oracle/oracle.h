@@ -10,8 +10,12 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use
  * this library.  The product (libispc_texcomp.so) never links or calls it.
  *
- * PARITY UNPINNED: the reference ships no golden outputs and cannot be built
- * here (needs the ispc compiler).  See x86_math.h / DESIGN.md.
+ * PARITY: the reference ships no golden outputs and its ispc build cannot be made
+ * here; pinned instead by the reference's kernel.ispc compiled as ONE scalar program
+ * instance (oracle/ref_build/ispc_as_cpp/, oracle/_ref/libispc_texcomp_ref_full.so):
+ * byte-identical to this restatement on every golden input, preset, random settings
+ * struct and both arithmetic-model switches (tests/test_reference_kernel_source.py).
+ * Assumed, not pinned: the ispc compiler / stdlib semantics (x86_math.h S2-S6).
  *
  * Symbols carry an oracle_ prefix so both libraries can live in one process.
  */

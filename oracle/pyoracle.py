@@ -4,8 +4,10 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this
 module.  It is the checker, never the product: the product library
 (libispc_texcomp.so) has no dependency on anything in oracle/.
 
-PARITY UNPINNED by the reference (no golden outputs exist upstream, ispc is not
-installable here); see oracle/x86_math.h and DESIGN.md.
+Parity status: no golden outputs exist upstream and ispc is not installable here; the
+restatement is pinned by the reference's own kernel.ispc built as a scalar program
+(oracle/pyref.py, tests/test_reference_kernel_source.py); the ispc compiler / stdlib
+semantics stay assumed (oracle/x86_math.h).
 """
 import ctypes as C
 import os

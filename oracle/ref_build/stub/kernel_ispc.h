@@ -6,7 +6,8 @@
  * own translation unit /root/reference/3rdParty/Intel/Source/ispc_texcomp.cpp:18,417-440 needs from it: the
  * `ispc::` struct names it casts to and the five exported kernel entry points (kernel.ispc:598, 607, 2030, 3132,
  * 3683), with C linkage as ISPC emits them.  With this on the include path the reference's ispc_texcomp.cpp compiles
- * UNMODIFIED from where it lies; the entry points are supplied by kernel_entry_glue.c (-> the oracle's restatement).
+ * UNMODIFIED from where it lies; the entry points are supplied by kernel_entry_glue.c (-> the oracle's restatement:
+ * libispc_texcomp_ref.so) or by kernel.ispc itself built as a scalar program (ispc_as_cpp/: libispc_texcomp_ref_full.so).
  */
 #pragma once
 #include <stdint.h>

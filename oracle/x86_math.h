@@ -16,9 +16,13 @@
  *  S5  (int)f = cvttps2dq: truncate; NaN / out of range -> INT_MIN.
  *  S6  min/max = minps/maxps: (a<b)?a:b / (a>b)?a:b  (returns b on NaN).
  *
- * PARITY UNPINNED BY THE REFERENCE: /root/reference holds no golden outputs and
- * ispc is not installable here, so this model (not an ISPC binary) defines
- * "bit-exact" for the project.  See DESIGN.md section "Oracle".
+ * PARITY STATUS: /root/reference holds no golden outputs and ispc is not installable
+ * here, so this model (not an ISPC binary) defines "bit-exact" for the project.  The
+ * ALGORITHM built on it is pinned: the reference's kernel.ispc, compiled as one scalar
+ * program instance over these same functions (oracle/ref_build/ispc_as_cpp/ ->
+ * oracle/_ref/libispc_texcomp_ref_full.so), emits the oracle's bytes
+ * (tests/test_reference_kernel_source.py).  What stays an assumption is S2-S6 itself:
+ * what the ispc compiler and its stdlib do.  See DESIGN.md section 5.
  */
 #ifndef ORACLE_X86_MATH_H
 #define ORACLE_X86_MATH_H

@@ -7,7 +7,7 @@ repo):
   * win32Threads.cpp:192-329 -> the reference's own CompressImageMT/ST + 17 trampolines (through a pthread Win32 shim)
                                 driving the product library with host pointers: "the plugin calls the ABI unchanged"
 
-kernel.ispc cannot be compiled (no ispc): the kernel arithmetic stays pinned by the oracle only.
+kernel.ispc itself is covered by tests/test_reference_kernel_source.py (built as one scalar program instance).
 """
 import ctypes as C
 import os

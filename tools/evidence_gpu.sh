@@ -7,6 +7,7 @@ OUT=gpurun_out/evidence_$TAG; mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -2 $OUT/pytest_gpu.log
 timeout 900 python tools/parity_campaign.py 2 > $OUT/parity_campaign_2Mpix_wide.txt 2>&1; tail -1 $OUT/parity_campaign_2Mpix_wide.txt
 timeout 1800 python tools/parity_campaign.py 16 > $OUT/parity_campaign_16Mpix_fused.txt 2>&1; tail -1 $OUT/parity_campaign_16Mpix_fused.txt
+timeout 1800 python tools/parity_campaign.py 4 ref > $OUT/parity_campaign_4Mpix_vs_reference_kernel.txt 2>&1; tail -1 $OUT/parity_campaign_4Mpix_vs_reference_kernel.txt
 timeout 600 python tools/profile_table.py 2>&1 | grep -v amdgpu > $OUT/preset_table.txt
 timeout 600 python tools/bc7_path_probe.py slow,basic,alpha_basic,veryfast,alpha_slow 2>&1 | grep -v amdgpu > $OUT/bc7_path_probe.txt
 timeout 600 python tools/bc7_path_probe.py slow,veryslow bc6h 2>&1 | grep -v amdgpu > $OUT/bc6h_path_probe.txt
