@@ -469,12 +469,16 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
         if (M.pairs == 2) sg[2] = sg[1];
         uint32_t qb[2];
         const int32_t err = select_block<M.bits, M.ch, M.pairs>(qb, ln.tx, sg, sh.pattern);
-        if (err < w.err) {
+        const bool better = err < w.err;
+        if (better) {
             #pragma unroll
             for (int j = 0; j < M.pairs; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) cq[j][i][p] = q[j][i][p];
             wqb[0] = qb[0]; wqb[1] = qb[1];
             w.err = err;
         }
+        // an iteration is a function of the kept indices alone (kernel.ispc:1331-1356): one that improves nothing leaves them
+        // as they were, so every later one repeats it.  Once that holds for all 64 blocks of the wave the rest is skipped.
+        if (__all(!better)) break;
     }
     int32_t err = w.err;
     if (MODE != 7) err += ln.opaque_err;
@@ -758,6 +762,7 @@ __device__ __forceinline__ int32_t encode_scalar(uint32_t (&qb)[2], int32_t (&qe
     for (int k = 0; k < 16; k++) { const int32_t v = (int32_t)((tx.w[k] >> shift) & 255u); lo = min(lo, v); hi = max(hi, v); }
     float ep[2] = {(float)lo, (float)hi};
     int32_t err = 0;
+    uint32_t pqb0 = 0, pqb1 = 0;
     for (int round = 0; ; round++) {
         int32_t de[2];
         #pragma unroll
@@ -803,6 +808,10 @@ __device__ __forceinline__ int32_t encode_scalar(uint32_t (&qb)[2], int32_t (&qe
         }
         err = (int32_t)errf;
         if (round >= iters) break;
+        // the next round's endpoints are a function of these indices (channel_opt_endpoints): if they repeat the previous
+        // round's for every block of the wave, all further rounds repeat this one
+        if (__all(round > 0 && qb[0] == pqb0 && qb[1] == pqb1)) break;
+        pqb0 = qb[0]; pqb1 = qb[1];
         const uint32_t qn[4] = {qb[0] & 0x0f0f0f0fu, (qb[0] >> 4) & 0x0f0f0f0fu, qb[1] & 0x0f0f0f0fu, (qb[1] >> 4) & 0x0f0f0f0fu};
         uint32_t sq_ = 0, sqq = 0, ssum = 0, satb = 0;                           // channel_opt_endpoints
 #pragma unroll
@@ -846,10 +855,14 @@ __device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const La
     for (int it = 0; it < iters; it++) {
         float ep[2][4];
         ep[0][3] = 0.f; ep[1][3] = 0.f;
+        const uint32_t was0 = qb[0], was1 = qb[1];
         refit_line<BITS, 3>(ep, rot.pl, qb, all, ln.T);
         quant_mode<MODE, false>(q, d, ep, 3);
         ps = build_palette<BITS, 3, TPB>(ln.pal, d);
         err = select_block_pal<BITS, 3, TPB>(qb, rot, ps, ln.pal, tt);
+        // the iteration maps indices to (endpoints, indices, error) (kernel.ispc:1598-1603): unchanged indices are a fixed
+        // point, further iterations reproduce exactly these values
+        if (__all(qb[0] == was0 && qb[1] == was1)) break;
     }
 
     int32_t aq[2];
@@ -955,10 +968,12 @@ __device__ __forceinline__ void mode_6(Lane& ln, const bc7_enc_settings& S)
     int32_t err = select_block<4, CH, 1>(qb, ln.tx, sg, 0u);
     const int iters = S.refineIterations[6];
     for (int it = 0; it < iters; it++) {
+        const uint32_t was0 = qb[0], was1 = qb[1];
         refit_line<4, CH>(ep, ln.tx.pl, qb, all, ln.T);
         quant_mode<6, false>(q, d, ep, CH);
         sg[0] = make_segment<4, CH>(d);
         err = select_block<4, CH, 1>(qb, ln.tx, sg, 0u);
+        if (__all(qb[0] == was0 && qb[1] == was1)) break;         // fixed point of the iteration (kernel.ispc:1672-1677)
     }
     if (err < ln.best_err) {
         ln.best_err = err;
