@@ -134,6 +134,24 @@ def test_reference_dispatch_over_reference_tu_equals_one_oracle_call(oracle, tmp
         assert first_mismatch(got, want, bpb) is None, (mode, first_mismatch(got, want, bpb))
 
 
+@pytest.mark.parametrize("tramp,fmt,prof,h,w,workers", [
+    ("BC3", "bc3", None, 200, 128, 5),
+    ("BC7_alpha_basic", "bc7", "alpha_basic", 100, 64, 3),
+    ("BC7_slow", "bc7", "slow", 64, 64, 64),
+    ("BC6H_slow", "bc6h", "slow", 64, 48, 4),
+])
+def test_the_all_reference_stack_equals_the_oracle(oracle, tmp_path, tramp, fmt, prof, h, w, workers):
+    """ref_threads_caller_ref: the reference's win32Threads.cpp (trampolines, CompressImageMT/ST) over its ispc_texcomp.cpp
+    (presets, ABI wrappers) over its kernel.ispc built as a scalar program -- no line of encoder code in that executable
+    is ours -- emits the bytes of one whole-surface oracle call."""
+    exe = _ensure_ref("ref_threads_caller_ref")
+    img = _surface(fmt, h, w)
+    want = oracle.encode(fmt, img, prof).reshape(-1)
+    for mode in ("mt", "st"):
+        got, _ = _run_threads_caller(exe, mode, tramp, img, tmp_path, workers)
+        assert first_mismatch(got, want, 8 if fmt == "bc1" else 16) is None, (mode, first_mismatch(got, want, 8 if fmt == "bc1" else 16))
+
+
 # ---------------------------------------------------------------------------- the same reference-built callers on the GPU
 
 @pytest.mark.gpu
