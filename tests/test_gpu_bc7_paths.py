@@ -219,3 +219,23 @@ def test_alpha_first_order_and_skipped_rgb_modes(itw, gpu, paths, oracle, prof):
         assert first_mismatch(got, want, 16) is None, (path, first_mismatch(got, want, 16))
     modes = np.array([int(b[0]).bit_length() and (int(b[0]) & -int(b[0])).bit_length() - 1 for b in want.reshape(-1, 16)])
     assert (modes <= 3).any() and (modes >= 4).any()          # both groups of modes win somewhere
+
+
+@pytest.mark.parametrize("prof", ["slow", "alpha_basic", "alpha_slow"])
+def test_unaligned_device_surfaces_take_the_dword_kernels(itw, gpu, paths, oracle, prof):
+    """Base pointer 12 bytes past a 16-byte boundary, rows 1 168 bytes apart (rgba_surface.stride is free): the VEC16 = false
+    instantiations of every scan / finish kernel, both launch shapes, incl. the two-phase RGBA order."""
+    import torch
+    from itw_amd import surfaces
+    img = surfaces.ldr_smooth(64, 256, seed=surfaces.SEED + 33).copy()
+    img[:, 128:, 3] = 255                                      # a translucent and an opaque half: skipped and unskipped waves
+    big = torch.zeros((64, 292, 4), dtype=torch.uint8, device=gpu)
+    big[:, 3:259] = torch.from_numpy(img).to(gpu)
+    view = big[:, 3:259]
+    assert view.data_ptr() % 16 == 12 and view.stride(0) == 1168
+    want = oracle.encode_mt("bc7", img, prof)
+    for path in ("deep", "wide"):
+        paths(path)
+        got = itw.compress("bc7", view, prof)
+        torch.cuda.synchronize()
+        assert first_mismatch(got.cpu().numpy(), want, 16) is None, (path, first_mismatch(got.cpu().numpy(), want, 16))
