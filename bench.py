@@ -17,12 +17,19 @@ N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-
                    strong-sharded: rank r encodes band r of the N bands, the output bands are all-gathered over xGMI
                    ("scaling": "strong"; --size 16384 --scaling strong at N = 1 runs the whole surface on one GPU).
                    A short weak-scaling figure (one 4096^2 band per rank) rides along as `weak_side`.
+                   After the timed region the gathered image is CHECKED (`gather_verified`): every rank re-encodes its own
+                   band and two other ranks' bands of the same seeded surface into fresh buffers and compares them byte for
+                   byte with what the all-gather delivered; `per_rank_kernel_ms` shows load imbalance.  Collectives carry a
+                   timeout (ITW_BENCH_DIST_TIMEOUT_S, default 300 s) and the whole run a watchdog (ITW_BENCH_WATCHDOG_S,
+                   default 1500 s): a rank mismatch ends in an error, not in a hang.
   --scaling weak   rank r owns band r of a size x (size*N) surface: per-GPU work fixed.
 
 cpu_baseline: the scalar C oracle (oracle/, test infrastructure) timed on this box's host cores on a bounded sample,
 rank 0, N=1 only.  It is a *port* (scalar restatement), not ISPC SIMD code: the reference cannot be built here.
 """
 import argparse
+import datetime
+import faulthandler
 import json
 import os
 import sys
@@ -38,6 +45,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_TOPS = 78.6          # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, separate mul/add (contract=off => no FMA credit)
+VALU_PEAK_FMA_TFLOPS = 157.3   # the guide's fp32 vector peak: the same issue rate with FMA / packed-fp32 credit (2 flops per lane-op)
 
 # algorithmic bytes per 4x4 block: texels read + block written
 ALG_BYTES = {"bc1": 64 + 8, "bc3": 64 + 16, "bc7": 64 + 16, "bc6h": 128 + 16, "bc4": 64 + 8, "bc5": 64 + 16}
@@ -82,6 +90,51 @@ def make_band(fmt, scaling, size, geo, rank):
     rows = (np.arange(geo["y0"], geo["y0"] + geo["rows"]) % 4096)
     cols = (np.arange(geo["width"]) % 4096)
     return np.ascontiguousarray(base[rows][:, cols])
+
+
+def fake_blocks(fmt, img):
+    """Stand-in "encoder" of the CPU control-flow test: every block's stream bytes = the bytes of its top-left texel, tiled.
+    A deterministic function of the texels, so the gather verification has something real to compare."""
+    from itw_amd import abi
+    bpb = abi.BYTES_PER_BLOCK[fmt]
+    tl = np.ascontiguousarray(img[0::4, 0::4]).reshape(-1, img.shape[2] * img.itemsize).view(np.uint8)
+    reps = -(-bpb // tl.shape[1])
+    return np.ascontiguousarray(np.tile(tl, (1, reps))[:, :bpb]).reshape(-1)
+
+
+def make_encoder(itw, fmt, prof, img, dev):
+    """(encode_into(out_band), device texels or None) for one band of texels."""
+    if FAKE:
+        blocks = torch.from_numpy(fake_blocks(fmt, img))
+        return (lambda out: out.copy_(blocks)), None
+    d_img = torch.from_numpy(img).to(dev)
+    return (lambda out: itw.compress(fmt, d_img, prof, out=out)), d_img
+
+
+def verify_gather(itw, dist, full, scaling, size, world, rank, fmt, prof, dev):
+    """Correctness of the N > 1 job, after the timed region: `full` is the whole-image stream the last step's all-gather
+    left on this rank.  This rank re-encodes (a) its own band -- it must have survived the in-place gather -- and (b) the
+    bands of ranks rank+1 and rank+N/2 (so every band is checked by up to three different ranks) from the same seeded
+    surface into FRESH buffers and compares them with the gathered bytes.  Returns the job-wide verdict (all ranks agree)."""
+    targets = []
+    for r in (rank, (rank + 1) % world, (rank + world // 2) % world):
+        if r not in targets:
+            targets.append(r)
+    bad_bytes = 0
+    for r in targets:
+        g = plan(scaling, size, world, r, fmt)
+        enc, keep = make_encoder(itw, fmt, prof, make_band(fmt, scaling, size, g, r), dev)
+        ref = torch.empty(g["band_bytes"], dtype=torch.uint8, device=dev)
+        enc(ref)
+        _sync()
+        bad_bytes += int((ref != full[g["band_off"]:g["band_off"] + g["band_bytes"]]).sum().item())
+        del ref, keep, enc
+    t = torch.tensor([bad_bytes, len(targets)], dtype=torch.int64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return {"gather_verified": int(t[0].item()) == 0, "mismatching_bytes": int(t[0].item()), "band_checks": int(t[1].item()),
+            "how": "every rank re-encoded its own band and the bands of ranks r+1 and r+N/2 of the same seeded surface into "
+                   "fresh buffers and compared them byte for byte with the all-gathered stream of the last timed step"}
 
 
 # ITW_BENCH_CONTROL_FLOW_TEST=1: no GPU, gloo instead of RCCL, the encode replaced by a memset.  NOT a measurement: it exists
@@ -197,18 +250,28 @@ def cpu_baseline_pair(fmt, prof, img, budget_s=2.0):
 
 
 def pmc_valu(workload):
-    """VALU wave-instructions per C-ABI call from a committed rocprofv3 SQ pass (profiles/*_valu.json), if present."""
-    if workload != "bc7_slow":
-        return None
+    """VALU wave-instructions per C-ABI call at 4096^2 from the latest committed rocprofv3 SQ pass: profiles/*_valu_by_workload.json
+    (one entry per workload, tools/profile_gpu.sh) or, for bc7_slow, the older profiles/*_valu.json."""
     best = None
     try:
         for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-            if name.endswith("_valu.json"):
+            if name.endswith("_valu_by_workload.json"):
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    v = json.load(f).get(workload, {}).get("SQ_INSTS_VALU")
+                best = v if v else best
+            elif name.endswith("_valu.json") and workload == "bc7_slow" and best is None:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     best = json.load(f).get("SQ_INSTS_VALU")
-    except (OSError, ValueError):
+    except (OSError, ValueError, AttributeError):
         return None
     return best
+
+
+def valu_block(insts, kernel_ms):
+    """The roofline that binds: executed VALU wave-instructions x 64 lanes / kernel time against the 2-cycle-issue peak."""
+    lane_ops = insts * 64 / (kernel_ms * 1e-3) / 1e12
+    return {"achieved": round(lane_ops, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": round(lane_ops / VALU_PEAK_TOPS, 4),
+            "wave_instructions_per_call": int(insts)}
 
 
 def op_counts(workload):
@@ -286,14 +349,19 @@ def main():
         dev = torch.device("cuda", local_rank)
         torch.cuda.set_device(dev)
 
+    # a hang must end in an error the driver can read, not in its 1800 s limit: watchdog for the whole run, timeout on collectives
+    faulthandler.dump_traceback_later(int(os.environ.get("ITW_BENCH_WATCHDOG_S", "1500")), exit=True)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")     # a failed / timed-out collective tears the process down
+        os.environ.setdefault("NCCL_ASYNC_ERROR_HANDLING", "1")
+        tmo = datetime.timedelta(seconds=int(os.environ.get("ITW_BENCH_DIST_TIMEOUT_S", "300")))
         if FAKE:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
 
     fmt, prof = WORKLOADS[args.workload]
     heavy = fmt in ("bc7", "bc6h")
@@ -311,11 +379,17 @@ def main():
         geo = plan(scaling, size, world, rank, fmt)
         img = make_band(fmt, scaling, size, geo, rank)
         assert img.shape[0] == geo["rows"] and img.shape[1] == geo["width"]
-        d_img = torch.from_numpy(img).to(dev)
         equal = geo["band_bytes"] * world == geo["total_bytes"]
         assert equal, "bench bands must be equal (in-place all-gather): pick a size whose block rows divide by N"
         assert geo["band_off"] == rank * geo["band_bytes"]
-        encode_into = (lambda out: out.zero_()) if FAKE else (lambda out: itw_amd.compress(fmt, d_img, prof, out=out))
+        encode_into, d_img = make_encoder(itw_amd, fmt, prof, img, dev)
+        if os.environ.get("ITW_BENCH_CORRUPT_RANK") == str(rank):
+            # test hook (tests/test_sharding_gloo.py): this rank damages its band after encoding it -- the verification must see it
+            clean = encode_into
+
+            def encode_into(out):
+                clean(out)
+                out[:1] ^= 0xFF
         pipe = shard.BandPipeline(geo["band_bytes"], world, rank, dev, encode_into)
         for _ in range(warmup):
             pipe.step()
@@ -342,8 +416,19 @@ def main():
     d_band = pipe.band[0]
     nblocks = (geo["width"] // 4) * (geo["rows"] // 4)          # blocks this rank encodes per step
 
+    # N > 1: is the gathered image the image?  (after the timed region; never inside it)
+    verdict = None
+    if world > 1:
+        verdict = verify_gather(itw_amd, dist, pipe.full[(pipe.steps - 1) % pipe.depth], scaling, size, world, rank, fmt, prof, dev)
+
     # kernel-only duration on the launch stream (HIP events), for the roofline
     k_avg_ms, k_min_ms = time_kernel(itw_amd, fmt, prof, d_img, d_band, steps=max(3, min(steps, 20)), warmup=1)
+    per_rank_ms = [round(k_avg_ms, 4)]
+    if dist is not None:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = k_avg_ms
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(v), 4) for v in t.tolist()]
 
     result = None
     if rank == 0:
@@ -375,6 +460,9 @@ def main():
                          "note": "BC7/BC6H are VALU-issue bound (no MFMA-shaped work); the HBM fraction is reported "
                                  "because the contract asks for it; `valu` is the roofline that binds (DESIGN.md 3)"},
         }
+        if verdict is not None:
+            result.update(verdict)
+            result["per_rank_kernel_ms"] = per_rank_ms
         rk = rocprof_kernels(fmt)
         if rk and world == 1 and size == 4096 and scaling == "weak":
             # the call is several kernels for BC7; `achieved` uses the whole call.  For the slow / alpha_slow profiles the
@@ -382,13 +470,11 @@ def main():
             result["roofline"]["rocprof_kernels"] = rk
         insts = pmc_valu(args.workload)
         if insts and world == 1 and size == 4096 and scaling == "weak":
-            lane_ops = insts * 64 / (k_avg_ms * 1e-3) / 1e12
-            result["roofline"]["valu"] = {
-                "achieved": round(lane_ops, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": round(lane_ops / VALU_PEAK_TOPS, 4),
-                "wave_instructions_per_call": int(insts),
-                "note": "SQ_INSTS_VALU of one call (committed rocprofv3 pass) x 64 lanes / live kernel time; peak = 256 CU x 4 SIMD "
-                        "x 32 lanes x 2.4 GHz, reached only by the 2-cycle VOP2 forms (v_mul/add_f32, v_add_u32, logic, shifts right); "
-                        "cvt / cmp / fma / packed / dot forms issue at half that rate (tools/ubench)"}
+            result["roofline"]["valu"] = valu_block(insts, k_avg_ms)
+            result["roofline"]["valu"]["note"] = (
+                "SQ_INSTS_VALU of one call (committed rocprofv3 pass) x 64 lanes / live kernel time; peak = 256 CU x 4 SIMD "
+                "x 32 lanes x 2.4 GHz, reached only by the 2-cycle VOP2 forms (v_mul/add_f32, v_add_u32, logic, shifts right); "
+                "cvt / cmp / fma / packed / dot forms issue at half that rate (tools/ubench)")
 
     if rank == 0:
         per_block, method = op_counts(args.workload)
@@ -397,14 +483,19 @@ def main():
             blocks_all = (geo["width"] // 4) * (geo["height"] // 4)
             arith, full = per_block.get("fp32_arith_ops", 0.0), per_block.get("fp32_arith_cmp_cvt_ops", 0.0)
             t = elapsed / steps
-            result["roofline"]["valu_algorithmic"] = {
-                "fp32_arith_ops_per_block": arith, "fp32_arith_cmp_cvt_ops_per_block": full,
-                "achieved_T_ops_s": round(full * blocks_all / t / 1e12, 2), "peak_T_lane_ops_s": VALU_PEAK_TOPS * world,
-                "frac": round(full * blocks_all / t / 1e12 / (VALU_PEAK_TOPS * world), 4),
-                "note": "reference algorithm's fp32 mul/add/div/sqrt + compares + conversions per block, counted by single-stepping the "
-                        "CPU oracle (profiles/op_counts.json), x blocks / measured step time / (256 CU x 128 lanes x 2.4 GHz per GPU, "
-                        "no FMA credit).  Below the executed-instruction figure where the kernels replace fp32 work by exact packed-"
-                        "integer forms (dot4: 4+ reference ops per instruction), above it where they cannot."}
+            ref_rate = full * blocks_all / t / 1e12
+            va = {"fp32_arith_ops_per_block": arith, "fp32_arith_cmp_cvt_ops_per_block": full,
+                  "reference_T_ops_s": round(ref_rate, 2), "peak_T_flops_s": VALU_PEAK_FMA_TFLOPS * world,
+                  "frac_of_fma_peak": round(ref_rate / (VALU_PEAK_FMA_TFLOPS * world), 4),
+                  "note": "NOT a roofline of this implementation: the reference algorithm's scalar fp32 operations per block (mul/add/"
+                          "div/sqrt + compares + conversions, counted by single-stepping the CPU oracle, profiles/op_counts.json) x blocks "
+                          "/ measured step time, against the chip's fp32 vector peak WITH FMA / packed credit (157.3 TFLOP/s per GPU: "
+                          "one lane-op = up to 2 flops).  The kernels retire several reference ops per executed lane-op (a v_dot4 "
+                          "= 7, a v_pk_fma_f32 = 4): `reference_ops_per_executed_lane_op` is that ratio; `roofline.valu` is the "
+                          "roofline that binds."}
+            if insts and world == 1 and size == 4096 and scaling == "weak":
+                va["reference_ops_per_executed_lane_op"] = round(full * blocks_all / (insts * 64), 3)
+            result["roofline"]["valu_algorithmic"] = va
 
     if world > 1 and scaling == "strong":
         # side figure: weak scaling, one 4096^2 band per rank (what round 1 reported); a few steps only
@@ -437,8 +528,22 @@ def main():
                 side[wl] = {"Mpixels/s": round(size * size / (avg * 1e-3) / 1e6, 1), "kernel_ms_avg": round(avg, 4),
                             "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5),
                             "traffic": pmc_traffic(wl)}
+                i2 = pmc_valu(wl)
+                if i2:                                         # the binding roofline of every format (SURVEY 8d asks for both)
+                    side[wl]["valu"] = valu_block(i2, avg)
                 if light:
                     side[wl]["timing"] = "one HIP event pair around 200 back-to-back launches"
+                if wl == "bc7_alpha_slow":
+                    # the RGBA profiles' cost depends on the alpha channel (alpha-group-first order): the synthetic
+                    # surface's alpha is translucent everywhere (best case); the same RGB with opaque and per-block mixed alpha
+                    side[wl]["content"] = "alpha translucent in every block (survey input I3): RGB modes are skipped almost everywhere"
+                    from itw_amd import surfaces
+                    for kind in ("opaque", "mixed"):
+                        d3 = torch.from_numpy(surfaces.ldr_alpha_variant(im2, kind)).to(dev)
+                        a3, _ = time_kernel(itw_amd, f2, p2, d3, o2, steps=3, warmup=1)
+                        side[f"{wl}@{kind}"] = {"Mpixels/s": round(size * size / (a3 * 1e-3) / 1e6, 1), "kernel_ms_avg": round(a3, 4),
+                                                "content": "alpha = 255 everywhere" if kind == "opaque" else "per 4x4 block: opaque or translucent, 50/50"}
+                        del d3
                 del d2, o2
             except Exception as e:  # a format whose kernel is not built yet aborts in C; anything else lands here
                 side[wl] = {"error": repr(e)}
@@ -511,6 +616,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":

@@ -14,6 +14,11 @@
  * Input texels: host memory is uploaded band by band by the GPU that encodes the band; a surface resident on one GPU is
  * scattered to the others with peer copies (the owner's band is encoded in place).
  * Each rank cuts its band in two: the gather of the first half runs on a second stream while the second half encodes.
+ * Strides are signed like the reference's (bottom-up surfaces are staged row by row, as CompressBlocks* does).
+ *
+ * Failures: the ranks allocate everything first and post transfers only if all of them are ready; a failure after that
+ * aborts the RCCL communicators so no rank keeps waiting for a peer that will not send (rebuilt on the next call).  The
+ * call then fails as a whole: abort() with a diagnostic, or `false` + itwLastError() under ITW_ON_ERROR_RETURN.
  */
 #ifndef ITW_MULTIGPU_H
 #define ITW_MULTIGPU_H
@@ -30,6 +35,10 @@ int itwMultiGpuRanks(void);
 
 /* "rccl" or "peer": what the last call on this process used for device-resident gathers (static storage). */
 const char* itwMultiGpuTransport(void);
+
+/* Directed device pairs for which the rank threads enabled peer access so far (hipDeviceEnablePeerAccess): scatter and
+ * peer-copy gather then travel over xGMI instead of bouncing through host memory.  0 on a one-GPU box. */
+int itwMultiGpuPeerLinks(void);
 
 /* Encode `input` with `cmpFunc` (a CompressImage* trampoline, win32Threads.h:58-80) across `ranks` ranks and leave the
  * whole block stream in `output`.  Pointers: host or device, as for CompressBlocks*.  Synchronous.  Returns false only in

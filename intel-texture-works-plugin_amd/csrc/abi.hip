@@ -189,6 +189,16 @@ float* bc7_workspace(int w, int h, hipStream_t st, int64_t wide_max_blocks = 0)
     return ws;
 }
 
+// Grows the per-thread workspace to `bytes` under the same ordering rules (used to pre-size it for a multi-run call).
+void reserve_workspace(size_t bytes, hipStream_t st)
+{
+    bind_thread_to_current_device();
+    if (!tls.ws_event) ITW_CHECK(hipEventCreateWithFlags(&tls.ws_event, hipEventDisableTiming));
+    if (tls.ws_used && tls.ws_stream != st) ITW_CHECK(hipStreamWaitEvent(st, tls.ws_event, 0));
+    (void)grow(tls.d_ws, tls.ws_cap, bytes);
+    tls.ws_stream = st; tls.ws_used = true;
+}
+
 // `staged`: a run of a host-pointer call.  Its upload / download overlap the neighbouring runs' kernels, and the wide BC7
 // shape (scans and single-subset modes side by side on two streams) fills the gaps between runs better than five dependent
 // launches: measured 8.75 -> 7.89 ms for a 4096^2 `slow` call.  Device-resident calls keep the deep shape above 262144
@@ -297,10 +307,19 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
             for (int c = 0; c < n; c++) { int r = (int)(by * f[c]); cut[c + 1] = r < cut[c] + 1 ? cut[c] + 1 : (r > by - (n - c) ? by - (n - c) : r); }
         }
     }
-    if (j.fmt == Fmt::BC7) {                           // size the workspace once, for the largest run (growing it frees it,
-        int big = 0;                                   // and hipFree waits for the runs in flight)
-        for (int c = 0; c < nch; c++) if (cut[c + 1] - cut[c] > big) big = cut[c + 1] - cut[c];
-        (void)bc7_workspace(w, big * 4, st, (!src_dev && !dst_dev) ? ((int64_t)1 << 20) : 0);
+    if (j.fmt == Fmt::BC7 || j.fmt == Fmt::BC6H) {
+        // Size the workspace once for the most demanding run: growing it frees it, and hipFree waits for the runs in flight.
+        // "Most demanding" is not "tallest" (ADVICE r02): a staged BC7 run of up to 2^20 blocks takes the wide shape at ~440
+        // B/block while a taller one takes the deep shape at 36 B/block, so the maximum is taken over every run's own need.
+        const int64_t wide_max = (!src_dev && !dst_dev) ? ((int64_t)1 << 20) : 0;
+        size_t need = 0;
+        for (int c = 0; c < nch; c++) {
+            const int run_rows = (cut[c + 1] - cut[c]) * 4;
+            if (run_rows <= 0) continue;
+            const size_t b = (j.fmt == Fmt::BC7) ? itw::bc7_workspace_bytes(w, run_rows, wide_max) : itw::bc6h_workspace_bytes(w, run_rows, *j.s6);
+            if (b > need) need = b;
+        }
+        if (need) reserve_workspace(need, st);
     }
     hipStream_t copy = (nch > 1) ? cs : st;
     int c = 0;

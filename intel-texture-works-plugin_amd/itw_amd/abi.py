@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = tuple(
     + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
        "itwConvertToRGBA8Device", "itwConvertToRGBA16FDevice"]
     # include/itw_multigpu.h: one surface over all GPUs, one process
-    + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwCompressImageMultiGPU"]
+    + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU"]
     # include/itw_bc45.h: the DirectXTex formats of the plugin
     + ["CompressBlocksBC4", "CompressBlocksBC5"]
     # include/itw_decode.h: device decoders
@@ -131,6 +131,7 @@ def lib():
         L.itwCompressImageSliced.restype = C.c_bool
         L.itwMultiGpuRanks.restype = C.c_int
         L.itwMultiGpuTransport.restype = C.c_char_p
+        L.itwMultiGpuPeerLinks.restype = C.c_int
         L.itwCompressImageMultiGPU.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.itwCompressImageMultiGPU.restype = C.c_bool
         L.itwPadToMultipleOf4.argtypes = [C.POINTER(RgbaSurface), C.c_int]

@@ -32,6 +32,26 @@ def ldr_smooth(h, w, seed=SEED):
     return np.ascontiguousarray(np.transpose(img, (1, 2, 0)))
 
 
+def ldr_alpha_variant(img, kind, seed=SEED + 7):
+    """The same RGB with another alpha channel, for the RGBA (`alpha_*`) BC7 profiles whose cost depends on it:
+    "translucent" = as generated (every block has alpha well below 255), "opaque" = alpha 255 everywhere (what most of a
+    real "has alpha" texture is), "mixed" = per 4x4 block either of the two, 50/50."""
+    if kind == "translucent":
+        return img
+    out = img.copy()
+    if kind == "opaque":
+        out[..., 3] = 255
+        return out
+    if kind != "mixed":
+        raise ValueError(kind)
+    h, w = img.shape[:2]
+    rng = np.random.default_rng(seed)
+    opaque = rng.integers(0, 2, size=((h + 3) // 4, (w + 3) // 4), dtype=np.uint8).astype(bool)
+    mask = np.repeat(np.repeat(opaque, 4, axis=0), 4, axis=1)[:h, :w]
+    out[..., 3] = np.where(mask, np.uint8(255), img[..., 3])
+    return out
+
+
 def ldr_uniform(h, w, seed=SEED + 1):
     """I3u: i.i.d. uniform bytes -- every block spans the full range (worst case)."""
     rng = np.random.default_rng(seed)

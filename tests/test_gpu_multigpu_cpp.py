@@ -62,3 +62,93 @@ def test_more_ranks_than_block_rows_and_default_rank_count(itw, gpu, oracle):
     assert itw.lib().itwMultiGpuRanks() >= 1
     got = itw.compress_image_multigpu("bc1", img)               # ranks = 0: one per visible device
     assert first_mismatch(got, want, 8) is None
+
+
+def test_bottom_up_surface_signed_stride(itw, gpu, oracle):
+    """a bottom-up surface (negative stride; the reference indexes ptr + y*stride with a signed stride,
+    kernel.ispc:105-151) encodes through the multi-GPU entry like it does through CompressBlocks*: staged row by row."""
+    img = _img("bc3", 64, 96)
+    flipped = img[::-1]                                          # view: ptr = last row in memory, stride < 0
+    assert flipped.strides[0] < 0
+    want = oracle.encode("bc3", np.ascontiguousarray(flipped)).reshape(-1)
+    got = itw.compress_image_multigpu("bc3", flipped, ranks=3)
+    assert first_mismatch(got, want, 16) is None, first_mismatch(got, want, 16)
+
+
+@pytest.mark.parametrize("spec", ["1:1", "0:1", "2:2", "0:2"])
+@pytest.mark.parametrize("device_out", [False, True])
+def test_a_failing_rank_fails_the_call_and_never_hangs(itw, gpu, oracle, spec, device_out):
+    """a rank that fails -- while preparing (stage 1: before any transfer is posted) or in the middle of
+    its band (stage 2: its first half is already on its way) -- must end the whole call with an error, not leave the other
+    ranks waiting.  ITW_MULTIGPU_TEST_FAIL injects the failure; under ITW_ON_ERROR_RETURN the call returns false with the
+    rank's message, and the next call (same rank threads, same buffers) is correct again."""
+    import os
+    import torch
+    img = _img("bc7", 128, 64)
+    want = oracle.encode("bc7", img, "veryfast").reshape(-1)
+    out = torch.empty(want.size, dtype=torch.uint8, device=gpu) if device_out else None
+    itw.set_error_mode(itw.ON_ERROR_RETURN)
+    os.environ["ITW_MULTIGPU_TEST_FAIL"] = spec
+    try:
+        with pytest.raises(RuntimeError, match="injected failure"):
+            itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, out=out)
+    finally:
+        del os.environ["ITW_MULTIGPU_TEST_FAIL"]
+        itw.set_error_mode(itw.ON_ERROR_ABORT)
+    got = itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, out=out)
+    if device_out:
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+    assert first_mismatch(got, want, 16) is None
+
+
+def _device_count():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+needs_two_gpus = pytest.mark.skipif(_device_count() < 2, reason="needs >= 2 visible GPUs (activates by itself on a multi-GPU node)")
+
+
+@needs_two_gpus
+@pytest.mark.parametrize("fmt,prof", [("bc1", None), ("bc7", "basic"), ("bc6h", "fast")])
+def test_real_devices_rccl_gather(itw, gpu, oracle, fmt, prof):
+    """>= 2 GPUs: one rank per device, texels and block stream resident on device 0 -- scatter by peer copies over xGMI
+    (peer access enabled by the rank threads), gather by RCCL send/recv.  Bytes equal the oracle's; the transport must
+    report "rccl"."""
+    import torch
+    n = _device_count()
+    img = _img(fmt, 64 * n, 256)
+    want = oracle.encode_mt(fmt, img, prof).reshape(-1)
+    d = torch.from_numpy(img).to(gpu)
+    out = itw.compress_image_multigpu(fmt, d, prof, ranks=n)
+    torch.cuda.synchronize()
+    assert first_mismatch(out.cpu().numpy(), want, itw.BYTES_PER_BLOCK[fmt]) is None
+    assert itw.lib().itwMultiGpuTransport() == b"rccl"
+    assert itw.lib().itwMultiGpuPeerLinks() >= n - 1
+    host = itw.compress_image_multigpu(fmt, img, prof, ranks=n)                     # host -> n GPUs -> host
+    assert first_mismatch(host, want, itw.BYTES_PER_BLOCK[fmt]) is None
+
+
+@needs_two_gpus
+def test_real_devices_failure_aborts_the_rccl_gather(itw, gpu, oracle):
+    """>= 2 GPUs: a rank that dies after the owner posted its receives -- ncclCommAbort releases the owner, the call fails,
+    the communicators are rebuilt and the next call is correct."""
+    import os
+    import torch
+    n = _device_count()
+    img = _img("bc7", 64 * n, 128)
+    want = oracle.encode("bc7", img, "veryfast").reshape(-1)
+    d = torch.from_numpy(img).to(gpu)
+    itw.set_error_mode(itw.ON_ERROR_RETURN)
+    os.environ["ITW_MULTIGPU_TEST_FAIL"] = "1:2"
+    try:
+        with pytest.raises(RuntimeError, match="injected failure"):
+            itw.compress_image_multigpu("bc7", d, "veryfast", ranks=n)
+    finally:
+        del os.environ["ITW_MULTIGPU_TEST_FAIL"]
+        itw.set_error_mode(itw.ON_ERROR_ABORT)
+    out = itw.compress_image_multigpu("bc7", d, "veryfast", ranks=n)
+    torch.cuda.synchronize()
+    assert first_mismatch(out.cpu().numpy(), want, 16) is None
+    assert itw.lib().itwMultiGpuTransport() == b"rccl"

@@ -196,6 +196,36 @@ def test_band_rule_keeps_partial_blocks_for_bc4_bc5(fmt, h, w, parts):
     assert covered == whole.size and np.array_equal(got, whole)
 
 
+def _run_bench_world2(extra_env):
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, ITW_BENCH_CONTROL_FLOW_TEST="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ITW_BENCH_DIST_TIMEOUT_S="120", **extra_env)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                                       "--size", "512", "--no-formats", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    return outs
+
+
+@pytest.mark.parametrize("corrupt", [None, "0", "1"])
+def test_bench_n_gt_1_verifies_the_gathered_image(corrupt):
+    """the N > 1 bench job checks what it gathered.  World 2 over gloo with the stand-in encoder (block
+    bytes = a function of the band's texels): an intact run reports gather_verified = true; a rank that damages one byte of
+    its band after encoding it (ITW_BENCH_CORRUPT_RANK) makes every rank's comparison of that band fail -> false, with the
+    damaged bytes counted (its own check + the other rank's check of it, per job)."""
+    import json
+    outs = _run_bench_world2({} if corrupt is None else {"ITW_BENCH_CORRUPT_RANK": corrupt})
+    j = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert j["band_checks"] == 4 and len(j["per_rank_kernel_ms"]) == 2          # world 2: own band + the other's, on both ranks
+    if corrupt is None:
+        assert j["gather_verified"] is True and j["mismatching_bytes"] == 0
+    else:
+        assert j["gather_verified"] is False and j["mismatching_bytes"] == 2   # seen by the damaged rank itself and by its peer
+
+
 def test_bench_n_gt_1_control_flow_runs_end_to_end_on_cpu():
     """bench.py --gpus 2 as the driver launches it (one process per rank, env rendezvous), with ITW_BENCH_CONTROL_FLOW_TEST=1:
     gloo instead of RCCL and a memset instead of the encode.  Not a measurement -- it executes every Python line of the N > 1
