@@ -102,6 +102,42 @@ __device__ __forceinline__ float rcp_nr(float v, const Bc1Tables& B)            
     t = 2.0f - t;
     return r * t;
 }
+// The same for an operand known to be a positive ordinary number (exponent field 1..252), or +0 where the caller shows the
+// result does not matter: no range test, no divergent branch, no sign handling -- 4 VALU operations + one LDS read for the
+// seed.  For +0 the seed comes out as a finite 2^126-sized number instead of +inf.
+__device__ __forceinline__ float rcp_nr_pos(float v, const Bc1Tables& B)
+{
+    const uint32_t x = __float_as_uint(v);
+    const uint32_t t = B.rcp32[(x >> 12) & 0x7ffu];
+    const float r = __uint_as_float(t - (x & 0x7f800000u));
+    float u = v * r;
+    u = 2.0f - u;
+    return r * u;
+}
+// ISPC rsqrt() of a positive ordinary operand (x86_rsqrtps_fast without its range test)
+__device__ __forceinline__ float rsqrt_nr_pos(float v, const Bc1Tables& B)
+{
+    const uint32_t x = __float_as_uint(v);
+    const uint32_t t = B.T.rsqrt32[(x >> 13) & 0x7ffu];
+    const float is = __uint_as_float(t - (((x + 0x00800000u) >> 1) & 0x7f800000u));
+    float a = v * is;
+    a = a * is;
+    a = 3.0f - a;
+    a = is * a;
+    return 0.5f * a;
+}
+
+template <int N> __device__ __forceinline__ float ubyte_f32(uint32_t w)
+{
+    float d;
+    if (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d) : "v"(w));
+    if (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d) : "v"(w));
+    if (N == 2) asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(d) : "v"(w));
+    if (N == 3) asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(d) : "v"(w));
+    return d;
+}
+// v_min_f32 as an instruction, for operands known to be numbers (fminf() quiets operands it cannot prove quiet)
+__device__ __forceinline__ float vmin_raw(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
 // ---- the lane's texels -------------------------------------------------------------------------------------------------
 // Kept as aligned register pairs so that the sums whose products cannot round -- the covariance of the centred texels
@@ -152,6 +188,10 @@ __device__ __forceinline__ void order(Endpoint& a, Endpoint& b)
 
 // Project the 16 texels on the endpoint segment and emit linear 2-bit indices.   [kernel.ispc:308-344]
 // Also returns each texel's index as a float (the refit's weights) when WANT_Q.
+// The index clamp(trunc(t), 0, 3) is taken in the float domain -- clamp to [0, 3] first (a NaN t clamps to 0 like the
+// reference's INT_MIN; trunc and floor agree on [0, 3]) then v_floor -- so the refit's float weight is the same register, and
+// the sixteen indices are packed by Horner steps acc*4 + q on two 8-texel halves (exact: below 2^16), converted once:
+// per texel clamp + floor + mul + add instead of convert + clamp + shift + or (+ convert back for the refit).
 template <bool WANT_Q>
 __device__ __forceinline__ uint32_t project_indices(const Texels& px, const Endpoint& e0, const Endpoint& e1, const Bc1Tables& B,
                                                     f2 (&qf)[8])
@@ -161,23 +201,28 @@ __device__ __forceinline__ uint32_t project_indices(const Texels& px, const Endp
 
     float sq_norm = sq(dir[0]);                      // 0 + x*x = x*x exactly
     sq_norm += sq(dir[1]); sq_norm += sq(dir[2]);
-    const float rs3 = rcp_nr(sq_norm, B) * 3.0f;
+    // sq_norm is an integer in [1, 3*255^2], or 0 when both endpoints decode alike.  The reference's rcp(0) is NaN (inf seed
+    // through the Newton step), every projection is NaN and every index (int)NaN = INT_MIN clamps to 0.  Here rcp(+0) stays
+    // finite (or overflows to inf after the * 3): dir = 0 * finite = 0 -> dot + bias = 0.5 -> index 0, or dir = 0 * inf =
+    // NaN -> index 0 as in the reference.  Either way the same sixteen zeros.
+    const float rs3 = rcp_nr_pos(sq_norm, B) * 3.0f;
     for (int p = 0; p < 3; p++) dir[p] *= rs3;
 
     float bias = 0.5f;
     for (int p = 0; p < 3; p++) bias -= e0.dec[p] * dir[p];
 
-    uint32_t bits = 0;
+    float half[2] = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 15; k >= 0; k--) {                  // Horner: texel k ends up at bits 2k
         float dot = px.r(k) * dir[0];                // the reference's 0 + a = a: exact (the sign of a zero cannot reach q)
         dot += px.g(k) * dir[1]; dot += px.b(k) * dir[2];
-        // finite and small (|dir| <= 3*255, texels <= 255) or NaN when p0 == p1 (rcp(0)): NaN -> 0 on both routes after the clamp
-        const int32_t q = iclamp(cvt_i32_sat(dot + bias), 0, 3);
-        bits |= (uint32_t)q << (2 * k);
-        if (WANT_Q) { if (k & 1) qf[k >> 1].y = (float)q; else qf[k >> 1].x = (float)q; }
+        const float q = __builtin_floorf(fclamp_num(dot + bias, 0.f, 3.f));
+        if (WANT_Q) { if (k & 1) qf[k >> 1].y = q; else qf[k >> 1].x = q; }
+        float& h = half[k >> 3];
+        h = h * 4.0f;
+        h = h + q;
     }
-    return bits;
+    return (uint32_t)half[0] | ((uint32_t)half[1] << 16);
 }
 
 // Least-squares endpoint update for fixed indices.               [kernel.ispc:419-480]
@@ -206,7 +251,9 @@ __device__ __forceinline__ void refit_endpoints(float (&c0)[3], float (&c1)[3], 
     const float cxx = 144.0f - 6.0f * sum_q + sum_qq;
     const float cyy = sum_qq;
     const float cxy = 3.0f * sum_q - sum_qq;
-    const float scale = 3.0f * rcp_nr(cxx * cyy - cxy * cxy, B);
+    // the determinant is an exact integer (all factors <= 144) and, by Cauchy-Schwarz, zero only when all indices are equal --
+    // the case that left above: a positive ordinary number here
+    const float scale = 3.0f * rcp_nr_pos(cxx * cyy - cxy * cxy, B);
     for (int p = 0; p < 3; p++) {
         const float atb1 = 3.0f * acc[p] - s[p];
         const float atb2 = s[p];
@@ -255,7 +302,7 @@ __device__ __forceinline__ void encode_color(const Texels& px, uint32_t out[2], 
         if (it & 1) {
             float n = 0.f;
             n += a0 * a0; n += a1 * a1; n += a2 * a2;
-            const float rn = ispc_rsqrt<true>(n, B.T);
+            const float rn = rsqrt_nr_pos(n, B);           // the diagonal carries +0.001: n is a positive ordinary number (see below)
             v[0] *= rn; v[1] *= rn; v[2] *= rn;
         }
     }
@@ -275,7 +322,7 @@ __device__ __forceinline__ void encode_color(const Texels& px, uint32_t out[2], 
 
     float nsq = v[0] * v[0];
     nsq += v[1] * v[1]; nsq += v[2] * v[2];
-    const float rn = rcp_nr(nsq, B);
+    const float rn = rcp_nr_pos(nsq, B);                 // |v|^2 of a just-normalised axis: about 1
 
     float c0[3], c1[3];
     for (int p = 0; p < 3; p++) {
@@ -300,78 +347,111 @@ __device__ __forceinline__ void encode_color(const Texels& px, uint32_t out[2], 
 }
 
 // Alpha part of BC3: min/max endpoints, 8-level ramp.            [kernel.ispc:535-571]
+// Per texel the reference computes u = clamp((int)((a - lo) * scale + 0.5), 0, 7), then q = 7 - u reordered for DXT5
+// (0 = alpha0 = max, 1 = alpha1 = min, 2.. the ramp): q' = q + 1 for q in 1..6, 0 for q = 0, 1 for q = 7.  Here u is taken in
+// the float domain (the argument lies in [0.5, 7.6]: min with 7, floor), packed by Horner steps acc*8 + u on two 8-texel
+// halves (exact: below 2^24) and the subtraction and the reordering run ONCE on the packed 3-bit fields.
+__device__ __forceinline__ uint32_t dxt5_order_8x3(uint32_t u)     // eight 3-bit fields u -> q'
+{
+    const uint32_t ones = 011111111u;                              // octal: bit 0 of every field
+    const uint32_t q = 077777777u - u;                             // 7 - u per field, no borrows
+    const uint32_t any = (q | (q >> 1) | (q >> 2)) & ones;         // q != 0
+    const uint32_t all = (q & (q >> 1) & (q >> 2)) & ones;         // q == 7
+    return ((q & ~(all * 7u)) + (any & ~all)) | all;               // 7 -> 1, 0 -> 0, else + 1 (no carries: at most 6 + 1)
+}
 __device__ __forceinline__ void encode_alpha(const float (&a)[16], uint32_t out[2], const Bc1Tables& B)
 {
     float lo = 255.f, hi = 0.f;
 #pragma unroll
     for (int k = 0; k < 16; k++) { lo = __builtin_fminf(lo, a[k]); hi = __builtin_fmaxf(hi, a[k]); }   // minps / maxps of ordinary numbers (bytes)
     if (lo == hi) hi = lo + 0.1f;
-    const float scale = 7.0f * rcp_nr(hi - lo, B);
+    const float scale = 7.0f * rcp_nr_pos(hi - lo, B);   // hi - lo in [0.1, 255]
 
-    uint32_t q0 = 0, q1 = 0;      // 8 x 3 bits each
+    float half[2] = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int32_t q = 7 - iclamp(cvt_i32_sat((a[k] - lo) * scale + 0.5f), 0, 7);      // hi - lo >= 0.1: finite, in [0.5, 7.6]
-        q = (q > 0) ? q + 1 : q;   // DXT5 order: 0 = alpha0(max), 1 = alpha1(min), 2.. ramp
-        q = (q == 8) ? 1 : q;
-        if (k < 8) q0 |= (uint32_t)q << (k * 3); else q1 |= (uint32_t)q << ((k - 8) * 3);
+    for (int k = 15; k >= 0; k--) {
+        const float x = (a[k] - lo) * scale + 0.5f;                 // hi - lo >= 0.1: finite, in [0.5, 7.6]
+        const float u = __builtin_floorf(vmin_raw(x, 7.0f));
+        float& h = half[k >> 3];
+        h = h * 8.0f;
+        h = h + u;
     }
+    const uint32_t q0 = dxt5_order_8x3((uint32_t)half[0]), q1 = dxt5_order_8x3((uint32_t)half[1]);   // 8 x 3 bits each
     out[0] = (uint32_t)(iclamp(cvt_i32_sat(lo), 0, 255) * 256 + iclamp(cvt_i32_sat(hi), 0, 255)) | (q0 << 16);
     out[1] = (q0 >> 16) | (q1 << 8);
 }
 
-// Workgroups are persistent: each stages the tables once and then walks chunks of 256 blocks.
-// 4 waves per SIMD (128 registers): measured best on MI355X; 3 and 5 were tried (tools/gpu_bc1.sh history in DESIGN.md 3).
+// The sixteen texel words of block `cur` (4 x dwordx4 when VEC16)
+template <bool VEC16>
+__device__ __forceinline__ void load_words(uint32_t (&w)[16], const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t cur)
+{
+    const int32_t yy = cur / blocks_x, xx = cur - yy * blocks_x;
+    const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 16;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        if (VEC16) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p + y * stride);
+            w[4 * y] = v.x; w[4 * y + 1] = v.y; w[4 * y + 2] = v.z; w[4 * y + 3] = v.w;
+        } else {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(p + y * stride);
+            w[4 * y] = q[0]; w[4 * y + 1] = q[1]; w[4 * y + 2] = q[2]; w[4 * y + 3] = q[3];
+        }
+    }
+}
+
 template <bool BC3, bool VEC16>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_tables[BC1_LDS_BYTES];
+    // The first chunk's texels are requested BEFORE the tables are staged: at launch every wave of the chip stands in this
+    // prologue at once, and the HBM round trip of the texels then runs under the 21 KiB table copy instead of after it.
+    int32_t base = blockIdx.x * 256;
+    uint32_t w[16];
+    {
+        const int32_t cur = base + threadIdx.x;
+        load_words<VEC16>(w, src, stride, blocks_x, cur < nblocks ? cur : nblocks - 1);
+    }
     const Bc1Tables B = stage_bc1_tables(s_tables, threadIdx.x, 256);
     __syncthreads();
-    for (int32_t base = blockIdx.x * 256; base < nblocks; base += gridDim.x * 256) {
+    for (;;) {
         const int32_t cur = base + threadIdx.x;
-        if (cur >= nblocks) break;
-        const int32_t yy = cur / blocks_x, xx = cur - yy * blocks_x;
-        // (requesting the next chunk's texels before encoding this one was measured: the 16 extra live registers cost more
+        // (requesting the NEXT chunk's texels before encoding this one was measured: the 16 extra live registers cost more
         // than the hidden latency gains -- four waves per SIMD already overlap each other's loads)
         Texels px;
         float al[16];
-        const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 16;
+        // one v_cvt_f32_ubyteN per channel, as instructions: from C++ the compiler recognises sums of converted bytes as integer
+        // sums and rebuilds them from v_bfe / v_add3 / v_cvt_f32_u32 (4-cycle forms) instead of 2-cycle float adds
 #pragma unroll
-        for (int y = 0; y < 4; y++) {
-            uint32_t w[4];
-            if (VEC16) {
-                const uint4 v = *reinterpret_cast<const uint4*>(p + y * stride);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else {
-                const uint32_t* q = reinterpret_cast<const uint32_t*>(p + y * stride);
-                w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
-            }
-#pragma unroll
-            for (int x = 0; x < 4; x++) {
-                const int k = y * 4 + x;
-                px.rg[k].x = (float)(w[x] & 255u);
-                px.rg[k].y = (float)((w[x] >> 8) & 255u);
-                if (k & 1) px.b2[k >> 1].y = (float)((w[x] >> 16) & 255u); else px.b2[k >> 1].x = (float)((w[x] >> 16) & 255u);
-                if (BC3) al[k] = (float)(w[x] >> 24);
-            }
+        for (int k = 0; k < 16; k++) {
+            px.rg[k].x = ubyte_f32<0>(w[k]);
+            px.rg[k].y = ubyte_f32<1>(w[k]);
+            if (k & 1) px.b2[k >> 1].y = ubyte_f32<2>(w[k]); else px.b2[k >> 1].x = ubyte_f32<2>(w[k]);
+            if (BC3) al[k] = ubyte_f32<3>(w[k]);
         }
 
         if (BC3) {
             uint32_t o[4];
             encode_alpha(al, &o[0], B);
             encode_color(px, &o[2], B);
-            uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)cur * 16);
-            if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(o[0], o[1], o[2], o[3]);
-            else { d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3]; }
+            if (cur < nblocks) {
+                uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)cur * 16);
+                if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(o[0], o[1], o[2], o[3]);
+                else { d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3]; }
+            }
         } else {
             uint32_t o[2];
             encode_color(px, o, B);
-            uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)cur * 8);
-            if (VEC16) *reinterpret_cast<uint2*>(d) = make_uint2(o[0], o[1]);
-            else { d[0] = o[0]; d[1] = o[1]; }
+            if (cur < nblocks) {
+                uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)cur * 8);
+                if (VEC16) *reinterpret_cast<uint2*>(d) = make_uint2(o[0], o[1]);
+                else { d[0] = o[0]; d[1] = o[1]; }
+            }
         }
+        base += gridDim.x * 256;
+        if (base >= nblocks) break;                                    // wave-uniform
+        const int32_t nxt = base + threadIdx.x;
+        load_words<VEC16>(w, src, stride, blocks_x, nxt < nblocks ? nxt : nblocks - 1);
     }
 }
 

@@ -230,8 +230,8 @@ __device__ __forceinline__ void fit_line(float (&ep)[2][4], const Tex& tx, uint3
                 float dot = axis[0] * (tx.get(0, k) - dc[0]);
 #pragma unroll
                 for (int p = 1; p < CH; p++) dot += axis[p] * (tx.get(p, k) - dc[p]);
-                lo = __builtin_fminf(lo, dot);
-                hi = __builtin_fmaxf(hi, dot);
+                lo = vmin_raw(lo, dot);                     // the instruction itself: fminf() adds a canonicalising v_max(x, x) per
+                hi = vmax_raw(hi, dot);                     // operand the compiler cannot prove quiet (lo / hi cross basic blocks)
             }
         }
     }
@@ -410,17 +410,33 @@ __device__ __forceinline__ int32_t select_block(uint32_t (&qb)[2], const Tex& tx
 
 // ---- index selection through a per-segment palette in LDS ---------------------------------------------------
 // The decoded colour of index q on a segment does not depend on the texel, so a table-order scan decodes every level
-// ONCE per (subset, mode) -- LEVELS x ~30 cycles -- into LDS and each texel then needs: the projection (2 dot ops, one
-// FMA), one 16-byte LDS read of the two neighbouring levels, and per candidate one v_dot4_u32_u8 against the texel as
-// loaded:  |P - t|^2 = |P|^2 - 2 P.t + |t|^2.  |t|^2 is the same for both candidates and sums to a per-block constant
-// over the texels (each texel belongs to exactly one subset), which the caller adds once per shape: the block error is
-// still the reference's exact integer.  Entry layout: {P0 | P1 << 8 | P2 << 16 | P3 << 24, -|P|^2}, level-major,
-// lane-minor (`pal[level * PAL_STRIDE]`): any mix of levels across a wave is bank-conflict free.
+// ONCE per (subset, mode) into LDS and each texel then needs: the projection, one 16-byte LDS read of the two neighbouring
+// levels, and per candidate one v_dot4_u32_u8 against the texel as loaded:  |P - t|^2 = |P|^2 - 2 P.t + |t|^2.  |t|^2 is
+// the same for both candidates and sums to a per-block constant over the texels (each texel belongs to exactly one subset),
+// which the caller adds once per shape: the block error is still the reference's exact integer.  Entry layout:
+// {P0 | P1 << 8 | P2 << 16 | P3 << 24, -|P|^2}, level-major, lane-minor (`pal[level * PAL_STRIDE]`): any mix of levels
+// across a wave is bank-conflict free.
+//
+// Projection (round 3).  N = sum (t-a)(b-a) = t.b - t.a - a.(b-a): the endpoints a, b as packed bytes ARE palette levels 0
+// and LEVELS-1, so N is two v_dot4_u32_u8 against the texel word as loaded (the palette's alpha byte is 0 when CH == 3)
+// and one subtraction -- no unpacking of the texel into 16-bit pairs.
+// Index (round 3).  The reference's q1 equals clamp(floor(y + 0.5), 1, LEVELS-1), y = N*LEVELS/D (statement (1) above).
+//   BITS == 2: q1 - 1 = [y + 0.5 >= 2] + [y + 0.5 >= 3] = [8N >= 3D] + [8N >= 5D] = [N >= ceil(3D/8)] + [N >= ceil(5D/8)]:
+//     two integer thresholds per segment, two subtractions and two sign extractions per texel; no float, no divide.
+//     D == 0 (the reference's 0/0 -> NaN -> INT_MIN -> clamp 1): thresholds that no N reaches.
+//   BITS == 3: x' = fma(N, k0, k1') with k0 = RN(LEVELS/D) and k1' = RN(1/D)/4 (exact scaling) approximates y + 1/(4D) to
+//     within 6.6e-7 (bound (2) above, now without the rounding of k1), and y + 1/(4D) is at least 1/(4D) >= 1.28e-6 away from
+//     every half-integer m - 0.5 with m in [2, LEVELS-1] -- so x' is never a rounding tie there, and adding 1.5 * 2^23
+//     (round to nearest at ulp 1) leaves floor(y + 0.5) in the low mantissa bits: one v_add_f32 instead of a conversion.
+//     Outside [1.5, LEVELS-1.5) the clamp decides, and any rounding of x' lands on the clamped side.
 struct PalSegment {
-    uint32_t ba01, ba23;    // endpoint 1 - endpoint 0 (as in Segment; CH == 3: ba23 = int32 of channel 2)
-    int32_t nc;             // -sum a*(b-a): N = sum t*(b-a) + nc
-    float k0, k1;           // LEVELS/|b-a|^2 (sign folded: x~ = N*k0 + k1) and 0.5 + 1/(4|b-a|^2), cf. Segment
+    uint32_t p0, p1;        // endpoints 0 / 1 as packed bytes (= palette levels 0 and LEVELS-1)
+    int32_t nc;             // -sum a*(b-a): N = t.p1 - t.p0 + nc
+    float k0, k1;           // BITS == 3: LEVELS/|b-a|^2 and 1/(4|b-a|^2)
+    int32_t th1, th2;       // BITS == 2: ceil(3D/8) - 1, ceil(5D/8) - 1
 };
+
+constexpr int32_t PAL_MAGIC = 0x4b400000;                                   // bits of 1.5 * 2^23
 
 template <int BITS, int CH, int PAL_STRIDE>
 __device__ __forceinline__ PalSegment build_palette(uint2* pal, const int32_t (&d)[2][4])
@@ -429,67 +445,96 @@ __device__ __forceinline__ PalSegment build_palette(uint2* pal, const int32_t (&
     constexpr int LEVELS = 1 << BITS;
     PalSegment s;
     const uint32_t a01 = pack16(d[0][0], d[0][1]);
-    s.ba01 = pk_sub(pack16(d[1][0], d[1][1]), a01);
-    uint32_t a23;
+    const uint32_t ba01 = pk_sub(pack16(d[1][0], d[1][1]), a01);
+    uint32_t a23, ba23;
     int32_t dd;
     if (CH == 4) {
         a23 = pack16(d[0][2], d[0][3]);
-        s.ba23 = pk_sub(pack16(d[1][2], d[1][3]), a23);
-        dd = dot2(s.ba01, s.ba01, dot2(s.ba23, s.ba23, 0));
-        s.nc = -dot2(a01, s.ba01, dot2(a23, s.ba23, 0));
+        ba23 = pk_sub(pack16(d[1][2], d[1][3]), a23);
+        dd = dot2(ba01, ba01, dot2(ba23, ba23, 0));
+        s.nc = -dot2(a01, ba01, dot2(a23, ba23, 0));
     } else {
         const int32_t ba2 = d[1][2] - d[0][2];
         a23 = (uint32_t)d[0][2];
-        s.ba23 = (uint32_t)ba2;
-        dd = dot2(s.ba01, s.ba01, ba2 * ba2);
-        s.nc = -dot2(a01, s.ba01, d[0][2] * ba2);
+        ba23 = (uint32_t)ba2;
+        dd = dot2(ba01, ba01, ba2 * ba2);
+        s.nc = -dot2(a01, ba01, d[0][2] * ba2);
     }
-    const float dn = -(float)dd;
-    const float r = (dd == 0) ? 0.0f : 1.0f / dn;                          // = RN(-1/D), cf. make_segment
-    s.k0 = -((float)LEVELS * r);                                           // M*k0 with M = -N  ==  N*(-k0): exact sign flips
-    s.k1 = 0.5f - 0.25f * r;
+    if (BITS == 3) {
+        const float dn = -(float)dd;
+        const float r = (dd == 0) ? 0.0f : 1.0f / dn;                      // = RN(-1/D): one IEEE divide per segment
+        s.k0 = -((float)LEVELS * r);
+        s.k1 = -0.25f * r;
+        s.th1 = s.th2 = 0;
+    } else {
+        s.k0 = s.k1 = 0.f;
+        s.th1 = (dd == 0) ? 0x3fffffff : ((3 * dd + 7) >> 3) - 1;         // stored minus one: [N >= th] = sign of (th - 1 - N)
+        s.th2 = (dd == 0) ? 0x3fffffff : ((5 * dd + 7) >> 3) - 1;         // |N| < 2^19: 2^30 is unreachable and th - 1 - N cannot wrap
+    }
     const s16x2 k32 = {32, 32}, six = {6, 6};
 #pragma unroll
     for (int q = 0; q < LEVELS; q++) {
         constexpr int D = LEVELS - 1;
         const uint32_t w = (uint32_t)((q * 128 + D) / (2 * D)) * 0x00010001u;           // the format's weight, both halves
         // decoded c0 | c1 << 16; the end levels are the endpoints themselves ((0*d + 32) >> 6 = 0, (64*d + 32) >> 6 = d)
-        const uint32_t x01 = (q == 0) ? a01 : (q == D) ? pk_add(s.ba01, a01)
-                                            : pk_add(as_u32((as_s16x2(w) * as_s16x2(s.ba01) + k32) >> six), a01);
-        uint32_t bytes, pp;
+        const uint32_t x01 = (q == 0) ? a01 : (q == D) ? pk_add(ba01, a01)
+                                            : pk_add(as_u32((as_s16x2(w) * as_s16x2(ba01) + k32) >> six), a01);
+        uint32_t bytes;
         if (CH == 4) {
-            const uint32_t x23 = (q == 0) ? a23 : (q == D) ? pk_add(s.ba23, a23)
-                                                : pk_add(as_u32((as_s16x2(w) * as_s16x2(s.ba23) + k32) >> six), a23);
+            const uint32_t x23 = (q == 0) ? a23 : (q == D) ? pk_add(ba23, a23)
+                                                : pk_add(as_u32((as_s16x2(w) * as_s16x2(ba23) + k32) >> six), a23);
             bytes = __builtin_amdgcn_perm(x23, x01, 0x06040200u);                         // low byte of each half
-            pp = (uint32_t)dot2(x01, x01, dot2(x23, x23, 0));
         } else {
-            const uint32_t x2 = (q == 0) ? a23 : (q == D) ? (uint32_t)d[1][2] : add_u16(ashr6_i16(add32_u16(mul_lo_u16(w, s.ba23))), a23);
+            const uint32_t x2 = (q == 0) ? a23 : (q == D) ? (uint32_t)d[1][2] : add_u16(ashr6_i16(add32_u16(mul_lo_u16(w, ba23))), a23);
             bytes = __builtin_amdgcn_perm(x2, x01, 0x0c040200u);
-            pp = (uint32_t)dot2(x01, x01, (int32_t)mul_lo_u16(x2, x2));
         }
+        const uint32_t pp = udot4(bytes, bytes, 0u);                                      // |P|^2 from the packed bytes: one instruction
         pal[q * PAL_STRIDE] = make_uint2(bytes, 0u - pp);                                 // negated: 2 P.t - |P|^2 is one v_lshl_add
+        if (q == 0) s.p0 = bytes;
+        if (q == D) s.p1 = bytes;
     }
     return s;
 }
 
-// One texel against a palette.  `w` = the texel as loaded (RGBA8; the palette's alpha byte is 0 when CH == 3), t01/t23 as
-// in select_texel.  e_out excludes |t|^2 (see above).
-template <int BITS, int CH, int PAL_STRIDE>
-__device__ __forceinline__ void select_texel_pal(int32_t& q_out, int32_t& e_out, const PalSegment& sg, const uint2* pal,
-                                                 uint32_t w, uint32_t t01, uint32_t t23)
+// N of one texel (RGBA8 word as loaded) against a palette segment
+__device__ __forceinline__ int32_t pal_project(const PalSegment& sg, uint32_t w)
+{
+    return (int32_t)(udot4(w, sg.p1, (uint32_t)sg.nc) - udot4(w, sg.p0, 0u));
+}
+
+// q1 - 1 in [0, LEVELS-2]: the lower of the two neighbouring levels the reference compares
+template <int BITS>
+__device__ __forceinline__ int32_t pal_lower_level(const PalSegment& sg, int32_t n)
 {
     constexpr int LEVELS = 1 << BITS;
-    int32_t n;                                                              // N = sum (t-a)*(b-a)
-    if (CH == 4) n = dot2(t01, sg.ba01, dot2(t23, sg.ba23, sg.nc));
-    else         n = dot2(t01, sg.ba01, (int32_t)t23 * (int32_t)sg.ba23 + sg.nc);
-    const float x = __builtin_fmaf((float)n, sg.k0, sg.k1);                 // = fma(M, k0', k1) of select_texel, signs folded
-    const int32_t q1 = imed3((int32_t)x, 1, LEVELS - 1);
-    const uint2* p = pal + (q1 - 1) * PAL_STRIDE;                           // one address, two reads a level apart
+    if (BITS == 2) {
+        // [n >= th] as the sign bit of (th - 1 - n), moved down by a logical shift: 0 or 1, never negative (the level indexes
+        // LDS).  Written as instructions: from C++ the compiler turns the pattern back into v_cmp + v_cndmask + v_addc
+        // (4-cycle forms with wait states between them); these are 2-cycle VOP2 instructions.
+        uint32_t d1, d2, s1, s2;
+        asm("v_sub_u32 %0, %1, %2" : "=v"(d1) : "v"(sg.th1), "v"(n));
+        asm("v_sub_u32 %0, %1, %2" : "=v"(d2) : "v"(sg.th2), "v"(n));
+        asm("v_lshrrev_b32 %0, 31, %1" : "=v"(s1) : "v"(d1));
+        asm("v_lshrrev_b32 %0, 31, %1" : "=v"(s2) : "v"(d2));
+        return (int32_t)(s1 + s2);
+    }
+    // + (1.5 * 2^23 - 1): the low mantissa bits are floor(y + 0.5) - 1 = q1 - 1 before the clamp; PAL_MAGIC << 11 is 0 mod 2^32,
+    // so the level's LDS offset is the clamped word shifted, no subtraction
+    const float x = __builtin_fmaf((float)n, sg.k0, sg.k1) + 12582911.0f;
+    return imed3(__float_as_int(x), PAL_MAGIC, PAL_MAGIC + LEVELS - 2) - PAL_MAGIC;
+}
+
+// One texel against a palette.  `w` = the texel as loaded.  e_out excludes |t|^2 (see above).
+template <int BITS, int CH, int PAL_STRIDE>
+__device__ __forceinline__ void select_texel_pal(int32_t& q_out, int32_t& e_out, const PalSegment& sg, const uint2* pal, uint32_t w)
+{
+    const int32_t q0 = pal_lower_level<BITS>(sg, pal_project(sg, w));
+    const uint2* p = pal + q0 * PAL_STRIDE;                                 // one address, two reads a level apart
     const uint2 lo = p[0], hi = p[PAL_STRIDE];
     // f = 2 P.t - |P|^2 = -(|P - t|^2 - |t|^2): the smaller error is the larger f; ties go to q1 like the reference's `<`
     const int32_t f0 = (int32_t)((udot4(lo.x, w, 0u) << 1) + lo.y), f1 = (int32_t)((udot4(hi.x, w, 0u) << 1) + hi.y);
     const bool first = f0 > f1;
-    q_out = first ? q1 - 1 : q1;
+    q_out = first ? q0 : q0 + 1;
     e_out = -max(f0, f1);
 }
 
@@ -497,15 +542,10 @@ __device__ __forceinline__ void select_texel_pal(int32_t& q_out, int32_t& e_out,
 // the winner alone, and the finish kernels recompute them from the winner's endpoints (one selection pass per mode and
 // block instead of compare + select + shift-or per texel, mode and shape).
 template <int BITS, int CH, int PAL_STRIDE>
-__device__ __forceinline__ int32_t texel_error_pal(const PalSegment& sg, const uint2* pal, uint32_t w, uint32_t t01, uint32_t t23)
+__device__ __forceinline__ int32_t texel_error_pal(const PalSegment& sg, const uint2* pal, uint32_t w)
 {
-    constexpr int LEVELS = 1 << BITS;
-    int32_t n;
-    if (CH == 4) n = dot2(t01, sg.ba01, dot2(t23, sg.ba23, sg.nc));
-    else         n = dot2(t01, sg.ba01, __mul24((int32_t)t23, (int32_t)sg.ba23) + sg.nc);     // |t23|, |ba23| <= 255
-    const float x = __builtin_fmaf((float)n, sg.k0, sg.k1);
-    const int32_t q1 = imed3((int32_t)x, 1, LEVELS - 1);
-    const uint2* p = pal + (q1 - 1) * PAL_STRIDE;
+    const int32_t q0 = pal_lower_level<BITS>(sg, pal_project(sg, w));
+    const uint2* p = pal + q0 * PAL_STRIDE;
     const uint2 lo = p[0], hi = p[PAL_STRIDE];
     const uint32_t d0 = udot4(lo.x, w, 0u), d1 = udot4(hi.x, w, 0u);
     const int32_t f0 = (int32_t)((d0 << 1) + lo.y), f1 = (int32_t)((d1 << 1) + hi.y);
@@ -519,26 +559,20 @@ __device__ __forceinline__ void subset_error_pal(int32_t& total, const Tex& tx, 
 #pragma unroll
     for (int k = 0; k < 16; k++)
         if ((mask >> k) & 1u)
-            total -= texel_error_pal<BITS, CH, PAL_STRIDE>(sg, pal, tx.w[k], tx.pair01(k), tx.template pair23<CH == 4>(k));
+            total -= texel_error_pal<BITS, CH, PAL_STRIDE>(sg, pal, tx.w[k]);
 }
 
-// Two palettes (the two modes of a family) against one texel, staged so that the four dot products sit side by side: a
+// Two palettes (the two modes of a family) against one texel, staged so that the dot products sit side by side: a
 // texel is its own basic block here (scalar branches on the subset mask), so the only instruction-level parallelism the
 // scheduler finds is what one texel offers, and a dot product followed at once by its consumer costs wait states.
 template <int BITSA, int BITSB, int CH, int PAL_STRIDE>
 __device__ __forceinline__ void texel_error2_pal(int32_t& ta, int32_t& tc, const PalSegment& sa, const uint2* pa,
-                                                 const PalSegment& sc, const uint2* pc, uint32_t w, uint32_t t01, uint32_t t23)
+                                                 const PalSegment& sc, const uint2* pc, uint32_t w)
 {
-    int32_t na, nb;
-    if (CH == 4) { na = dot2(t01, sa.ba01, dot2(t23, sa.ba23, sa.nc)); nb = dot2(t01, sc.ba01, dot2(t23, sc.ba23, sc.nc)); }
-    else {                                                                  // 24-bit multiply-add: |t23| <= 255, |ba23| <= 255
-        na = dot2(t01, sa.ba01, __mul24((int32_t)t23, (int32_t)sa.ba23) + sa.nc);
-        nb = dot2(t01, sc.ba01, __mul24((int32_t)t23, (int32_t)sc.ba23) + sc.nc);
-    }
-    const float xa = __builtin_fmaf((float)na, sa.k0, sa.k1), xb = __builtin_fmaf((float)nb, sc.k0, sc.k1);
-    const int32_t qa = imed3((int32_t)xa, 1, (1 << BITSA) - 1), qb = imed3((int32_t)xb, 1, (1 << BITSB) - 1);
-    const uint2* p0 = pa + (qa - 1) * PAL_STRIDE;
-    const uint2* p1 = pc + (qb - 1) * PAL_STRIDE;
+    const int32_t na = pal_project(sa, w), nb = pal_project(sc, w);
+    const int32_t qa = pal_lower_level<BITSA>(sa, na), qb = pal_lower_level<BITSB>(sc, nb);
+    const uint2* p0 = pa + qa * PAL_STRIDE;
+    const uint2* p1 = pc + qb * PAL_STRIDE;
     const uint2 la = p0[0], ha = p0[PAL_STRIDE], lb = p1[0], hb = p1[PAL_STRIDE];
     const uint32_t d0 = udot4(la.x, w, 0u), d1 = udot4(ha.x, w, 0u), d2 = udot4(lb.x, w, 0u), d3 = udot4(hb.x, w, 0u);
     const int32_t f0 = (int32_t)((d0 << 1) + la.y), f1 = (int32_t)((d1 << 1) + ha.y);
@@ -554,7 +588,7 @@ __device__ __forceinline__ void subset_error2_pal(int32_t& ta, int32_t& tc, cons
 #pragma unroll
     for (int k = 0; k < 16; k++)
         if ((mask >> k) & 1u)
-            texel_error2_pal<BITSA, BITSB, CH, PAL_STRIDE>(ta, tc, sa, pa, sc, pc, tx.w[k], tx.pair01(k), tx.template pair23<CH == 4>(k));
+            texel_error2_pal<BITSA, BITSB, CH, PAL_STRIDE>(ta, tc, sa, pa, sc, pc, tx.w[k]);
 }
 
 // Texels of one subset (wave-uniform mask) against one or two palettes; accumulates errors WITHOUT the |t|^2 terms.
@@ -566,7 +600,7 @@ __device__ __forceinline__ void select_subset_pal(uint32_t (&qb)[2], int32_t& to
     for (int k = 0; k < 16; k++) {
         if ((mask >> k) & 1u) {
             int32_t q, e;
-            select_texel_pal<BITS, CH, PAL_STRIDE>(q, e, sg, pal, tx.w[k], tx.pair01(k), tx.template pair23<CH == 4>(k));
+            select_texel_pal<BITS, CH, PAL_STRIDE>(q, e, sg, pal, tx.w[k]);
             if (k < 8) qb[0] |= (uint32_t)q << (4 * k); else qb[1] |= (uint32_t)q << (4 * (k - 8));
             total += e;
         }
@@ -580,10 +614,9 @@ __device__ __forceinline__ void select_subset2_pal(uint32_t (&qa)[2], int32_t& t
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         if ((mask >> k) & 1u) {
-            const uint32_t t01 = tx.pair01(k), t23 = tx.template pair23<CH == 4>(k);
             int32_t q0, e0, q1, e1;
-            select_texel_pal<BITSA, CH, PAL_STRIDE>(q0, e0, sa, pa, tx.w[k], t01, t23);
-            select_texel_pal<BITSB, CH, PAL_STRIDE>(q1, e1, sc, pc, tx.w[k], t01, t23);
+            select_texel_pal<BITSA, CH, PAL_STRIDE>(q0, e0, sa, pa, tx.w[k]);
+            select_texel_pal<BITSB, CH, PAL_STRIDE>(q1, e1, sc, pc, tx.w[k]);
             if (k < 8) { qa[0] |= (uint32_t)q0 << (4 * k); qc[0] |= (uint32_t)q1 << (4 * k); }
             else       { qa[1] |= (uint32_t)q0 << (4 * (k - 8)); qc[1] |= (uint32_t)q1 << (4 * (k - 8)); }
             ta += e0; tc += e1;
@@ -600,7 +633,7 @@ __device__ __forceinline__ int32_t select_block_pal(uint32_t (&qb)[2], const Tex
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         int32_t q, e;
-        select_texel_pal<BITS, CH, PAL_STRIDE>(q, e, sg, pal, tx.w[k], tx.pair01(k), tx.template pair23<CH == 4>(k));
+        select_texel_pal<BITS, CH, PAL_STRIDE>(q, e, sg, pal, tx.w[k]);
         if (k < 8) qb[0] |= (uint32_t)q << (4 * k); else qb[1] |= (uint32_t)q << (4 * (k - 8));
         total += e;
     }

@@ -22,6 +22,10 @@ namespace itw {
 #include "bc7_tables.h"
 #undef BCN_TABLE_QUAL
 
+// v_min_f32 / v_max_f32 as instructions (operands known to be numbers: no NaN quieting needed)
+__device__ __forceinline__ float vmin_raw(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float vmax_raw(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+
 // ---- partition table access (kernel.ispc:688-758) --------------------------
 struct Shape {
     uint32_t pattern;   // 2 bits / texel
@@ -204,8 +208,8 @@ __device__ __forceinline__ void fit_from_stats(float (&ep)[2][4], const TX& px, 
                 float dot = axis[0] * (px.get(0, k) - dc[0]);
                 #pragma unroll
                 for (int p = 1; p < CH; p++) dot += axis[p] * (px.get(p, k) - dc[p]);
-                lo = __builtin_fminf(lo, dot);
-                hi = __builtin_fmaxf(hi, dot);
+                lo = vmin_raw(lo, dot);                     // (fminf() would add a canonicalising v_max(x, x) per loop-carried operand)
+                hi = vmax_raw(hi, dot);
             }
         }
     }

@@ -123,6 +123,62 @@ def test_reference_index_is_floor_of_exact_ratio():
             assert reference_index(N, D, levels) == min(max(fl, 1), levels - 1), (N, D, levels)
 
 
+def palette_index_2bit(N, D):
+    """pal_lower_level<2> of bc7_exact.hpp (round 3): q1 = 1 + [N >= ceil(3D/8)] + [N >= ceil(5D/8)], each [..] the sign bit of
+    (th - 1 - N) in 32-bit arithmetic; D == 0 -> thresholds no N reaches."""
+    if D == 0:
+        th1 = th2 = 0x3fffffff
+    else:
+        th1, th2 = ((3 * D + 7) >> 3) - 1, ((5 * D + 7) >> 3) - 1
+    bit = lambda v: ((v & 0xffffffff) >> 31)
+    assert -2**31 <= th1 - N < 2**31 and -2**31 <= th2 - N < 2**31            # no wrap
+    return 1 + bit(th1 - N) + bit(th2 - N)
+
+
+def palette_index_3bit(N, D):
+    """pal_lower_level<3>: x' = fma(N, k0, k1'), k0 = -(8 * r), k1' = -0.25 * r, r = RN(1 / -D); the low mantissa bits of
+    RN(x' + (1.5 * 2^23 - 1)) are floor(y + 0.5) - 1, clamped to [0, 6] on the raw word."""
+    if D == 0:
+        k0 = k1 = Fraction(0)
+    else:
+        r = rn32(1 / Fraction(-D))
+        k0, k1 = -(8 * r), -(r / 4)
+        assert rn32(k0) == k0 and rn32(k1) == k1                                # exact scalings
+    x = rn32(Fraction(N) * k0 + k1)                                             # one FMA
+    s = rn32(x + 12582911)
+    assert 2**23 <= s < 2**24 and s.denominator == 1                            # ulp 1: the add rounds to an integer
+    word = 0x4b000000 + (int(s) - 2**23)                                        # float32 bits of s
+    K = 0x4b400000
+    assert 0x4b3fffff == 0x4b000000 + (12582911 - 2**23)
+    return min(max(word, K), K + 6) - K + 1
+
+
+def test_round3_palette_index_forms_equal_the_reference_index():
+    """The integer thresholds (2-bit indices) and the magic-number floor (3-bit) of the palette path give the reference's
+    index on the proofs' worst cases (y + 0.5 at and next to every integer, extreme D) and on random (N, D)."""
+    rng = np.random.default_rng(33)
+    for N, D in _cases(4, 260100, rng, 20000):
+        assert palette_index_2bit(N, D) == reference_index(N, D, 4), (N, D)
+    for N, D in _cases(8, 195075, rng, 8000):
+        assert palette_index_3bit(N, D) == reference_index(N, D, 8), (N, D)
+    # every D a 3-channel segment of small span can have, all N around all thresholds (dense for small D, where 1/(4D) is large)
+    for D in range(1, 400):
+        for N in range(-3, 3 * D + 3):
+            assert palette_index_2bit(N, D) == reference_index(N, D, 4), (N, D)
+            assert palette_index_3bit(N, D) == reference_index(N, D, 8), (N, D)
+
+
+def test_palette_endpoint_bytes_give_the_projection():
+    """N = sum (t-a)(b-a) = t.b - t.a - a.(b-a) (pal_project): two unsigned byte dot products and a constant, in 32-bit wrap-around."""
+    rng = np.random.default_rng(34)
+    a = rng.integers(0, 256, size=(5000, 4)); b = rng.integers(0, 256, size=(5000, 4)); t = rng.integers(0, 256, size=(5000, 4))
+    n_ref = ((t - a) * (b - a)).sum(axis=1)
+    nc = (-(a * (b - a)).sum(axis=1)) & 0xffffffff
+    n = (((t * b).sum(axis=1) + nc) - (t * a).sum(axis=1)) & 0xffffffff
+    n = np.where(n >= 2**31, n - 2**32, n)
+    assert np.array_equal(n, n_ref)
+
+
 def _header(name):
     return open(os.path.join(CSRC, name)).read()
 
