@@ -14,40 +14,57 @@
 //
 // Arithmetic is the pinned x86 model of x86_math.hpp; float sums run serially in
 // texel order k = 0..15 inside the lane, exactly like one ISPC program instance.
+#include <cstdlib>
 #include "x86_math.hpp"
 #include "kernels.hpp"
+
+// A/B switches of tools/gpu_probe_bc1.sh (separate builds; the product build leaves them at their defaults)
+#ifndef ITW_BC1_PK
+#define ITW_BC1_PK 1             // projections / channel sums on v_pk_mul_f32 / v_pk_add_f32
+#endif
+#ifndef ITW_BC1_FQUANT
+#define ITW_BC1_FQUANT 1         // index clamp / floor / packing in the float domain
+#endif
+#ifndef ITW_BC1_ASMCVT
+#define ITW_BC1_ASMCVT 1         // texel bytes -> float as v_cvt_f32_ubyteN instructions
+#endif
+#ifndef ITW_BC1_EARLYLOAD
+#define ITW_BC1_EARLYLOAD 1      // first chunk's texel loads issued before the table staging
+#endif
+#ifndef ITW_BC1_WAVES
+#define ITW_BC1_WAVES 4          // waves per SIMD the register allocation targets
+#endif
+#ifndef ITW_BC1_PROBE
+#define ITW_BC1_PROBE 0          // 0 = product.  1..3: measurement probes of tools/gpu_probe_bc1.sh (separate builds)
+#endif
 
 namespace itw {
 
 // ---- per-workgroup tables in LDS ------------------------------------------------------------------------------------
 // The kernel is bound by VALU issue, not by HBM: every instruction that is not one of the reference's
-// fp32 multiplies / adds is overhead worth removing.  Three table families, staged once per workgroup (the workgroup then
+// fp32 multiplies / adds is overhead worth removing.  Two table families, staged once per workgroup (the workgroup then
 // walks several chunks of 256 blocks, so the staging is amortised):
-//   * RSQRTPS seeds pre-expanded to words (x86_math.hpp, as in the BC7 kernels);
-//   * RCPPS seeds pre-expanded the same way: a reciprocal seed of an ordinary operand is one LDS word minus the operand's
-//     exponent field (x86_rcpps_fast below), instead of ~20 bit operations and three special-case selects;
+//   * RCPPS / RSQRTPS seeds, packed to 16 bit as generated (x86_luts_packed.h); a lookup is one LDS read, one v_lshl_or to
+//     rebuild the seed word and one subtraction of the operand's exponent field;
 //   * 8 bit -> 5/6 bit endpoint quantisation (kernel.ispc:234-248: (t + (t >> 8)) >> 8 with t = v*31 + 128) and the
 //     decoded value of the code (kernel.ispc:250-259: bit replication), as two byte tables each, indexed by the
 //     truncated endpoint: packing an endpoint is a conversion and a byte read per channel.
-// The expanded seed words and the 565 tables as one ready-made image (21 KiB), built at compile time from the packed
-// seed tables: a workgroup stages it with plain 16-byte copies.
+// One ready-made image (9 KiB), built at compile time: a workgroup stages it with plain 16-byte copies.
 namespace tables_src {
 #define X86_LUT_QUAL static constexpr
 #include "x86_luts_packed.h"
 #undef X86_LUT_QUAL
 }
 struct Bc1Image {
-    uint32_t rsq32[2048];       // x86_rsqrtps_fast's words (x86_math.hpp stage_seed_tables_fast)
-    uint32_t rcp32[2048];       // RCPPS seed mantissa | exponent field 253
-    unsigned short rcp16[2048]; // packed RCPPS seeds for the general model
+    unsigned short rsq16[2048]; // RSQRTPS seeds, indexed by bits [23:13] of the operand (exponent LSB, top 10 mantissa bits)
+    unsigned short rcp16[2048]; // RCPPS seeds, indexed by mantissa[22:12]
     uint8_t q[1024];            // q5 | q6 | d5 | d6
 };
 constexpr Bc1Image make_bc1_image()
 {
     Bc1Image im{};
     for (int i = 0; i < 2048; i++) {
-        im.rsq32[i] = (0x3f000000u | ((uint32_t)tables_src::X86_RSQRT_SEED16[i ^ 0x400] << 11)) + 0x20000000u;
-        im.rcp32[i] = 0x7e800000u | ((uint32_t)tables_src::X86_RCP_SEED16[i] << 11);
+        im.rsq16[i] = tables_src::X86_RSQRT_SEED16[i ^ 0x400];
         im.rcp16[i] = tables_src::X86_RCP_SEED16[i];
     }
     for (int v = 0; v < 256; v++) {
@@ -59,11 +76,14 @@ constexpr Bc1Image make_bc1_image()
     return im;
 }
 __device__ const Bc1Image BC1_IMAGE = make_bc1_image();
-static_assert(sizeof(Bc1Image) == 8192 + 8192 + 4096 + 1024, "Bc1Image layout");
+static_assert(sizeof(Bc1Image) == 4096 + 4096 + 1024, "Bc1Image layout");
 
+// Round 3: the image is 9 KiB (was 21): the seeds stay packed to 16 bit and a lookup expands its word with one v_lshl_or.
+// At launch every workgroup of the chip copies the image at the same time and nothing overlaps that copy but the first
+// texel loads: measured 2.4 us of a 29 us BC1 launch for 21 KiB x 2048 workgroups (tools/gpu_probe_bc1.sh).
 struct Bc1Tables {
-    SeedTables T;
-    const uint32_t* rcp32;      // [2048] RCPPS seed word | exponent 253, indexed by mantissa[22:12]
+    const unsigned short* rsq16;
+    const unsigned short* rcp16;
     const uint8_t* q5;          // [256]  5-bit code of a byte value
     const uint8_t* q6;          // [256]  6-bit code
     const uint8_t* d5;          // [256]  value a decoder reconstructs from q5[v]
@@ -79,36 +99,20 @@ __device__ __forceinline__ Bc1Tables stage_bc1_tables(unsigned char* lds, int ti
     for (int i = tid; i < BC1_LDS_BYTES / 16; i += nthreads) dst[i] = src[i];
     const Bc1Image* im = reinterpret_cast<const Bc1Image*>(lds);
     Bc1Tables B;
-    B.T = SeedTables{im->rcp16, X86_RSQRT_SEED16, im->rsq32};
-    B.rcp32 = im->rcp32; B.q5 = im->q; B.q6 = im->q + 256; B.d5 = im->q + 512; B.d6 = im->q + 768;
+    B.rsq16 = im->rsq16; B.rcp16 = im->rcp16;
+    B.q5 = im->q; B.q6 = im->q + 256; B.d5 = im->q + 512; B.d6 = im->q + 768;
     return B;
 }
 
-// RCPPS of an ordinary operand (exponent field 1..252, either sign): the seed's exponent is 253 - e and its mantissa
-// comes from the table, i.e. seed = word(mantissa[22:12]) - (e << 23), sign copied.  Zero, denormal, huge, inf and NaN
-// operands take the general model (x86_math.hpp) in a divergent branch.  Same function as x86_rcpps for every input.
-__device__ __forceinline__ float x86_rcpps_fast(float v, const Bc1Tables& B)
-{
-    const uint32_t x = __float_as_uint(v);
-    const uint32_t ax = x & 0x7fffffffu;
-    if (__builtin_expect((ax - 0x00800000u) >= 0x7e000000u, 0)) return x86_rcpps(v, B.T.rcp);
-    const uint32_t t = B.rcp32[(x >> 12) & 0x7ffu];
-    return __uint_as_float((t - (ax & 0x7f800000u)) | (x & 0x80000000u));
-}
-__device__ __forceinline__ float rcp_nr(float v, const Bc1Tables& B)               // ISPC rcp(): r * (2 - v*r)
-{
-    const float r = x86_rcpps_fast(v, B);
-    float t = v * r;
-    t = 2.0f - t;
-    return r * t;
-}
-// The same for an operand known to be a positive ordinary number (exponent field 1..252), or +0 where the caller shows the
-// result does not matter: no range test, no divergent branch, no sign handling -- 4 VALU operations + one LDS read for the
-// seed.  For +0 the seed comes out as a finite 2^126-sized number instead of +inf.
+// ISPC rcp(v) = r * (2 - v*r) on the RCPPS seed r, for an operand known to be a positive ordinary number (exponent field
+// 1..252: the seed's exponent is 253 - e, its mantissa the table's, i.e. seed = (0x7e800000 | s16 << 11) - (e << 23)), or +0
+// where the caller shows the result does not matter: no range test, no divergent branch, no sign handling -- the general
+// model (x86_math.hpp x86_rcpps: zero, denormal, huge, inf, NaN, negative operands) is never needed in this kernel, each
+// call site says why.  For +0 the seed comes out as a finite 2^126-sized number instead of +inf.
 __device__ __forceinline__ float rcp_nr_pos(float v, const Bc1Tables& B)
 {
     const uint32_t x = __float_as_uint(v);
-    const uint32_t t = B.rcp32[(x >> 12) & 0x7ffu];
+    const uint32_t t = 0x7e800000u | ((uint32_t)B.rcp16[(x >> 12) & 0x7ffu] << 11);
     const float r = __uint_as_float(t - (x & 0x7f800000u));
     float u = v * r;
     u = 2.0f - u;
@@ -118,7 +122,7 @@ __device__ __forceinline__ float rcp_nr_pos(float v, const Bc1Tables& B)
 __device__ __forceinline__ float rsqrt_nr_pos(float v, const Bc1Tables& B)
 {
     const uint32_t x = __float_as_uint(v);
-    const uint32_t t = B.T.rsqrt32[(x >> 13) & 0x7ffu];
+    const uint32_t t = 0x5f000000u | ((uint32_t)B.rsq16[(x >> 13) & 0x7ffu] << 11);      // seed | 0.5's exponent, + 64 << 23
     const float is = __uint_as_float(t - (((x + 0x00800000u) >> 1) & 0x7f800000u));
     float a = v * is;
     a = a * is;
@@ -129,6 +133,9 @@ __device__ __forceinline__ float rsqrt_nr_pos(float v, const Bc1Tables& B)
 
 template <int N> __device__ __forceinline__ float ubyte_f32(uint32_t w)
 {
+#if !ITW_BC1_ASMCVT
+    return (float)((w >> (8 * N)) & 255u);
+#endif
     float d;
     if (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d) : "v"(w));
     if (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d) : "v"(w));
@@ -211,18 +218,44 @@ __device__ __forceinline__ uint32_t project_indices(const Texels& px, const Endp
     float bias = 0.5f;
     for (int p = 0; p < 3; p++) bias -= e0.dec[p] * dir[p];
 
+    // The products run two per instruction (v_pk_mul_f32: the same IEEE multiply per half) -- (R, G) of a texel against
+    // (dir0, dir1), B of a texel pair against dir2 -- and the sums keep the reference's order: (R*d0 + G*d1) + B*d2, then + bias.
+    const f2 d01 = {dir[0], dir[1]}, d22 = {dir[2], dir[2]};
     float half[2] = {0.f, 0.f};
+    uint32_t ibits = 0; (void)ibits;
 #pragma unroll
-    for (int k = 15; k >= 0; k--) {                  // Horner: texel k ends up at bits 2k
-        float dot = px.r(k) * dir[0];                // the reference's 0 + a = a: exact (the sign of a zero cannot reach q)
-        dot += px.g(k) * dir[1]; dot += px.b(k) * dir[2];
-        const float q = __builtin_floorf(fclamp_num(dot + bias, 0.f, 3.f));
-        if (WANT_Q) { if (k & 1) qf[k >> 1].y = q; else qf[k >> 1].x = q; }
-        float& h = half[k >> 3];
-        h = h * 4.0f;
-        h = h + q;
+    for (int j = 7; j >= 0; j--) {                   // Horner: texel k ends up at bits 2k
+        const f2 bb = px.b2[j] * d22;
+#pragma unroll
+        for (int t = 1; t >= 0; t--) {
+            const int k = 2 * j + t;
+#if ITW_BC1_PK
+            const f2 m = px.rg[k] * d01;
+            float dot = m.x + m.y;                   // the reference's 0 + a = a: exact (the sign of a zero cannot reach q)
+            dot += t ? bb.y : bb.x;
+#else
+            float dot = px.r(k) * dir[0];
+            dot += px.g(k) * dir[1]; dot += px.b(k) * dir[2];
+#endif
+#if ITW_BC1_FQUANT
+            const float q = __builtin_floorf(fclamp_num(dot + bias, 0.f, 3.f));
+            if (WANT_Q) { if (t) qf[j].y = q; else qf[j].x = q; }
+            float& h = half[k >> 3];
+            h = h * 4.0f;
+            h = h + q;
+#else
+            const int32_t qi = iclamp(cvt_i32_sat(dot + bias), 0, 3);
+            ibits |= (uint32_t)qi << (2 * k);
+            if (WANT_Q) { if (t) qf[j].y = (float)qi; else qf[j].x = (float)qi; }
+#endif
+        }
     }
+#if ITW_BC1_FQUANT
     return (uint32_t)half[0] | ((uint32_t)half[1] << 16);
+#else
+    (void)half;
+    return ibits;
+#endif
 }
 
 // Least-squares endpoint update for fixed indices.               [kernel.ispc:419-480]
@@ -266,13 +299,25 @@ __device__ __forceinline__ void refit_endpoints(float (&c0)[3], float (&c1)[3], 
 // [kernel.ispc:494-533]
 __device__ __forceinline__ void encode_color(const Texels& px, uint32_t out[2], const Bc1Tables& B)
 {
+    // channel sums: integers <= 4080, exact in any order -- packed adds over the (R, G) pairs and the B pairs
     float acc[3], dc[3];
-    for (int p = 0; p < 3; p++) {
-        float a = px.ch(p, 0);
+    {
+#if ITW_BC1_PK
+        f2 srg = px.rg[0], sbb = px.b2[0];
 #pragma unroll
-        for (int k = 1; k < 16; k++) a += px.ch(p, k);
-        acc[p] = a;                                  // an integer <= 4080: exact
-        dc[p] = a * 0.0625f;
+        for (int k = 1; k < 16; k++) srg = srg + px.rg[k];
+#pragma unroll
+        for (int j = 1; j < 8; j++) sbb = sbb + px.b2[j];
+        acc[0] = srg.x; acc[1] = srg.y; acc[2] = sbb.x + sbb.y;
+#else
+        for (int p = 0; p < 3; p++) {
+            float a = px.ch(p, 0);
+#pragma unroll
+            for (int k = 1; k < 16; k++) a += px.ch(p, k);
+            acc[p] = a;
+        }
+#endif
+        for (int p = 0; p < 3; p++) dc[p] = acc[p] * 0.0625f;
     }
 
     // packed symmetric covariance  [rr rg rb gg gb bb]          [kernel.ispc:377-417]
@@ -310,13 +355,26 @@ __device__ __forceinline__ void encode_color(const Texels& px, uint32_t out[2], 
     // extreme projections -> endpoints                           [kernel.ispc:274-306]
     // The projections are finite (the diagonal carries +0.001, so the iteration never meets a zero or overflowing norm):
     // minps / maxps are ordinary minimum / maximum here; only the sign of a zero could differ and it is added to dc >= 0.
+    // Two differences and two products per instruction (v_pk_add_f32 / v_pk_mul_f32), sums in the reference's order.
     float lo = 65536.0f, hi = 0.0f;
+    const f2 v01 = {v[0], v[1]}, v22 = {v[2], v[2]}, dc22 = {dc[2], dc[2]};
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        float dot = (px.r(k) - dc[0]) * v[0];
-        dot += (px.g(k) - dc[1]) * v[1]; dot += (px.b(k) - dc[2]) * v[2];
-        lo = __builtin_fminf(lo, dot);
-        hi = __builtin_fmaxf(hi, dot);
+    for (int j = 0; j < 8; j++) {
+        const f2 bb = (px.b2[j] - dc22) * v22;
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+#if ITW_BC1_PK
+            const f2 m = (px.rg[2 * j + t] - dc_rg) * v01;
+            float dot = m.x + m.y;
+            dot += t ? bb.y : bb.x;
+#else
+            const int k = 2 * j + t;
+            float dot = (px.r(k) - dc[0]) * v[0];
+            dot += (px.g(k) - dc[1]) * v[1]; dot += (px.b(k) - dc[2]) * v[2];
+#endif
+            lo = __builtin_fminf(lo, dot);
+            hi = __builtin_fmaxf(hi, dot);
+        }
     }
     if (hi - lo < 1.0f) { lo -= 0.5f; hi += 0.5f; }
 
@@ -359,22 +417,29 @@ __device__ __forceinline__ uint32_t dxt5_order_8x3(uint32_t u)     // eight 3-bi
     const uint32_t all = (q & (q >> 1) & (q >> 2)) & ones;         // q == 7
     return ((q & ~(all * 7u)) + (any & ~all)) | all;               // 7 -> 1, 0 -> 0, else + 1 (no carries: at most 6 + 1)
 }
-__device__ __forceinline__ void encode_alpha(const float (&a)[16], uint32_t out[2], const Bc1Tables& B)
+__device__ __forceinline__ void encode_alpha(const f2 (&a)[8], uint32_t out[2], const Bc1Tables& B)
 {
     float lo = 255.f, hi = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo = __builtin_fminf(lo, a[k]); hi = __builtin_fmaxf(hi, a[k]); }   // minps / maxps of ordinary numbers (bytes)
+    for (int j = 0; j < 8; j++) {                                   // minps / maxps of ordinary numbers (bytes)
+        lo = __builtin_fminf(lo, a[j].x); hi = __builtin_fmaxf(hi, a[j].x);
+        lo = __builtin_fminf(lo, a[j].y); hi = __builtin_fmaxf(hi, a[j].y);
+    }
     if (lo == hi) hi = lo + 0.1f;
     const float scale = 7.0f * rcp_nr_pos(hi - lo, B);   // hi - lo in [0.1, 255]
 
+    const f2 lo2 = {lo, lo}, sc2 = {scale, scale}, h2 = {0.5f, 0.5f};
     float half[2] = {0.f, 0.f};
 #pragma unroll
-    for (int k = 15; k >= 0; k--) {
-        const float x = (a[k] - lo) * scale + 0.5f;                 // hi - lo >= 0.1: finite, in [0.5, 7.6]
-        const float u = __builtin_floorf(vmin_raw(x, 7.0f));
-        float& h = half[k >> 3];
-        h = h * 8.0f;
-        h = h + u;
+    for (int j = 7; j >= 0; j--) {
+        const f2 x = (a[j] - lo2) * sc2 + h2;                       // hi - lo >= 0.1: finite, in [0.5, 7.6]; two texels per instruction
+#pragma unroll
+        for (int t = 1; t >= 0; t--) {
+            const float u = __builtin_floorf(vmin_raw(t ? x.y : x.x, 7.0f));
+            float& h = half[j >> 2];
+            h = h * 8.0f;
+            h = h + u;
+        }
     }
     const uint32_t q0 = dxt5_order_8x3((uint32_t)half[0]), q1 = dxt5_order_8x3((uint32_t)half[1]);   // 8 x 3 bits each
     out[0] = (uint32_t)(iclamp(cvt_i32_sat(lo), 0, 255) * 256 + iclamp(cvt_i32_sat(hi), 0, 255)) | (q0 << 16);
@@ -400,26 +465,64 @@ __device__ __forceinline__ void load_words(uint32_t (&w)[16], const uint8_t* __r
 }
 
 template <bool BC3, bool VEC16>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITW_BC1_WAVES, ITW_BC1_WAVES)))
 bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_tables[BC1_LDS_BYTES];
+#if ITW_BC1_PROBE == 1 || ITW_BC1_PROBE == 3
+    // measurement probe (tools/gpu_probe_bc1.sh, never in the product build): the kernel's memory side alone -- same grid,
+    // same loads and stores, no encode (3: no table staging either)
+    {
+#if ITW_BC1_PROBE == 1
+        const Bc1Tables Bp = stage_bc1_tables(s_tables, threadIdx.x, 256);
+        __syncthreads();
+        const uint32_t salt = Bp.q5[threadIdx.x & 255];
+#else
+        const uint32_t salt = 0;
+#endif
+        for (int32_t b0 = blockIdx.x * 256; b0 < nblocks; b0 += gridDim.x * 256) {
+            const int32_t cur = b0 + threadIdx.x;
+            uint32_t w[16];
+            load_words<VEC16>(w, src, stride, blocks_x, cur < nblocks ? cur : nblocks - 1);
+            uint32_t o[4] = {salt, 0, 0, 0};
+            for (int k = 0; k < 16; k++) o[k & 3] ^= w[k];
+            if (cur < nblocks) {
+                if (BC3) *reinterpret_cast<uint4*>(dst + (int64_t)cur * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<uint2*>(dst + (int64_t)cur * 8) = make_uint2(o[0] ^ o[2], o[1] ^ o[3]);
+            }
+        }
+        return;
+    }
+#endif
     // The first chunk's texels are requested BEFORE the tables are staged: at launch every wave of the chip stands in this
     // prologue at once, and the HBM round trip of the texels then runs under the 21 KiB table copy instead of after it.
     int32_t base = blockIdx.x * 256;
     uint32_t w[16];
+#if ITW_BC1_EARLYLOAD
+    {
+        const int32_t cur = base + threadIdx.x;
+#if ITW_BC1_PROBE == 2
+        // measurement probe: the kernel's arithmetic alone -- texels made up from the block index, no global loads
+        for (int k = 0; k < 16; k++) w[k] = ((uint32_t)cur * 2654435761u) ^ ((uint32_t)k * 0x9e3779b9u);
+#else
+        load_words<VEC16>(w, src, stride, blocks_x, cur < nblocks ? cur : nblocks - 1);
+#endif
+    }
+#endif
+    const Bc1Tables B = stage_bc1_tables(s_tables, threadIdx.x, 256);
+    __syncthreads();
+#if !ITW_BC1_EARLYLOAD
     {
         const int32_t cur = base + threadIdx.x;
         load_words<VEC16>(w, src, stride, blocks_x, cur < nblocks ? cur : nblocks - 1);
     }
-    const Bc1Tables B = stage_bc1_tables(s_tables, threadIdx.x, 256);
-    __syncthreads();
+#endif
     for (;;) {
         const int32_t cur = base + threadIdx.x;
         // (requesting the NEXT chunk's texels before encoding this one was measured: the 16 extra live registers cost more
         // than the hidden latency gains -- four waves per SIMD already overlap each other's loads)
         Texels px;
-        float al[16];
+        f2 al[8];
         // one v_cvt_f32_ubyteN per channel, as instructions: from C++ the compiler recognises sums of converted bytes as integer
         // sums and rebuilds them from v_bfe / v_add3 / v_cvt_f32_u32 (4-cycle forms) instead of 2-cycle float adds
 #pragma unroll
@@ -427,7 +530,7 @@ bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
             px.rg[k].x = ubyte_f32<0>(w[k]);
             px.rg[k].y = ubyte_f32<1>(w[k]);
             if (k & 1) px.b2[k >> 1].y = ubyte_f32<2>(w[k]); else px.b2[k >> 1].x = ubyte_f32<2>(w[k]);
-            if (BC3) al[k] = ubyte_f32<3>(w[k]);
+            if (BC3) { if (k & 1) al[k >> 1].y = ubyte_f32<3>(w[k]); else al[k >> 1].x = ubyte_f32<3>(w[k]); }
         }
 
         if (BC3) {
@@ -451,17 +554,29 @@ bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
         base += gridDim.x * 256;
         if (base >= nblocks) break;                                    // wave-uniform
         const int32_t nxt = base + threadIdx.x;
+#if ITW_BC1_PROBE == 2
+        for (int k = 0; k < 16; k++) w[k] = ((uint32_t)nxt * 2654435761u) ^ ((uint32_t)k * 0x9e3779b9u);
+#else
         load_words<VEC16>(w, src, stride, blocks_x, nxt < nblocks ? nxt : nblocks - 1);
+#endif
     }
 }
 
-// Persistent workgroups: at most 2048 (two per resident slot at 4 waves per SIMD), each walking chunks of 256 blocks, so a
-// 4096^2 surface stages the 21 KiB table image 2048 times instead of 4096 (measured: 1024 / 1536 / 2048 / 4096 workgroups
-// within 3 % of each other; 2048 best for BC3).
+// Persistent workgroups: at most 2048 (two per resident slot at 4 waves per SIMD), each walking chunks of 256 blocks (measured
+// round 3, tools/gpu_probe_bc1.sh: 1024 / 1536 / 2048 workgroups 29.4 / 28.7 / 28.9 us BC1 and 32.8 / 30.9 / 31.1 us BC3 at 4096^2).
+#ifndef ITW_BC13_GRID
+#define ITW_BC13_GRID 2048
+#endif
+// measurement knob (tools/gpu_probe_bc1.sh): dynamic LDS bytes added to every launch, to cap the workgroups a CU can hold
+static unsigned bc13_lds_pad()
+{
+    static const unsigned pad = [] { const char* e = std::getenv("ITW_BC13_LDS_PAD"); return e ? (unsigned)std::atoi(e) : 0u; }();
+    return pad;
+}
 static unsigned bc13_grid(int64_t n)
 {
     const int64_t chunks = (n + 255) / 256;
-    return (unsigned)(chunks < 2048 ? chunks : 2048);
+    return (unsigned)(chunks < ITW_BC13_GRID ? chunks : ITW_BC13_GRID);
 }
 
 // VEC16 requires: src base and stride multiples of 16, dst multiple of 16 (BC3) / 8 (BC1).
@@ -472,8 +587,8 @@ void launch_bc1(const uint8_t* src, int64_t stride, int width, int height, uint8
     if (n <= 0) return;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
     const dim3 grid(bc13_grid(n)), blk(256);
-    if (vec) hipLaunchKernelGGL((bc13_kernel<false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
-    else     hipLaunchKernelGGL((bc13_kernel<false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+    if (vec) hipLaunchKernelGGL((bc13_kernel<false, true>),  grid, blk, bc13_lds_pad(), st, src, stride, bx, (int32_t)n, dst);
+    else     hipLaunchKernelGGL((bc13_kernel<false, false>), grid, blk, bc13_lds_pad(), st, src, stride, bx, (int32_t)n, dst);
 }
 
 void launch_bc3(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st)
@@ -483,8 +598,8 @@ void launch_bc3(const uint8_t* src, int64_t stride, int width, int height, uint8
     if (n <= 0) return;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const dim3 grid(bc13_grid(n)), blk(256);
-    if (vec) hipLaunchKernelGGL((bc13_kernel<true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
-    else     hipLaunchKernelGGL((bc13_kernel<true, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+    if (vec) hipLaunchKernelGGL((bc13_kernel<true, true>),  grid, blk, bc13_lds_pad(), st, src, stride, bx, (int32_t)n, dst);
+    else     hipLaunchKernelGGL((bc13_kernel<true, false>), grid, blk, bc13_lds_pad(), st, src, stride, bx, (int32_t)n, dst);
 }
 
 } // namespace itw
