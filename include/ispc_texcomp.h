@@ -22,8 +22,11 @@
  *       8 bytes/block for BC1, 16 bytes/block for BC3/BC7/BC6H
  *     (kernel.ispc:582,595,2027,3129; the "4/8 bytes" remark in the reference
  *     header is off by 2x).
- *   - void return, no errno: on any HIP failure the library prints a diagnostic
- *     and abort()s.  There is no CPU fallback.
+ *   - void return, no errno.  There is no CPU fallback: a HIP failure (no device, out of
+ *     memory, bad pointer) either prints a diagnostic and abort()s (the default: loud,
+ *     never a silently wrong texture) or, after itwSetErrorMode(ITW_ON_ERROR_RETURN)
+ *     (include/itw_amd.h), makes the call return with the message kept per host thread in
+ *     itwLastError(); itwAvailable() lets a host decide before it calls.
  *   - re-entrant; may be called concurrently from many host threads on disjoint
  *     row bands (win32Threads.cpp:211-274 does exactly that).
  *

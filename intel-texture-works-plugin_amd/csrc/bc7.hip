@@ -1226,8 +1226,11 @@ bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, 
 // skipped where they cannot win: PHASE 1 = the alpha-capable modes 7,4,5,6 (their relative order kept), leaves the block and
 // its error; PHASE 2 = modes 0,2,1,3 for the waves that still need them, then the reference's choice between the two groups:
 // the first strict minimum over 0,2,1,3,7,4,5,6 is the RGB group's winner iff its error <= the alpha group's.
+#ifndef FINISH_ALL_WAVES
+#define FINISH_ALL_WAVES 2
+#endif
 template <bool VEC16, int PHASE>
-__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FINISH_ALL_WAVES, FINISH_ALL_WAVES)))
 bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst,
                const uint32_t* __restrict__ wins4, const bc7_enc_settings S, int32_t* __restrict__ alpha_err)
 {

@@ -90,7 +90,7 @@ def lib():
 
 # Arithmetic-model variants of the oracle (x86_math.h switches; `make -C oracle variants`).  Study material only
 # (tools/arith_sensitivity.py, tests/test_arith_models.py): parity is always against the default model.
-VARIANTS = ("div1158rcp", "ieee", "fma", "ieee_fma")
+VARIANTS = ("div1158rcp", "ieee", "fma", "ieee_fma", "reassoc")
 _override = None
 _variant_libs = {}
 

@@ -31,6 +31,10 @@ def _ensure_ref(name):
     p = os.path.join(REF, name)
     if not os.path.exists(p):
         if not os.path.exists(REFERENCE_TREE):
+            if os.path.exists("/dev/kfd") and os.environ.get("ITW_ALLOW_NO_REF") != "1":
+                # a GPU box: the prebuilt checkers are part of what must travel (no silent downgrade)
+                pytest.fail(f"oracle/_ref/{name} did not travel to this GPU box (build in the container: make -C oracle/ref_build; "
+                            "ITW_ALLOW_NO_REF=1 to run without)")
             pytest.skip(f"oracle/_ref/{name} not prebuilt and /root/reference absent")
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle", "ref_build")], check=True)
@@ -195,3 +199,46 @@ def test_reference_dispatch_code_drives_the_product_unchanged(gpu, oracle, tmp_p
     for mode in ("mt", "st"):
         got, _ = _run_threads_caller(exe, mode, tramp, img, tmp_path, workers)
         assert first_mismatch(got, want, bpb) is None, (mode, first_mismatch(got, want, bpb))
+
+
+def test_prepass_oracle_equals_the_reference_scalar_conversions(oracle):
+    """oracle/prepass.c (the checker of csrc/convert.hip) was a restatement nothing reference-held pinned.
+    oracle/_ref/libintelplugin_convert_ref.so is IntelPlugin.h:31-96 compiled from where it lies (F32toF16 / FloatToByte /
+    ConvertTo8Bit x 3 / ConvertTo16Bit x 3; typedef shim for the Photoshop SDK's scalar types, DirectXMath half conversions
+    from dxmath_stub/).  Exhaustive over the 8- and 16-bit sources, a dense sample incl. every special class for the 32-bit
+    ones -- byte for byte, the gamma path too (same libm on the same host)."""
+    L = C.CDLL(_ensure_ref("libintelplugin_convert_ref.so"))
+    L.ref_convert8_from8.argtypes = [C.c_uint8]; L.ref_convert8_from8.restype = C.c_uint8
+    L.ref_convert8_from16.argtypes = [C.c_uint16]; L.ref_convert8_from16.restype = C.c_uint8
+    L.ref_convert8_from32.argtypes = [C.c_float, C.c_int]; L.ref_convert8_from32.restype = C.c_uint8
+    L.ref_convert16_from8.argtypes = [C.c_uint8]; L.ref_convert16_from8.restype = C.c_uint16
+    L.ref_convert16_from16.argtypes = [C.c_uint16]; L.ref_convert16_from16.restype = C.c_uint16
+    L.ref_convert16_from32.argtypes = [C.c_float]; L.ref_convert16_from32.restype = C.c_uint16
+    O = oracle.lib()
+
+    def via_oracle8(src, depth, gamma=0):
+        out = np.zeros((src.size, 4), np.uint8)
+        O.oracle_convert_rgba8(src.ctypes.data_as(C.c_void_p), depth, 1, 0, gamma, src.size, 1, out.ctypes.data_as(C.c_void_p))
+        assert (out[:, 1:3] == 0).all() and (out[:, 3] == 255).all()
+        return out[:, 0]
+
+    def via_oracle16(src, depth):
+        out = np.zeros((src.size, 4), np.uint16)
+        O.oracle_convert_rgba16f(src.ctypes.data_as(C.c_void_p), depth, 1, 0, src.size, 1, out.ctypes.data_as(C.c_void_p))
+        assert (out[:, 1:3] == 0).all() and (out[:, 3] == 0x3c00).all()
+        return out[:, 0]
+
+    b = np.arange(256, dtype=np.uint8)
+    assert np.array_equal(via_oracle8(b, 8), np.array([L.ref_convert8_from8(int(v)) for v in b], np.uint8))
+    assert np.array_equal(via_oracle16(b, 8), np.array([L.ref_convert16_from8(int(v)) for v in b], np.uint16))
+    w = np.arange(65536, dtype=np.uint16)                               # Photoshop's 0..32768 range and everything above it
+    assert np.array_equal(via_oracle8(w, 16), np.array([L.ref_convert8_from16(int(v)) for v in w], np.uint8))
+    assert np.array_equal(via_oracle16(w, 16), np.array([L.ref_convert16_from16(int(v)) for v in w], np.uint16))
+    rng = np.random.default_rng(8)
+    f = np.concatenate([np.linspace(-0.25, 1.25, 20001), rng.uniform(0, 1, 20000), np.exp2(rng.uniform(-30, 15.9, 20000)),
+                        -np.exp2(rng.uniform(-30, 15.9, 2000)), [0.0, -0.0, 1.0, 65504.0, 6.1e-5, 5.96e-8, 2.9e-8, 1e-10]]).astype(np.float32)
+    for gamma in (0, 1):
+        src = f[f >= 0] if gamma else f                                 # pow of a negative base is NaN: its byte cast is unspecified
+        assert np.array_equal(via_oracle8(src, 32, gamma), np.array([L.ref_convert8_from32(float(v), gamma) for v in src], np.uint8)), gamma
+    fin = f[np.abs(f) <= 65504.0]                                       # beyond: DirectXMath releases disagree (oracle/prepass.c header)
+    assert np.array_equal(via_oracle16(fin, 32), np.array([L.ref_convert16_from32(float(v)) for v in fin], np.uint16))

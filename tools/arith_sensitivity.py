@@ -9,6 +9,8 @@ inputs, per format and preset:
     ieee         rcp = 1.0f/v, rsqrt = 1.0f/sqrtf(v) (what an AMD host CPU or a portable build would be closest to)
     fma          gcc -ffp-contract=fast -mfma (the avx2 target's licence to fuse; gcc's choice of sums to fuse)
     ieee_fma     both
+    reassoc      gcc -fassociative-math -freciprocal-math (-fno-signed-zeros -fno-trapping-math): sums and products may be
+                 re-associated, reciprocals folded -- the other thing `--opt=fast-math` could license in LLVM
 
 Output: a table of "% of blocks whose bytes differ from the pinned model" -> profiles/arith_sensitivity.txt.
 Every variant is a legal encoding of the same quality class; the point is how far "bit-exact vs the ISPC binary" could

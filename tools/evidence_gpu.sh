@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence, one gpurun call:  tools/evidence_gpu.sh <tag>   -> gpurun_out/evidence_<tag>/ (+ gpurun_out/prof_<tag>/)
 # Then in the build container: python tools/summarize_profiles.py <tag>; cp gpurun_out/evidence_<tag>/* profiles/ (named <tag>_*).
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/evidence_$TAG; mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -q > $OUT/pytest_gpu.log 2>&1; tail -2 $OUT/pytest_gpu.log

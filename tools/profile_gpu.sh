@@ -32,9 +32,12 @@ for wl in bc1 bc3 bc4 bc5 bc7_slow bc6h_slow; do
     rm -rf $OUT/pmc_${wl}_$ctr
   done
 done
-# 3. SQ counters for the BC7 kernels (VALU instruction counts, wave cycles)
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- python $ROOT/bench.py --workload bc7_slow --no-formats --no-cpu --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_sq.log
-f=$(find $OUT/pmc_sq -name '*counter_collection*.csv' | head -1)
-if [ -n "$f" ]; then head -1 $f > $OUT/pmc_sq_bc7.csv; grep -E 'bc7_' $f | head -400 >> $OUT/pmc_sq_bc7.csv; fi
-rm -rf $OUT/pmc_sq
+# 3. SQ counters (VALU instruction counts, wave cycles) per workload: the roofline that binds for every format
+for wl in bc7_slow bc7_alpha_slow bc6h_slow bc1 bc3 bc4 bc5; do
+  rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- python $ROOT/bench.py --workload $wl --no-formats --no-cpu --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_sq_$wl.log
+  f=$(find $OUT/pmc_sq -name '*counter_collection*.csv' | head -1)
+  if [ -n "$f" ]; then head -1 $f > $OUT/pmc_sq_$wl.csv; grep -E "$KERNELS" $f | head -600 >> $OUT/pmc_sq_$wl.csv; fi
+  rm -rf $OUT/pmc_sq
+done
+cp $OUT/pmc_sq_bc7_slow.csv $OUT/pmc_sq_bc7.csv 2>/dev/null
 ls -la $OUT

@@ -65,6 +65,23 @@ def main():
         out["_note"] = "per C-ABI call of bc7_slow at 4096x4096 (all kernels of the call); SQ cycle counters are in quad-cycles"
         with open(os.path.join(dst, f"{tag}_valu.json"), "w") as fh:
             json.dump(out, fh, indent=1)
+    by_wl = {}
+    for wl in ("bc7_slow", "bc7_alpha_slow", "bc6h_slow", "bc1", "bc3", "bc4", "bc5"):
+        sqf = os.path.join(src, f"pmc_sq_{wl}.csv")
+        if not os.path.exists(sqf):
+            continue
+        row = {}
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAVES"):
+            v, n = per_call(sqf, c)
+            if v is not None:
+                row[c] = v
+        if row:
+            by_wl[wl] = row
+    if by_wl:
+        by_wl["_note"] = ("per C-ABI call at 4096x4096 (all kernels of the call), rocprofv3 --pmc SQ pass of tools/profile_gpu.sh; SQ cycle "
+                          "counters are in quad-cycles; bench.py turns SQ_INSTS_VALU into formats[*].valu")
+        with open(os.path.join(dst, f"{tag}_valu_by_workload.json"), "w") as fh:
+            json.dump(by_wl, fh, indent=1)
     print(json.dumps(traffic, indent=1)[:1500])
 
 
