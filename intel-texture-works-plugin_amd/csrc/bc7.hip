@@ -1178,7 +1178,7 @@ template <bool VEC16, bool RANKED_LISTS, bool FAM7>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(scan_all_waves(RANKED_LISTS, FAM7), scan_all_waves(RANKED_LISTS, FAM7))))
 bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint32_t* __restrict__ wins4,
              const bc7_enc_settings S, const ScanTasks tasks, const int ranked13, const int ranked7, const int32_t nchunks, const int32_t grain,
-             const int32_t* __restrict__ alpha_err)
+             const int32_t* __restrict__ rgb_list, const int32_t* __restrict__ rgb_count)
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
@@ -1189,24 +1189,24 @@ bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, 
     const int t = (int)(r / (uint32_t)grain);
     const int32_t chunk = (int32_t)(group * (uint32_t)grain + r % (uint32_t)grain);
     if (chunk >= nchunks) return;                                    // whole workgroup: no barrier is pending
+    // RGBA profile, alpha-capable modes already encoded (bc7_finish_all<.., 1>): an RGB-only mode's error includes
+    // sum (alpha - 255)^2 (kernel.ispc:1267-1277, 1356), so where that term alone exceeds the alpha modes' best error no
+    // three-channel mode can win or tie.  Round 3: finish<1> COMPACTS the blocks where an RGB mode can still win or tie into
+    // rgb_list (any order: blocks are independent), and this kernel walks the list instead of the surface -- lanes are
+    // filled with blocks that need the scans whatever their position, so a surface whose opaque and translucent blocks are
+    // mixed at random pays for the opaque half only (round 2 skipped whole waves: nothing on such content).
+    const int32_t nact = (!FAM7 && rgb_list) ? *rgb_count : nblocks;
+    if (chunk * TPB >= nact) return;
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
     const int32_t gid = chunk * TPB + threadIdx.x;
-    const bool live = gid < nblocks;
-    const int32_t b = live ? gid : nblocks - 1;
+    const bool live = gid < nact;
+    const int32_t slot = live ? gid : nact - 1;                      // idle lanes of the last workgroup redo its last block, store nothing
+    const int32_t b = (!FAM7 && rgb_list) ? rgb_list[slot] : slot;
     ln.keys = nullptr;
     ln.pal = s_pal + threadIdx.x;
     load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
-    if (!FAM7 && alpha_err) {
-        // RGBA profile, alpha-capable modes already encoded (bc7_finish_all<.., 1>): an RGB-only mode's error includes
-        // sum (alpha - 255)^2 (kernel.ispc:1267-1277, 1356), so where that term alone exceeds the alpha modes' best error no
-        // three-channel mode can win or tie.  Whole waves of such blocks skip their scans (exact: the block is unchanged).
-        uint32_t e = 0;
-#pragma unroll
-        for (int d = 0; d < 4; d++) { const uint32_t x = ~ln.tx.pl[3][d]; e = udot4(x, x, e); }
-        if (__all((int32_t)e > alpha_err[b])) return;
-    }
     const int kind = tasks.kind[t];                                  // wave-uniform
     Win wa, wb;
     if (!FAM7 && kind == WK_SCAN02) {
@@ -1232,17 +1232,21 @@ bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, 
 template <bool VEC16, int PHASE>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FINISH_ALL_WAVES, FINISH_ALL_WAVES)))
 bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst,
-               const uint32_t* __restrict__ wins4, const bc7_enc_settings S, int32_t* __restrict__ alpha_err)
+               const uint32_t* __restrict__ wins4, const bc7_enc_settings S, int32_t* __restrict__ alpha_err,
+               int32_t* __restrict__ rgb_list, int32_t* __restrict__ rgb_count)
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
     __shared__ uint2 s_pal[8 * TPB];
+    const int32_t nact = (PHASE == 2) ? *rgb_count : nblocks;        // PHASE 2 walks the compacted list of finish<1>
+    if (PHASE == 2 && (int32_t)(blockIdx.x * TPB) >= nact) return;   // whole workgroup, before any barrier
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
     const int32_t gid = blockIdx.x * TPB + threadIdx.x;
-    const bool live = gid < nblocks;
-    const int32_t b = live ? gid : nblocks - 1;
+    const bool live = gid < nact;
+    const int32_t slot = live ? gid : nact - 1;
+    const int32_t b = (PHASE == 2) ? rgb_list[slot] : slot;
     ln.keys = nullptr;
     ln.pal = s_pal + threadIdx.x;
     load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
@@ -1258,10 +1262,7 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
     }
     const bool on13 = S.mode_selection[1];
     int32_t e_alpha = ERR_MAX;
-    if (PHASE == 2) {
-        e_alpha = alpha_err[b];
-        if (__all(ln.opaque_err > e_alpha)) return;          // same predicate as the scans: these waves have no winners to refine
-    }
+    if (PHASE == 2) e_alpha = alpha_err[b];                  // every listed block has opaque_err <= e_alpha: its winners exist
     Win w;
     if (PHASE != 1) {
         if (S.mode_selection[0]) {
@@ -1278,7 +1279,20 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
         if (S.mode_selection[2]) modes_45(ln, S);
         if (S.mode_selection[3]) { if (S.channels == 4) mode_6<4>(ln, S); else mode_6<3>(ln, S); }
     }
-    if (PHASE == 1 && live) alpha_err[b] = ln.best_err;
+    if (PHASE == 1) {
+        if (live) alpha_err[b] = ln.best_err;
+        // the blocks where a three-channel mode can still win or tie (its error carries sum (255 - a)^2): appended to the list the
+        // RGB scans and finish<2> walk -- one atomic per wave, ranks within the wave by ballot
+        const bool need = live && ln.opaque_err <= ln.best_err;
+        const unsigned long long m = __ballot(need);
+        if (m) {
+            const int lane = (int)(threadIdx.x & 63u);
+            int32_t base = 0;
+            if (lane == 0) base = atomicAdd(rgb_count, (int32_t)__popcll(m));
+            base = __shfl(base, 0);
+            if (need) rgb_list[base + (int32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
+        }
+    }
     if (PHASE == 2 && !(ln.best_err <= e_alpha)) return;     // the alpha group's block stands (ties go to the earlier, RGB, group)
     if (live) {
         uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
@@ -1727,8 +1741,10 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             const int32_t groups = (chunks8 + grain - 1) / grain;
             const int a13 = r13 ? 1 : 0, a7 = r7 ? 1 : 0;
             int32_t* alpha_err = reinterpret_cast<int32_t*>(wins4 + (size_t)5 * n);            // [n] x 4 B behind the winner rows
+            int32_t* rgb_list = alpha_err + n;                                                 // [n] block ids + their count (RGBA profiles)
+            int32_t* rgb_count = rgb_list + n;
             const dim3 blk(TPB);
-            auto scan_rgb = [&](const int32_t* prune) {
+            auto scan_rgb = [&](const int32_t* list, const int32_t* count) {
                 ScanTasks T;
                 T.n = 0;
                 if (on13) T.kind[T.n++] = WK_SCAN13;                           // longest first
@@ -1736,11 +1752,11 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                 if (T.n == 0) return;
                 const dim3 grid((unsigned)(groups * grain * T.n));
                 if (r13) {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, prune);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, prune);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count);
                 } else {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, prune);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, prune);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count);
                 }
             };
             auto scan_7 = [&]() {
@@ -1749,25 +1765,26 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                 T7.n = 1; T7.kind[0] = WK_SCAN7;
                 const dim3 grid((unsigned)chunks8);
                 if (r7) {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr, nullptr);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr, nullptr);
                 } else {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr, nullptr);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr, nullptr);
                 }
             };
             auto finish = [&](auto phase) {
                 constexpr int PH = decltype(phase)::value;
-                if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true, PH>),  L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err);
-                else       hipLaunchKernelGGL((bc7_finish_all<false, PH>), L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err);
+                if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true, PH>),  L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, rgb_list, rgb_count);
+                else       hipLaunchKernelGGL((bc7_finish_all<false, PH>), L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, rgb_list, rgb_count);
             };
             if (bc7_alpha_first(S)) {
+                (void)hipMemsetAsync(rgb_count, 0, sizeof(int32_t), st);
                 scan_7();
                 finish(std::integral_constant<int, 1>{});
-                scan_rgb(alpha_err);
+                scan_rgb(rgb_list, rgb_count);
                 finish(std::integral_constant<int, 2>{});
             } else {
-                scan_rgb(nullptr);
+                scan_rgb(nullptr, nullptr);
                 scan_7();
                 finish(std::integral_constant<int, 0>{});
             }
