@@ -1,13 +1,23 @@
-# Where does a BC1 / BC3 launch spend its time?  Build variants (gpurun_variants/lib_*.so, built in the container):
-#   bc1old     round-2 kernel            bc1probe1  memory side only (loads + table staging + stores, no encode)
-#   bc1probe2  arithmetic only (no global loads)            bc1probe3  loads + stores only (no staging, no encode)
+# Where does a BC1 / BC3 launch spend its time?    Build variants of csrc/bc1_bc3.hip, made in the container into
+# gpurun_variants/lib_bc1<name>.so (see the switches at the top of that file):
+#   r02        the round-2 kernel                      memonly    loads + table staging + stores, no encode  (ITW_BC1_PROBE=1)
+#   loadstore  loads + stores only                     aluonly    the arithmetic alone, no global loads      (ITW_BC1_PROBE=2)
+#   nopk / nofq / alloff   the round-3 instruction-level changes switched off one by one / all
+#   w5, aluonly_w5         register allocation for 5 waves per SIMD (96 VGPRs, a few spills)
+# and the product kernel under ITW_BC13_LDS_PAD (dynamic LDS that caps the workgroups per CU: 3, 2 waves per SIMD).
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/probe_bc1
 L=intel-texture-works-plugin_amd/lib/libispc_texcomp.so
 cp $L /tmp/orig.so
-for v in orig $(ls gpurun_variants | grep bc1 | sed 's/lib_//;s/\.so//'); do
-  if [ $v = orig ]; then cp /tmp/orig.so $L; else cp gpurun_variants/lib_$v.so $L; fi
-  echo "== $v"
-  timeout 300 python tools/bc13_timing.py 2>&1 | grep -E "^bc"
-done | tee gpurun_out/probe_bc1/table.txt
+run() { echo "== $1"; ITW_BC13_LDS_PAD=${2:-0} timeout 300 python tools/bc13_timing.py 2>&1 | grep -E "^bc" | paste - - - -; }
+{
+run "product (4 waves per SIMD)"
+run "product, 3 waves per SIMD (LDS pad 36 KiB)" 36864
+run "product, 2 waves per SIMD (LDS pad 48 KiB)" 49152
+for v in $(ls gpurun_variants | grep '^lib_bc1' | sed 's/lib_bc1//;s/\.so//'); do
+  cp gpurun_variants/lib_bc1$v.so $L
+  run "$v"
+  case $v in aluonly) run "aluonly, 2 waves per SIMD" 49152;; esac
+done
+} 2>&1 | tee gpurun_out/probe_bc1/table.txt
 cp /tmp/orig.so $L
