@@ -96,7 +96,7 @@ def main():
     for (use, var, decl), n in all_sites.most_common():
         emit(f"{n:8d}  use {use:<44s} <- `{var}` declared at {decl}")
     emit()
-    emit("## 2. Emitted blocks whose BYTES depend on uninitialised storage (MSan shadow of the output stream)")
+    emit("## 2. Emitted blocks whose bytes carry uninitialised DATA (MSan shadow of the output stream; a value selected by a tainted decision is not tainted -- section 3 measures those)")
     for a in audits:
         emit(a)
     emit()
