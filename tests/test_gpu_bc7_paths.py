@@ -221,6 +221,31 @@ def test_alpha_first_order_and_skipped_rgb_modes(itw, gpu, paths, oracle, prof):
     assert (modes <= 3).any() and (modes >= 4).any()          # both groups of modes win somewhere
 
 
+@pytest.mark.parametrize("opaque_blocks", [0, 1, 7, 255, 256, 257, 1000, 4096])
+def test_rgb_block_list_of_every_length(itw, gpu, paths, oracle, opaque_blocks):
+    """Round 3: under an RGBA profile bc7_finish_all<1> compacts the blocks where an RGB mode can still win into a list
+    (atomic per wave, any order) and the RGB scans / finish<2> walk the list.  A 256 x 256 surface (4 096 blocks) whose alpha is
+    far from 255 except in `opaque_blocks` blocks scattered at random: list lengths 0 (every RGB workgroup leaves at once), 1, less
+    than a wave, one workgroup exactly, one over, many, all -- same bytes as the oracle each time, and twice in a row (the counter
+    is reset per call)."""
+    from itw_amd import surfaces
+    rng = np.random.default_rng(1000 + opaque_blocks)
+    img = surfaces.ldr_smooth(256, 256, seed=surfaces.SEED + 41).copy()
+    img[..., 3] = rng.integers(40, 120, (256, 256))
+    chosen = rng.permutation(4096)[:opaque_blocks]
+    for b in chosen:
+        y, x = divmod(int(b), 64)
+        img[4 * y:4 * y + 4, 4 * x:4 * x + 4, 3] = 255
+    want = oracle.encode_mt("bc7", img, "alpha_basic")
+    paths("deep")                                              # the fused launch shape at this size
+    for _ in range(2):
+        got = _encode(itw, gpu, img, "alpha_basic")
+        assert first_mismatch(got, want, 16) is None, (opaque_blocks, first_mismatch(got, want, 16))
+    if opaque_blocks == 4096:
+        modes = np.array([(int(b[0]) & -int(b[0])).bit_length() - 1 for b in want.reshape(-1, 16)])
+        assert (modes <= 3).any()                              # the RGB group does win on opaque blocks
+
+
 @pytest.mark.parametrize("prof", ["slow", "alpha_basic", "alpha_slow"])
 def test_unaligned_device_surfaces_take_the_dword_kernels(itw, gpu, paths, oracle, prof):
     """Base pointer 12 bytes past a 16-byte boundary, rows 1 168 bytes apart (rgba_surface.stride is free): the VEC16 = false
