@@ -463,6 +463,16 @@ def main():
         if verdict is not None:
             result.update(verdict)
             result["per_rank_kernel_ms"] = per_rank_ms
+            # the same job on ONE GPU, from the latest committed single-GPU run of this geometry: what a strong-scaling ratio of
+            # this line should be taken against (the default N = 1 line is BASELINE configs[2], a 4096^2 surface -- another job)
+            try:
+                names = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith(f"_bench_{size}_strong_n1.json"))
+                with open(os.path.join(ROOT, "profiles", names[-1])) as f:
+                    one = json.load(f)
+                result["same_job_on_one_gpu"] = {"value": one["value"], "unit": one["unit"], "ms_per_step": one["ms_per_step"],
+                                                 "source": "profiles/" + names[-1]}
+            except (OSError, ValueError, KeyError, IndexError):
+                result["same_job_on_one_gpu"] = None
         rk = rocprof_kernels(fmt)
         if rk and world == 1 and size == 4096 and scaling == "weak":
             # the call is several kernels for BC7; `achieved` uses the whole call.  For the slow / alpha_slow profiles the
