@@ -63,6 +63,10 @@ namespace itw {
 #include "bc7_f02_schedule.h"
 #undef BCN_TABLE_QUAL
 
+#ifndef ITW_BC7_LANE_PAL
+#define ITW_BC7_LANE_PAL 1                // per-lane shapes (refinement, ranked lists <= 16) through per-subset palettes in LDS (bc7_exact.hpp)
+#endif
+constexpr int LANE_PAL_LEVELS = 24;       // 3 subsets x 8 levels: the most one mode's refinement decodes (48 KiB per workgroup)
 constexpr int TPB = 256;                  // four waves share one staged seed table
 constexpr float INV255 = 1.0f / 255.0f;   // x/255f under fast-math = x*(1.f/255.f)
 constexpr int32_t ERR_MAX = 0x7fffffff;
@@ -431,8 +435,16 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
     uint32_t wqb[2];
     #pragma unroll
     for (int j = 0; j < 3; j++) for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) cq[j][i][p] = 0;
+#if ITW_BC7_LANE_PAL
+    constexpr int LEVELS = 1 << M.bits;
+    const int32_t tt = block_norm2<M.ch>(ln.tx.pl);
+#endif
     {
+#if ITW_BC7_LANE_PAL
+        PalSegment sg0[3];
+#else
         Segment sg0[3];
+#endif
         #pragma unroll 1
         for (int j = 0; j < M.pairs; j++) {
             const SubsetMask s = subset_of(w.shape, j);       // (selecting among sm[0..2] here made the compiler index them in scratch)
@@ -443,7 +455,11 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
             fit_line<M.ch>(ep, ln.tx, s.bits, st, ispc_rcp((float)s.n, ln.T), ln.T);
             int32_t q[2][4], d[2][4];
             quant_mode<MODE, true>(q, d, ep, M.ch);
+#if ITW_BC7_LANE_PAL
+            const PalSegment sgj = build_palette<M.bits, M.ch, TPB>(ln.pal + j * (LEVELS * TPB), d);
+#else
             const Segment sgj = make_segment<M.bits, M.ch>(d);
+#endif
             #pragma unroll
             for (int i = 0; i < 2; i++) for (int p = 0; p < 4; p++) {
                 if (j == 0) cq[0][i][p] = q[i][p]; else if (j == 1) cq[1][i][p] = q[i][p]; else cq[2][i][p] = q[i][p];
@@ -451,12 +467,20 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
             if (j == 0) sg0[0] = sgj; else if (j == 1) sg0[1] = sgj; else sg0[2] = sgj;
         }
         if (M.pairs == 2) sg0[2] = sg0[1];
+#if ITW_BC7_LANE_PAL
+        (void)select_block_lanes_pal<M.bits, M.ch, M.pairs, TPB, true>(wqb, ln.tx, sg0, ln.pal, sh.pattern, tt);
+#else
         (void)select_block<M.bits, M.ch, M.pairs>(wqb, ln.tx, sg0, sh.pattern);
+#endif
     }
     for (int it = 0; it < iterations; it++) {
         ln.tx.fence();
         int32_t q[3][2][4];
+#if ITW_BC7_LANE_PAL
+        PalSegment sg[3];
+#else
         Segment sg[3];
+#endif
         #pragma unroll
         for (int j = 0; j < M.pairs; j++) {
             float ep[2][4];
@@ -464,11 +488,19 @@ __device__ __forceinline__ void refine_and_commit(Lane& ln, Win& w, int iteratio
             ep[0][3] = 0.f; ep[1][3] = 0.f;
             refit_line<M.bits, M.ch>(ep, ln.tx.pl, wqb, sm[j], ln.T);
             quant_mode<MODE, false>(q[j], d, ep, settings_channels);       // :1343 passes the profile's channel count
+#if ITW_BC7_LANE_PAL
+            sg[j] = build_palette<M.bits, M.ch, TPB>(ln.pal + j * (LEVELS * TPB), d);
+#else
             sg[j] = make_segment<M.bits, M.ch>(d);
+#endif
         }
         if (M.pairs == 2) sg[2] = sg[1];
         uint32_t qb[2];
+#if ITW_BC7_LANE_PAL
+        const int32_t err = select_block_lanes_pal<M.bits, M.ch, M.pairs, TPB, true>(qb, ln.tx, sg, ln.pal, sh.pattern, tt);
+#else
         const int32_t err = select_block<M.bits, M.ch, M.pairs>(qb, ln.tx, sg, sh.pattern);
+#endif
         const bool better = err < w.err;
         if (better) {
             #pragma unroll
@@ -690,6 +722,49 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
             ln.tx.fence();
             const int shape = prev & 63;
             const Shape sh = load_shape(shape);
+#if ITW_BC7_LANE_PAL
+            if (RANKED == 2) {
+                // lists of at most 16 shapes (every preset): the candidate's subsets decode their palettes into the lane's LDS column
+                // (mode 1: 2 x 8 levels; mode 3 afterwards over the same stretch: 2 x 4) and the texels are scored through them
+                float fits[2][2][4];
+                IStats<FIT_CH> rest2 = full;
+                #pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const SubsetMask sm = subset_of(shape, j);
+                    IStats<FIT_CH> st;
+                    if (j == 0) stats_int<FIT_CH>(st, ln.tx.pl, sm); else st = rest2;
+                    stats_sub<FIT_CH>(rest2, st);
+                    fits[j][0][3] = 0.f; fits[j][1][3] = 0.f;
+                    fit_line<FIT_CH>(fits[j], ln.tx, sm.bits, st, ispc_rcp((float)sm.n, ln.T), ln.T);
+                }
+                uint32_t qbl[2];
+                int32_t q[2][4], d[2][4];
+                PalSegment ps[3];
+                if (FAMILY7) {
+                    #pragma unroll
+                    for (int j = 0; j < 2; j++) { quant_mode<7, true>(q, d, fits[j], 4); ps[j] = build_palette<2, 4, TPB>(ln.pal + j * (4 * TPB), d); }
+                    ps[2] = ps[1];
+                    const int32_t e = select_block_lanes_pal<2, 4, 2, TPB, false>(qbl, ln.tx, ps, ln.pal, sh.pattern, tt);
+                    if (e < wa.err) take(wa, e, shape, prev);
+                } else {
+                    if (i < na) {
+                        #pragma unroll
+                        for (int j = 0; j < 2; j++) { quant_mode<1, true>(q, d, fits[j], 3); ps[j] = build_palette<3, 3, TPB>(ln.pal + j * (8 * TPB), d); }
+                        ps[2] = ps[1];
+                        const int32_t e = select_block_lanes_pal<3, 3, 2, TPB, false>(qbl, ln.tx, ps, ln.pal, sh.pattern, tt);
+                        if (e < wa.err) take(wa, e, shape, prev);
+                    }
+                    if (i < nb) {
+                        #pragma unroll
+                        for (int j = 0; j < 2; j++) { quant_mode<3, true>(q, d, fits[j], 3); ps[j] = build_palette<2, 3, TPB>(ln.pal + j * (4 * TPB), d); }
+                        ps[2] = ps[1];
+                        const int32_t e = select_block_lanes_pal<2, 3, 2, TPB, false>(qbl, ln.tx, ps, ln.pal, sh.pattern, tt);
+                        if (e < wb.err) take(wb, e, shape, prev);
+                    }
+                }
+                continue;
+            }
+#endif
             Segment sa[3], sc[3];
             IStats<FIT_CH> rest = full;
             #pragma unroll
@@ -1057,7 +1132,8 @@ bc7_search_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
     extern __shared__ int32_t s_keys[];            // 64 * TPB keys, only allocated for RANKED == 1
-    __shared__ uint2 s_pal[RANKED ? 1 : 12 * TPB]; // per-lane palettes of the table-order scans: 8 + 4 levels (24 KiB)
+    // per-lane palettes: table-order scans 8 + 4 levels (24 KiB); ranked lists <= 16: 2 subsets x 8 levels (32 KiB); longer lists: none
+    __shared__ uint2 s_pal[RANKED == 0 ? 12 * TPB : (RANKED == 2 && ITW_BC7_LANE_PAL) ? 16 * TPB : 1];
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
@@ -1065,7 +1141,7 @@ bc7_search_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
     const bool live = gid < nblocks;
     const int32_t b = live ? gid : nblocks - 1;    // idle lanes of the last workgroup redo its last block, store nothing
     ln.keys = s_keys + threadIdx.x;
-    ln.pal = s_pal + (RANKED ? 0 : threadIdx.x);
+    ln.pal = s_pal + ((RANKED == 0 || (RANKED == 2 && ITW_BC7_LANE_PAL)) ? threadIdx.x : 0);
     load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
 
     Win wa, wb;
@@ -1088,7 +1164,8 @@ bc7_finish_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
-    __shared__ uint2 s_pal[FAMILY == F_MODES456 ? 8 * TPB : 1];     // one palette per lane for the mode 4/5 vector part (16 KiB)
+    // mode 4/5 vector part: one palette per lane (16 KiB); refinement of a family's winners: one per subset (pairs x levels)
+    __shared__ uint2 s_pal[FAMILY == F_MODES456 ? 8 * TPB : (ITW_BC7_LANE_PAL ? (FAMILY == F_MODES02 ? 24 : 16) * TPB : 1)];
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
@@ -1096,7 +1173,7 @@ bc7_finish_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
     const bool live = gid < nblocks;
     const int32_t b = live ? gid : nblocks - 1;
     ln.keys = nullptr;
-    ln.pal = s_pal + (FAMILY == F_MODES456 ? threadIdx.x : 0);
+    ln.pal = s_pal + ((FAMILY == F_MODES456 || ITW_BC7_LANE_PAL) ? threadIdx.x : 0);
     load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
 
     ln.best_err = first ? ERR_MAX : err_ws[b];
@@ -1182,7 +1259,7 @@ bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, 
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
-    __shared__ uint2 s_pal[12 * TPB];
+    __shared__ uint2 s_pal[((RANKED_LISTS && ITW_BC7_LANE_PAL) ? 16 : 12) * TPB];   // ranked lists: 2 subsets x 8 levels (3 waves per SIMD: 3 x 44 KiB)
     // `grain` chunks of one family, then the same chunks of the next family (grain is a multiple of 8, so a chunk's
     // families run on the same XCD: workgroup w -> XCD w % 8)
     const uint32_t w = blockIdx.x, per = (uint32_t)grain * (uint32_t)tasks.n, group = w / per, r = w % per;
@@ -1237,7 +1314,7 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
-    __shared__ uint2 s_pal[8 * TPB];
+    __shared__ uint2 s_pal[(ITW_BC7_LANE_PAL ? LANE_PAL_LEVELS : 8) * TPB];   // refinement: a palette per subset of the lane's winner
     const int32_t nact = (PHASE == 2) ? *rgb_count : nblocks;        // PHASE 2 walks the compacted list of finish<1>
     if (PHASE == 2 && (int32_t)(blockIdx.x * TPB) >= nact) return;   // whole workgroup, before any barrier
     Lane ln;
@@ -1404,7 +1481,7 @@ bc7_wide_phase1(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_
     const WideDims dims{nblocks, pstride};
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
-    __shared__ uint2 s_pal[12 * TPB];
+    __shared__ uint2 s_pal[((RANKED_LISTS && ITW_BC7_LANE_PAL) ? 16 : 12) * TPB];
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
@@ -1444,7 +1521,7 @@ bc7_wide_phase2(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_
     const WideDims dims{nblocks, pstride};
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
-    __shared__ uint2 s_pal[SINGLES ? 8 * TPB : 1]; // one palette per lane for the mode 4/5 vector part
+    __shared__ uint2 s_pal[SINGLES ? 8 * TPB : (ITW_BC7_LANE_PAL ? LANE_PAL_LEVELS * TPB : 1)];   // mode 4/5 vector part / refinement palettes
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
@@ -1452,7 +1529,7 @@ bc7_wide_phase2(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_
     const bool live = gid < nblocks;
     const int32_t b = live ? gid : nblocks - 1;
     ln.keys = nullptr;
-    ln.pal = s_pal + (SINGLES ? threadIdx.x : 0);
+    ln.pal = s_pal + ((SINGLES || ITW_BC7_LANE_PAL) ? threadIdx.x : 0);
     load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
     ln.best_err = ERR_MAX; ln.improved = false;
     ln.best[0] = ln.best[1] = ln.best[2] = ln.best[3] = 0u;

@@ -640,6 +640,64 @@ __device__ __forceinline__ int32_t select_block_pal(uint32_t (&qb)[2], const Tex
     return total;
 }
 
+// ---- palettes where the shape differs per lane (round 3) ---------------------------------------------------------------
+// Refinement of a lane's own winner and the ranked candidate lists of the fast presets cannot branch on the subset mask (it is
+// per lane), so they used the direct path (select_block: decode both neighbouring levels per texel with packed 16-bit math,
+// ~150 issue cycles per texel incl. the per-texel choice of segment).  The palette path works there too: each of the shape's
+// PAIRS subsets decodes its LEVELS colours once into its own stretch of the lane's LDS column (subset j at level offset
+// j * LEVELS), and a texel picks its subset's projection constants (five selects per extra subset) and palette stretch by the
+// pattern word -- ~75 cycles per texel, plus ~30 per decoded level.  Same projection, same index, same two candidate levels,
+// same integer errors as select_block; `tt` = sum of |texel|^2 over the block (CH channels), the term the palette path leaves out.
+__device__ __forceinline__ PalSegment pick_pal(const PalSegment& s0, const PalSegment& s1, bool one)
+{
+    PalSegment r;
+    r.p0 = one ? s1.p0 : s0.p0; r.p1 = one ? s1.p1 : s0.p1; r.nc = one ? s1.nc : s0.nc;
+    r.k0 = one ? s1.k0 : s0.k0; r.k1 = one ? s1.k1 : s0.k1;
+    r.th1 = one ? s1.th1 : s0.th1; r.th2 = one ? s1.th2 : s0.th2;      // (the unused pair is dead code per BITS)
+    return r;
+}
+
+template <int CH>
+__device__ __forceinline__ int32_t block_norm2(const uint32_t (&pl)[4][4])
+{
+    uint32_t t = 0;
+#pragma unroll
+    for (int c = 0; c < CH; c++)
+#pragma unroll
+        for (int d = 0; d < 4; d++) t = udot4(pl[c][d], pl[c][d], t);
+    return (int32_t)t;
+}
+
+// WANT_Q = false: the error alone (candidate scans)
+template <int BITS, int CH, int PAIRS, int PAL_STRIDE, bool WANT_Q>
+__device__ __forceinline__ int32_t select_block_lanes_pal(uint32_t (&qb)[2], const Tex& tx, const PalSegment (&sg)[3], const uint2* pal,
+                                                          uint32_t pattern, int32_t tt)
+{
+    constexpr int LEVELS = 1 << BITS;
+    int32_t total = tt;
+    qb[0] = qb[1] = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        PalSegment s = sg[0];
+        const uint2* base = pal;
+        if (PAIRS >= 2) {
+            const uint32_t j = (pattern >> (2 * k)) & 3u;
+            s = pick_pal(s, sg[1], j == 1u);
+            if (PAIRS == 3) s = pick_pal(s, sg[2], j == 2u);
+            base = pal + j * (uint32_t)(LEVELS * PAL_STRIDE);
+        }
+        if (WANT_Q) {
+            int32_t q, e;
+            select_texel_pal<BITS, CH, PAL_STRIDE>(q, e, s, base, tx.w[k]);
+            if (k < 8) qb[0] |= (uint32_t)q << (4 * k); else qb[1] |= (uint32_t)q << (4 * (k - 8));
+            total += e;
+        } else {
+            total -= texel_error_pal<BITS, CH, PAL_STRIDE>(s, base, tx.w[k]);
+        }
+    }
+    return total;
+}
+
 // ---- least-squares endpoints for fixed indices (kernel.ispc:1198-1262 opt_endpoints) -------------------
 // The sums are exact integers (sum q*t <= 16*15*255); the 2x2 solve is fp32 exactly as in the reference.
 template <int BITS, int CH>
