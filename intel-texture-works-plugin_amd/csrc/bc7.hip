@@ -1039,15 +1039,29 @@ __device__ __forceinline__ void mode_6(Lane& ln, const bc7_enc_settings& S)
     fit_line<CH>(ep, ln.tx, 0xffffu, st, rcp_of_count(16), ln.T);
     if (CH == 3) { ep[0][3] = 255.f; ep[1][3] = 255.f; }
     quant_mode<6, true>(q, d, ep, CH);
+#if ITW_BC7_LANE_PAL
+    // the sixteen decoded colours once into the lane's LDS column, then one projection, one 16-byte read and two dot products
+    // per texel instead of decoding both neighbouring levels with packed 16-bit math per texel (bc7_exact.hpp)
+    const int32_t tt = block_norm2<CH>(ln.tx.pl);
+    PalSegment ps = build_palette<4, CH, TPB>(ln.pal, d);
+    int32_t err = select_block_pal<4, CH, TPB>(qb, ln.tx, ps, ln.pal, tt);
+    (void)sg;
+#else
     sg[0] = make_segment<4, CH>(d); sg[1] = sg[0]; sg[2] = sg[0];
     int32_t err = select_block<4, CH, 1>(qb, ln.tx, sg, 0u);
+#endif
     const int iters = S.refineIterations[6];
     for (int it = 0; it < iters; it++) {
         const uint32_t was0 = qb[0], was1 = qb[1];
         refit_line<4, CH>(ep, ln.tx.pl, qb, all, ln.T);
         quant_mode<6, false>(q, d, ep, CH);
+#if ITW_BC7_LANE_PAL
+        ps = build_palette<4, CH, TPB>(ln.pal, d);
+        err = select_block_pal<4, CH, TPB>(qb, ln.tx, ps, ln.pal, tt);
+#else
         sg[0] = make_segment<4, CH>(d);
         err = select_block<4, CH, 1>(qb, ln.tx, sg, 0u);
+#endif
         if (__all(qb[0] == was0 && qb[1] == was1)) break;         // fixed point of the iteration (kernel.ispc:1672-1677)
     }
     if (err < ln.best_err) {
@@ -1165,7 +1179,7 @@ bc7_finish_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
     // mode 4/5 vector part: one palette per lane (16 KiB); refinement of a family's winners: one per subset (pairs x levels)
-    __shared__ uint2 s_pal[FAMILY == F_MODES456 ? 8 * TPB : (ITW_BC7_LANE_PAL ? (FAMILY == F_MODES02 ? 24 : 16) * TPB : 1)];
+    __shared__ uint2 s_pal[FAMILY == F_MODES456 ? (ITW_BC7_LANE_PAL ? 16 : 8) * TPB : (ITW_BC7_LANE_PAL ? (FAMILY == F_MODES02 ? 24 : 16) * TPB : 1)];
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
@@ -1521,7 +1535,7 @@ bc7_wide_phase2(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_
     const WideDims dims{nblocks, pstride};
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
-    __shared__ uint2 s_pal[SINGLES ? 8 * TPB : (ITW_BC7_LANE_PAL ? LANE_PAL_LEVELS * TPB : 1)];   // mode 4/5 vector part / refinement palettes
+    __shared__ uint2 s_pal[SINGLES ? (ITW_BC7_LANE_PAL ? 16 : 8) * TPB : (ITW_BC7_LANE_PAL ? LANE_PAL_LEVELS * TPB : 1)];   // mode 4/5 vector part, mode 6 (16 levels) / refinement palettes
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();

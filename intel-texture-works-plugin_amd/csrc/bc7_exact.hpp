@@ -441,7 +441,6 @@ constexpr int32_t PAL_MAGIC = 0x4b400000;                                   // b
 template <int BITS, int CH, int PAL_STRIDE>
 __device__ __forceinline__ PalSegment build_palette(uint2* pal, const int32_t (&d)[2][4])
 {
-    static_assert(BITS <= 3, "4-bit indices keep the direct path");
     constexpr int LEVELS = 1 << BITS;
     PalSegment s;
     const uint32_t a01 = pack16(d[0][0], d[0][1]);
@@ -460,7 +459,12 @@ __device__ __forceinline__ PalSegment build_palette(uint2* pal, const int32_t (&
         dd = dot2(ba01, ba01, ba2 * ba2);
         s.nc = -dot2(a01, ba01, d[0][2] * ba2);
     }
-    if (BITS == 3) {
+    if (BITS == 4) {                                                       // mode 6: the exactly rounded quotient of select_texel (statement (3))
+        const float dn = -(float)dd;
+        s.k0 = dn;
+        s.k1 = (dd == 0) ? 0.0f : 1.0f / dn;
+        s.th1 = s.th2 = 0;
+    } else if (BITS == 3) {
         const float dn = -(float)dd;
         const float r = (dd == 0) ? 0.0f : 1.0f / dn;                      // = RN(-1/D): one IEEE divide per segment
         s.k0 = -((float)LEVELS * r);
@@ -517,6 +521,16 @@ __device__ __forceinline__ int32_t pal_lower_level(const PalSegment& sg, int32_t
         asm("v_lshrrev_b32 %0, 31, %1" : "=v"(s1) : "v"(d1));
         asm("v_lshrrev_b32 %0, 31, %1" : "=v"(s2) : "v"(d2));
         return (int32_t)(s1 + s2);
+    }
+    if (BITS == 4) {
+        // 4-bit indices (mode 6): 1/(4D) is too small a margin for the biased FMA, so the quotient is formed exactly as in
+        // select_texel -- q0 = RN(M*rn), one exact remainder, one correction = RN(N/D) -- with M = -N (an exact negation)
+        const float mf = (float)(-n);
+        float q = mf * sg.k1;
+        const float rem = __builtin_fmaf(-q, sg.k0, mf);
+        q = __builtin_fmaf(rem, sg.k1, q);
+        const float x = __builtin_fmaf(q, (float)LEVELS, 0.5f);
+        return imed3((int32_t)x, 1, LEVELS - 1) - 1;
     }
     // + (1.5 * 2^23 - 1): the low mantissa bits are floor(y + 0.5) - 1 = q1 - 1 before the clamp; PAL_MAGIC << 11 is 0 mod 2^32,
     // so the level's LDS offset is the clamped word shifted, no subtraction
