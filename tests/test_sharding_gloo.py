@@ -196,7 +196,7 @@ def test_band_rule_keeps_partial_blocks_for_bc4_bc5(fmt, h, w, parts):
     assert covered == whole.size and np.array_equal(got, whole)
 
 
-def _run_bench_world2(extra_env):
+def _run_bench_world2(extra_env, extra_args=()):
     import subprocess
     port = _free_port()
     procs = []
@@ -204,7 +204,7 @@ def _run_bench_world2(extra_env):
         env = dict(os.environ, ITW_BENCH_CONTROL_FLOW_TEST="1", RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ITW_BENCH_DIST_TIMEOUT_S="120", **extra_env)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                                       "--size", "512", "--no-formats", "--no-cpu"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+                                       "--size", "512", "--no-formats", "--no-cpu", *extra_args], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=600) for p in procs]
     assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
     return outs
@@ -224,6 +224,16 @@ def test_bench_n_gt_1_verifies_the_gathered_image(corrupt):
         assert j["gather_verified"] is True and j["mismatching_bytes"] == 0
     else:
         assert j["gather_verified"] is False and j["mismatching_bytes"] == 2   # seen by the damaged rank itself and by its peer
+
+
+def test_bench_weak_scaling_job_verifies_too():
+    """--scaling weak: every rank owns its own seeded 512 x 512 band of a 512 x 1024 surface; the verification regenerates the
+    other rank's band from ITS seed.  Intact -> true; rank 1 damaged -> false."""
+    import json
+    for corrupt, want in ((None, True), ("1", False)):
+        outs = _run_bench_world2({} if corrupt is None else {"ITW_BENCH_CORRUPT_RANK": corrupt}, ("--scaling", "weak"))
+        j = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+        assert j["scaling"] == "weak" and "512x1024" in j["config"]["workload"] and j["gather_verified"] is want, j
 
 
 def test_bench_n_gt_1_control_flow_runs_end_to_end_on_cpu():
