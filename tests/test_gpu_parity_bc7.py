@@ -249,6 +249,23 @@ def test_whole_16384_surface_on_one_gpu(itw, gpu, oracle):
         del out, got
 
 
+def test_whole_16384_surface_rgba_profile_block_list(itw, gpu, oracle):
+    """The same 16.8 M-block surface under an RGBA profile with opaque and translucent blocks mixed per block: the alpha group's
+    finish kernel compacts ~8 M block ids into the RGB list (atomic per wave, offsets beyond 2^23 entries) and the RGB scans walk
+    it with gathered texel loads.  Tiled cell, so every tile of the output must equal the oracle's stream of the cell."""
+    import torch
+    from itw_amd import surfaces
+    cell = surfaces.ldr_alpha_variant(surfaces.ldr_smooth(512, 512), "mixed")
+    d_cell = torch.from_numpy(cell).to(gpu)
+    img = d_cell.repeat(32, 32, 1)
+    out = itw.compress("bc7", img, "alpha_basic")
+    torch.cuda.synchronize()
+    want = torch.from_numpy(oracle.encode_mt("bc7", cell, "alpha_basic").reshape(128, 128 * 16)).to(gpu)
+    got = out.view(32, 128, 32, 128 * 16)
+    same = (got == want[None, :, None, :]).all(dim=3).all(dim=1)
+    assert bool(same.all()), torch.nonzero(~same)[:4].tolist()
+
+
 def test_random_settings_fuzz(itw, gpu, oracle):
     """The settings struct is a caller-owned POD (ispc_texcomp.h:27-41) and any combination is legal input: 160 random
     structs -- mode families on/off, refine counts 0..5 per mode, thresholds 0 / at the 16|17 and 64 boundaries /
