@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types and prototypes only: the symbols are resolved with dlsym on first use
 #include <dlfcn.h>
+#include <sched.h>
 #include <atomic>
 #include <condition_variable>
 #include <cstdio>
@@ -286,9 +287,45 @@ void run_rank(RankCtx& c, const Call& k)
     }
 }
 
+// Best effort: run the rank's host thread on the CPUs of its GPU's NUMA node, so that the pageable band uploads / downloads of the
+// host-pointer case stay on the socket the GPU hangs off.  PCI bus id -> sysfs numa_node -> that node's
+// cpulist -> sched_setaffinity.  Anything missing (no sysfs, node -1, one-node box): the thread keeps its affinity.
+// ITW_MULTIGPU_AFFINITY=0 disables it.
+void place_thread_near_device(int device)
+{
+    const char* e = std::getenv("ITW_MULTIGPU_AFFINITY");
+    if (e && e[0] == '0') return;
+    char bus[32] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char* p = bus; *p; p++) if (*p >= 'A' && *p <= 'Z') *p = (char)(*p - 'A' + 'a');          // sysfs spells the id in lower case
+    char path[160];
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    int node = -1;
+    if (FILE* f = std::fopen(path, "r")) { if (std::fscanf(f, "%d", &node) != 1) node = -1; std::fclose(f); }
+    if (node < 0) return;
+    std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    char list[1024] = {0};
+    if (FILE* f = std::fopen(path, "r")) { if (!std::fgets(list, (int)sizeof list, f)) list[0] = 0; std::fclose(f); }
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int any = 0;
+    for (const char* p = list; *p;) {                            // "0-31,64-95"
+        char* q = nullptr;
+        const long a = std::strtol(p, &q, 10);
+        if (q == p) break;
+        long b = a;
+        if (*q == '-') { p = q + 1; b = std::strtol(p, &q, 10); }
+        for (long cpu = a; cpu <= b && cpu < CPU_SETSIZE; cpu++) { CPU_SET((int)cpu, &set); any = 1; }
+        p = (*q == ',') ? q + 1 : q;
+        if (*q != ',' ) break;
+    }
+    if (any) (void)sched_setaffinity(0, sizeof set, &set);
+}
+
 void rank_main(RankCtx* c)
 {
     (void)hipSetDevice(c->device);
+    place_thread_near_device(c->device);
     std::unique_lock<std::mutex> lk(g.m);
     for (;;) {
         g.work.wait(lk, [&] { return g.quit || c->pending; });
