@@ -23,6 +23,15 @@ N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-
                    timeout (ITW_BENCH_DIST_TIMEOUT_S, default 300 s) and the whole run a watchdog (ITW_BENCH_WATCHDOG_S,
                    default 1500 s): a rank mismatch ends in an error, not in a hang.
   --scaling weak   rank r owns band r of a size x (size*N) surface: per-GPU work fixed.
+  --host cpp|python|auto   who drives the N GPUs.  `cpp` = ONE process, itwCompressImageMultiGPUEx (include/itw_multigpu.h,
+                   csrc/multigpu.hip): the C++ entry a host application calls -- one host thread per GPU, band r resident on
+                   GPU r (tile-sharded input, BASELINE configs[4]), RCCL ncclSend/ncclRecv gather of the block stream to GPU 0,
+                   every byte of the gathered image compared with a fresh single-GPU encode of its band.  `python` = the
+                   torch.distributed job above.  auto (default): N > 1 runs BOTH -- the headline `value` is the C++ job's
+                   (rank 0 runs it in a child process with a timeout while the other ranks wait at a CPU barrier; a child that
+                   fails or hangs leaves the torch.distributed figure as the headline and says so in `cpp_host`), the
+                   torch.distributed job rides along as `python_side`.  N = 1: `formats["multigpu_cpp@8virtual_16384"]` times
+                   the same C++ entry with 8 ranks sharing the one device against the single 16384^2 call (dispatch overhead).
 
 cpu_baseline: the scalar C oracle (oracle/, test infrastructure) timed on this box's host cores on a bounded sample,
 rank 0, N=1 only.  It is a *port* (scalar restatement), not ISPC SIMD code: the reference cannot be built here.
@@ -320,6 +329,111 @@ def pmc_traffic(workload):
         return None
 
 
+def _all_device_sync():
+    for i in range(torch.cuda.device_count()):
+        torch.cuda.synchronize(i)
+
+
+def cpp_job(itw, fmt, prof, size, ranks, steps, warmup, scatter_steps=0):
+    """BASELINE configs[4] through the C++ host path: ONE process, itwCompressImageMultiGPUEx, band r of the size^2 surface resident
+    on device r % device_count (each band derived from the same seeded base as the torch.distributed job's), block stream gathered
+    to device 0.  Every call is synchronous (all rank streams drained before it returns), so the timed region is K calls between
+    two all-device synchronisations.  Afterwards EVERY band of the gathered image is compared with a fresh single-GPU encode."""
+    ndev = torch.cuda.device_count()
+    bands, geos = [], []
+    for r in range(ranks):
+        g = plan("strong", size, ranks, r, fmt)
+        geos.append(g)
+        bands.append(torch.from_numpy(make_band(fmt, "strong", size, g, r)).to(f"cuda:{r % ndev}"))
+    out = torch.zeros(geos[0]["total_bytes"], dtype=torch.uint8, device="cuda:0")
+    st = itw.MultiGpuStats()
+    for _ in range(warmup):
+        itw.compress_image_multigpu(fmt, (size, size), prof, bands=bands, out=out, stats=st)
+    first = st.as_dict() if warmup else None               # the first call of the process: communicator set-up, first connections
+    _all_device_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        itw.compress_image_multigpu(fmt, (size, size), prof, bands=bands, out=out, stats=st)
+    _all_device_sync()
+    elapsed = time.perf_counter() - t0
+    last = st.as_dict()
+    bad = 0
+    for r in range(ranks):
+        ref = itw.compress(fmt, bands[r], prof)
+        torch.cuda.synchronize(ref.device)
+        g = geos[r]
+        bad += int((ref.to("cuda:0") != out[g["band_off"]:g["band_off"] + g["band_bytes"]]).sum().item())
+        del ref
+    res = {"host": "cpp: one process, itwCompressImageMultiGPUEx, one host thread per rank", "elapsed_s": elapsed, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 4), "value": round(size * size * steps / elapsed / 1e6, 2), "unit": "Mpixels/s",
+           "gather_verified": bad == 0, "mismatching_bytes": bad, "band_checks": ranks,
+           "how": "every band of the gathered stream on GPU 0 compared byte for byte with a fresh single-GPU encode of the same texels",
+           "ranks": ranks, "devices": ndev, "transport": last["transport"], "transport_note": last["transport_note"],
+           "ranks_seen_by_rccl": last["rccl_ranks"], "peer_links": last["peer_links"], "stats_last_call": last,
+           "first_call_wall_ms": first["wall_ms"] if first else None}
+    if scatter_steps > 0:
+        # the other way a C++ host holds its texels: the WHOLE surface resident on GPU 0, scattered to the ranks by peer copies
+        # inside the call (the second half-band's copy under the first's encode)
+        whole = torch.cat([b.to("cuda:0") for b in bands], dim=0)
+        o2 = torch.zeros_like(out)
+        itw.compress_image_multigpu(fmt, whole, prof, ranks=ranks, out=o2, stats=st)
+        _all_device_sync()
+        t0 = time.perf_counter()
+        for _ in range(scatter_steps):
+            itw.compress_image_multigpu(fmt, whole, prof, ranks=ranks, out=o2, stats=st)
+        _all_device_sync()
+        e2 = time.perf_counter() - t0
+        res["scatter_from_gpu0"] = {"ms_per_step": round(e2 / scatter_steps * 1e3, 4), "value": round(size * size * scatter_steps / e2 / 1e6, 2),
+                                    "unit": "Mpixels/s", "steps": scatter_steps, "identical_to_resident_bands_result": bool(torch.equal(o2, out)),
+                                    "stats_last_call": st.as_dict()}
+        del whole, o2
+    return res
+
+
+def cpp_worker(args):
+    """Child process of rank 0 (N > 1): runs cpp_job over all visible GPUs and prints its result as one JSON line."""
+    fmt, prof = WORKLOADS[args.workload]
+    if FAKE:                                               # control-flow test on CPU (tests/test_sharding_gloo.py): a canned account
+        if os.environ.get("ITW_BENCH_CPP_WORKER_CRASH"):
+            raise SystemExit(3)
+        print(json.dumps({"host": "cpp (CONTROL-FLOW TEST, canned)", "elapsed_s": 0.002 * args.steps, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 2.0, "value": round(args.size * args.size / 2e-3 / 1e6, 2), "unit": "Mpixels/s",
+                          "gather_verified": os.environ.get("ITW_BENCH_FAKE_CPP") != "bad", "mismatching_bytes": 0, "band_checks": args.gpus,
+                          "how": "canned", "ranks": args.gpus, "devices": args.gpus, "transport": "rccl", "transport_note": "", "ranks_seen_by_rccl": args.gpus,
+                          "peer_links": args.gpus * (args.gpus - 1), "stats_last_call": None, "first_call_wall_ms": None}), flush=True)
+        return
+    import itw_amd
+    itw_amd.lib()
+    assert torch.cuda.is_available() and torch.cuda.device_count() >= args.gpus, \
+        f"cpp worker: {torch.cuda.device_count()} visible devices for {args.gpus} ranks"
+    faulthandler.dump_traceback_later(int(os.environ.get("ITW_BENCH_CPP_TIMEOUT_S", "600")), exit=True)
+    res = cpp_job(itw_amd, fmt, prof, args.size, args.gpus, args.steps, args.warmup, scatter_steps=min(3, args.steps))
+    print(json.dumps(res), flush=True)
+
+
+def run_cpp_child(args, world, size, steps, warmup):
+    """Rank 0 of an N > 1 launch: the C++ job in a child process (its own HIP contexts on all N GPUs; torchrun's variables
+    removed), bounded by a timeout.  Returns its result dict, or {"error": ...}."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_NAME",
+                        "ROLE_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS") and not k.startswith("TORCHELASTIC_")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpp-worker", "--gpus", str(world), "--steps", str(steps), "--warmup", str(warmup),
+           "--workload", args.workload, "--size", str(size)]
+    tmo = int(os.environ.get("ITW_BENCH_CPP_TIMEOUT_S", "600"))
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=tmo + 30)
+    except subprocess.TimeoutExpired:
+        return {"error": f"the C++ multi-GPU job did not finish within {tmo + 30} s and was killed"}
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"the C++ multi-GPU job exited with {p.returncode}", "stderr_tail": p.stderr[-1500:]}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as e:
+        return {"error": f"unreadable result of the C++ multi-GPU job: {e}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,7 +447,15 @@ def main():
     ap.add_argument("--no-16k", action="store_true", help="skip the 16384^2 BC1/BC3 side figures (tools/profile_gpu.sh: keeps the "
                     "per-kernel-name averages of rocprofv3 --stats those of the 4096^2 launches)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--host", choices=["auto", "cpp", "python"], default="auto",
+                    help="N > 1: who drives the GPUs (see the module docstring); auto = both, C++ job as the headline")
+    ap.add_argument("--cpp-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpp_worker:
+        args.size = args.size or 16384
+        args.steps = args.steps if args.steps is not None else 10
+        args.warmup = args.warmup if args.warmup is not None else 2
+        return cpp_worker(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -362,6 +484,8 @@ def main():
             dist.init_process_group("gloo", timeout=tmo)
         else:
             dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+        # CPU-side barrier for the time rank 0's child process owns the GPUs (an RCCL barrier would spin a kernel on every GPU)
+        cpu_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=int(os.environ.get("ITW_BENCH_CPP_TIMEOUT_S", "600")) + 120))
 
     fmt, prof = WORKLOADS[args.workload]
     heavy = fmt in ("bc7", "bc6h")
@@ -520,6 +644,40 @@ def main():
                                    "workload": f"{args.workload} on a 4096 x {4096 * world} surface, one 4096^2 band per rank"}
         del w_pipe
 
+    # N > 1: the same job through the C++ host path (one process, itwCompressImageMultiGPUEx) -- the headline when it succeeds
+    want_cpp = world > 1 and scaling == "strong" and args.host in ("auto", "cpp") and (not FAKE or os.environ.get("ITW_BENCH_FAKE_CPP"))
+    if want_cpp:
+        if not FAKE:
+            torch.cuda.empty_cache()
+            _sync()
+        dist.barrier(group=cpu_group)
+        cpp = run_cpp_child(args, world, size, steps, warmup) if rank == 0 else None
+        dist.barrier(group=cpu_group)                         # ranks 1..N-1 wait on the CPU while the child owns the GPUs
+        if rank == 0:
+            python_side = {k: result.get(k) for k in ("value", "unit", "ms_per_step", "gather_verified", "mismatching_bytes", "band_checks",
+                                                      "per_rank_kernel_ms", "how")}
+            python_side["host"] = "python: one process per GPU, torch.distributed all_gather_into_tensor (RCCL), gather of step i under encode i+1"
+            python_side["ranks_seen_by_rccl"] = result["config"]["ranks_seen_by_rccl"]
+            result["python_side"] = python_side
+            if "error" not in cpp and cpp.get("gather_verified"):
+                for k in ("value", "ms_per_step", "gather_verified", "mismatching_bytes", "band_checks", "how"):
+                    result[k] = cpp.get(k)
+                result["steps"], result["warmup"] = cpp["steps"], cpp["warmup"]
+                result["config"]["host"] = cpp["host"]
+                result["config"]["sharding"] = ("block-row bands, one per rank (itwBandForPart), band r resident on GPU r; gather of the block stream "
+                                                "to GPU 0 by RCCL ncclSend / grouped ncclRecv on a second stream, a rank's first half-band under its second half's encode")
+                result["config"]["ranks_seen_by_rccl"] = cpp["ranks_seen_by_rccl"]
+                result["config"]["transport"] = cpp["transport"]
+                result["timing"] = ("C++ job: K synchronous itwCompressImageMultiGPUEx calls (every rank stream drained before a call returns) between two "
+                                    "all-device synchronisations, wall clock of the one process that drives all N GPUs; python_side: barrier + "
+                                    "synchronize on both sides, MAX over ranks")
+                result["cpp_host"] = {k: cpp.get(k) for k in ("transport", "transport_note", "ranks_seen_by_rccl", "peer_links", "devices",
+                                                              "first_call_wall_ms", "stats_last_call", "scatter_from_gpu0")}
+            else:
+                cpp["note"] = "the C++ job did not produce a verified result: the headline is the torch.distributed job (python_side)"
+                result["cpp_host"] = cpp
+                result["config"]["host"] = python_side["host"]
+
     size_side = 4096
     if rank == 0 and world == 1 and not args.no_formats and size == 4096:
         size, nblocks = size_side, (size_side // 4) ** 2
@@ -589,6 +747,39 @@ def main():
                 pass
             except Exception as e:
                 side["@16384"] = {"error": repr(e)}
+            # The C++ multi-GPU entry on this one device: the 16384^2 `slow` surface of configs[4] through 8
+            # virtual ranks (8 host threads x 2 half-bands on 8 stream pairs of the same GPU, encoded in place) against ONE call --
+            # what the dispatch layer costs; same bytes required
+            try:
+                if args.no_16k:
+                    raise StopIteration
+                big = 16384
+                d2 = torch.from_numpy(make_surface("bc7", 4096, 0)).to(dev).repeat(big // 4096, big // 4096, 1).contiguous()
+                o2 = torch.empty((big // 4) ** 2 * 16, dtype=torch.uint8, device=dev)
+                o3 = torch.zeros_like(o2)
+                one_avg, one_min = time_kernel(itw_amd, "bc7", "slow", d2, o2, steps=3, warmup=1)
+                st = itw_amd.MultiGpuStats()
+                itw_amd.compress_image_multigpu("bc7", d2, "slow", ranks=8, out=o3, stats=st)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    itw_amd.compress_image_multigpu("bc7", d2, "slow", ranks=8, out=o3, stats=st)
+                torch.cuda.synchronize()
+                multi_ms = (time.perf_counter() - t0) / 3 * 1e3
+                sd = st.as_dict()
+                side["multigpu_cpp@8virtual_16384"] = {
+                    "what": "bc7 slow, one 16384^2 surface: itwCompressImageMultiGPUEx with 8 ranks on this one device vs one CompressBlocksBC7 call",
+                    "single_call_ms": round(one_avg, 3), "multigpu_8virtual_ms": round(multi_ms, 3), "overhead_frac": round(multi_ms / one_avg - 1.0, 4),
+                    "Mpixels/s": round(big * big / (multi_ms * 1e-3) / 1e6, 1), "identical_bytes": bool(torch.equal(o2, o3)),
+                    "transport": sd["transport"], "transport_note": sd["transport_note"], "posted_ms": sd["posted_ms"], "wall_ms_last_call": sd["wall_ms"],
+                    "per_rank_encode_ms": [r["encode_ms"] for r in sd["per_rank"]],
+                    "timing": "single call: HIP events on its stream, 3 calls; multi: wall clock of 3 synchronous calls (includes waking 8 host threads)"}
+                del d2, o2, o3
+                torch.cuda.empty_cache()
+            except StopIteration:
+                pass
+            except Exception as e:
+                side["multigpu_cpp@8virtual_16384"] = {"error": repr(e)}
             # SURVEY 8(d) input I4 / BASELINE configs[3]: the reference's monkey-32bit.hdr (RGBE -> RGBA16F, committed as a
             # fixture: tests/golden/inputs.npz) tiled 19 x 19 and cropped to 4096^2
             try:

@@ -19,10 +19,12 @@
  * Failures: the ranks allocate everything first and post transfers only if all of them are ready; a failure after that
  * aborts the RCCL communicators so no rank keeps waiting for a peer that will not send (rebuilt on the next call).  The
  * call then fails as a whole: abort() with a diagnostic, or `false` + itwLastError() under ITW_ON_ERROR_RETURN.
+ * A watchdog covers the one thing a failure model cannot: a rank that neither fails nor proceeds (itwCompressImageMultiGPUEx).
  */
 #ifndef ITW_MULTIGPU_H
 #define ITW_MULTIGPU_H
 
+#include <stdint.h>
 #include "itw_dispatch.h"
 
 #ifdef __cplusplus
@@ -44,6 +46,48 @@ int itwMultiGpuPeerLinks(void);
  * whole block stream in `output`.  Pointers: host or device, as for CompressBlocks*.  Synchronous.  Returns false only in
  * error mode "return" (itwSetErrorMode) when some rank failed; itwLastError() then holds the message. */
 bool itwCompressImageMultiGPU(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks);
+
+/* What one call did, per rank (device-side durations from HIP events on the rank's own streams, summed over its two
+ * half-bands) and as a whole.  `transport` = "rccl" | "peer" | "host" (output in host memory: every GPU downloads its own
+ * band); `transport_note` says why RCCL was not used when it was not.  `rccl_ranks` = size of the communicator clique
+ * the gather ran on (0 unless transport is "rccl"). */
+typedef struct itw_multigpu_rank_stats {
+    int32_t rank, device;
+    int32_t block_row0, block_rows;      /* the rank's band (itwBandForPart's rule) */
+    float   upload_ms;                   /* host->GPU or owner GPU->GPU copies of the band's texels (0 when encoded in place) */
+    float   encode_ms;                   /* the CompressBlocks* launches */
+    float   gather_ms;                   /* D2H / ncclSend / peer copy of the band's blocks; on the owner rank: its grouped ncclRecv */
+    float   span_ms;                     /* first device-side event to last: upload, encode and gather overlap inside it */
+} itw_multigpu_rank_stats;
+
+typedef struct itw_multigpu_stats {
+    int32_t ranks, devices, peer_links, rccl_ranks;
+    int32_t watchdog_fired;              /* 1 = a rank did not finish posting its work in time and the call was aborted */
+    int32_t resident_bands;              /* 1 = the texels were already on the ranks' devices (no scatter) */
+    float   wall_ms;                     /* host wall clock of the whole call */
+    float   posted_ms;                   /* host wall clock until every rank had posted all its work (launch + enqueue cost) */
+    char    transport[8];
+    char    transport_note[96];
+    itw_multigpu_rank_stats rank[64];
+} itw_multigpu_stats;
+
+/* The same call with two optional extras.
+ *   resident_bands  NULL, or an array of `ranks` surfaces: band r of the image (block rows itwBandForPart(r, ranks)),
+ *                   already resident on the device rank r runs on (device r % device_count) -- the tile-sharded input of
+ *                   a pipeline that produced the texels where they are encoded.  No scatter happens; `input` then only
+ *                   carries width / height (its ptr may be NULL).  ranks must be given explicitly (> 0).
+ *   stats           NULL, or where to leave the call's account (filled on failure too, as far as the call got).
+ * Watchdog: a rank that has not posted all its work (launches, copies, ncclSend / ncclGroupEnd) within
+ * ITW_MULTIGPU_POST_TIMEOUT_S (default 30) -- the first RCCL call of a process sets up its peer connections inside those
+ * calls -- or a call that has not finished within ITW_MULTIGPU_TIMEOUT_S (default 600) is aborted through the same path
+ * as a failing rank (ncclCommAbort on every communicator); the call fails with "watchdog" in the message. */
+bool itwCompressImageMultiGPUEx(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks,
+                                const rgba_surface* resident_bands, itw_multigpu_stats* stats);
+
+/* Test hook (tests/test_gpu_multigpu_cpp.py): the NEXT call on this process fails inside rank `rank` at `stage`
+ * (1 = while preparing, before any transfer is posted; 2 = after its first half-band was posted; 3 = the rank stalls for
+ * `stall_ms` before posting anything, which is what the watchdog is for).  One-shot; nothing in the environment can set it. */
+void itwMultiGpuTestInjectFailure(int rank, int stage, int stall_ms);
 
 #ifdef __cplusplus
 }

@@ -1869,7 +1869,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                 else       hipLaunchKernelGGL((bc7_finish_all<false, PH>), L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, rgb_list, rgb_count);
             };
             if (bc7_alpha_first(S)) {
-                (void)hipMemsetAsync(rgb_count, 0, sizeof(int32_t), st);
+                ITW_CHECK(hipMemsetAsync(rgb_count, 0, sizeof(int32_t), st));      // finish<1> appends to the list through it
                 scan_7();
                 finish(std::integral_constant<int, 1>{});
                 scan_rgb(rgb_list, rgb_count);
@@ -1897,7 +1897,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
         launch_finish<F_MODE7>(L);
     }
     if (S.mode_selection[2] || S.mode_selection[3]) launch_finish<F_MODES456>(L);
-    if (L.first) (void)hipMemsetAsync(dst, 0, (size_t)n * 16, st);   // no mode enabled: defined (zero) output
+    if (L.first) ITW_CHECK(hipMemsetAsync(dst, 0, (size_t)n * 16, st));   // no mode enabled: defined (zero) output
 }
 
 } // namespace itw

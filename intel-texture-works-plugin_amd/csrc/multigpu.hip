@@ -1,30 +1,39 @@
-// multigpu.hip -- itwCompressImageMultiGPU (include/itw_multigpu.h): one surface over all GPUs of the node from ONE
+// multigpu.hip -- itwCompressImageMultiGPU[Ex] (include/itw_multigpu.h): one surface over all GPUs of the node from ONE
 // process, host code in C++: band per rank (win32Threads.cpp:217-231 on block rows), scatter of a device-resident
-// surface by peer copies, gather of the output bands to the owner of `output` by RCCL send/recv (or peer copies), the
-// gather of a rank's first half-band overlapping the encode of its second.
+// surface by peer copies (or none: bands already resident on their devices), gather of the output bands to the owner of
+// `output` by RCCL send/recv (or peer copies), a rank's band cut in two so that the upload of its second half and the gather
+// of its first run under an encode.
 //
 // One persistent host thread per rank, bound to its device: CompressBlocks* keeps per-thread, per-device state (stream,
 // BC7 workspace), so a rank's thread is the natural owner of its streams and staging buffers.
 //
-// Failure model (ADVICE r02).  A rank that fails must never leave another rank waiting in a collective:
+// Failure model (ADVICE r02, r03).  A rank that fails must never leave another rank waiting in a collective:
 //   * everything that can fail for lack of resources (streams, events, peer access, staging buffers) happens in a PREPARE
 //     step; the ranks then meet at a host-side barrier and post transfers only if every rank is ready;
 //   * a failure after that point (a launch, a copy) raises the call's abort flag and, on the RCCL transport, calls
 //     ncclCommAbort on every communicator, which releases a peer blocked in ncclGroupEnd / hipStreamSynchronize; the
-//     communicators are rebuilt by the next call;
+//     communicators are rebuilt by the next call.  Every use of a communicator handle happens under that communicator's
+//     mutex with the abort flag re-checked inside, and the abort takes the same mutex (bounded wait: a rank that sits INSIDE
+//     an RCCL call is exactly the one the abort has to release), so no thread enters RCCL with a handle that was freed;
 //   * a failed rank drains its streams before it reports, so the next call never reuses buffers that still have work queued;
 //   * any C++ exception ends the rank's work as a failure, and the submitting thread reports it through report_failure():
-//     abort mode aborts loudly, return mode returns false with the message in itwLastError().
+//     abort mode aborts loudly, return mode returns false with the message in itwLastError();
+//   * a rank that neither fails nor proceeds is the watchdog's: the submitting thread, which only waits, aborts the call
+//     when a rank has not posted its work within ITW_MULTIGPU_POST_TIMEOUT_S (the first RCCL send/recv of a process sets up
+//     its connections inside ncclSend / ncclGroupEnd) or the call has not finished within ITW_MULTIGPU_TIMEOUT_S.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types and prototypes only: the symbols are resolved with dlsym on first use
 #include <dlfcn.h>
 #include <sched.h>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <future>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -34,11 +43,16 @@
 
 namespace {
 
+constexpr int MAX_RANKS = 64;
+using Clock = std::chrono::steady_clock;
+double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
 struct Rccl {
     void* lib = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclCommAbort) CommAbort = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -50,7 +64,8 @@ struct Rccl {
         for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
         if (!lib) return false;
 #define ITW_SYM(f) f = reinterpret_cast<decltype(f)>(dlsym(lib, "nccl" #f)); if (!f) { dlclose(lib); lib = nullptr; return false; }
-        ITW_SYM(CommInitAll) ITW_SYM(CommDestroy) ITW_SYM(CommAbort) ITW_SYM(Send) ITW_SYM(Recv) ITW_SYM(GroupStart) ITW_SYM(GroupEnd) ITW_SYM(GetErrorString)
+        ITW_SYM(CommInitAll) ITW_SYM(CommDestroy) ITW_SYM(CommAbort) ITW_SYM(CommCount) ITW_SYM(Send) ITW_SYM(Recv) ITW_SYM(GroupStart)
+        ITW_SYM(GroupEnd) ITW_SYM(GetErrorString)
 #undef ITW_SYM
         return true;
     }
@@ -62,41 +77,57 @@ struct Call {                      // one itwCompressImageMultiGPU call, shared 
     rgba_surface input;
     uint8_t* output = nullptr;
     CompressionFunc* fn = nullptr;
+    const rgba_surface* bands = nullptr;                   // resident bands (one per rank, on the rank's device) or nullptr
     int bpb = 16, texel_bytes = 4, ranks = 1;
     bool keep_partial = false;
     bool src_dev = false, dst_dev = false;
     int src_device = -1, dst_device = -1, dst_rank = -1;   // dst_rank: the rank (on dst_device) that posts the receives
     bool use_rccl = false;
-    int fail_rank = -1, fail_stage = 0;                    // test hook (ITW_MULTIGPU_TEST_FAIL="rank:stage"): that rank throws in
-};                                                         // stage 1 = prepare, 2 = after its first half-band was posted
+    int fail_rank = -1, fail_stage = 0, stall_ms = 0;      // itwMultiGpuTestInjectFailure
+};
+
+// device-side timestamps of one rank and one call: [half][begin, end] per activity
+enum { T_UP = 0, T_ENC = 1, T_GATHER = 2, T_RECV = 3, T_KINDS = 4 };
 
 struct RankCtx {
     int rank = 0, device = 0;
     std::thread th;
     hipStream_t enc = nullptr, xfer = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ev[T_KINDS][2][2] = {};                     // [kind][half][begin | end], timing enabled
+    bool rec[T_KINDS][2] = {};                             // pair recorded in the current call
     void* d_in = nullptr;  size_t in_cap = 0;
     void* d_out = nullptr; size_t out_cap = 0;
     bool peers_enabled = false;
     bool pending = false, failed = false;
+    std::atomic<int> stage{0};                             // 0 idle / running, 1 prepared, 2 everything posted, 3 done
+    double posted_ms = 0.0;
+    itw_multigpu_rank_stats st{};
     char msg[384] = {0};
 };
 
 struct Group {
-    std::mutex m, submit;
+    std::mutex m, submit, abort_mu;
     std::condition_variable work, done, ready_cv;
     std::vector<RankCtx*> ranks;
     int devices = 1, outstanding = 0;
     int ready = 0;                      // ranks that finished PREPARE (ok or not) in the current call
     bool prepare_failed = false;        // some rank failed in PREPARE: nobody posts a transfer
-    std::atomic<bool> abort{false};     // some rank failed after PREPARE: the others stop posting work
+    std::atomic<bool> abort{false};     // some rank failed after PREPARE (or the watchdog fired): the others stop posting work
     bool comms_aborted = false;         // ncclCommAbort was called: communicators are rebuilt by the next call (g.m)
+    bool wedged = false;                // a rank thread never came back from a call: the group cannot be used again
+    bool rccl_dead = false;             // ncclCommInitAll did not return: RCCL is not tried again in this process
     bool quit = false;
     Call call;
+    Clock::time_point t0;
     Rccl rccl;
-    std::vector<ncclComm_t> comms;      // one per rank when RCCL is in use (ranks == distinct devices)
+    int ncomms = 0;                                        // communicators currently alive (= the rank count they were built for)
+    std::atomic<ncclComm_t> comms[MAX_RANKS];              // one per rank when RCCL is in use (ranks == distinct devices)
+    std::timed_mutex comm_mu[MAX_RANKS];                   // guards every use of comms[i] against abort_transfers()
     const char* transport = "peer";
+    char note[96] = {0};
     std::atomic<int> peer_links{0};     // directed device pairs with peer access enabled (xGMI instead of a bounce through the host)
+    std::atomic<int> inject_rank{-1}, inject_stage{0}, inject_stall{0};
+    Group() { for (auto& c : comms) c.store(nullptr); }
 };
 Group& g = *new Group;             // never destroyed: rank threads outlive static destruction
 
@@ -122,12 +153,13 @@ int device_of(const void* p)
 {
     hipPointerAttribute_t a;
     std::memset(&a, 0, sizeof a);
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    if (!p || hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
     return (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) ? a.device : -1;
 }
 
 // block rows [r0, r1) of rank r (itwBandForPart's rule), then the half-band cut
 void band_rows(int by, int rank, int ranks, int& r0, int& r1) { r0 = (int)((int64_t)by * rank / ranks); r1 = (int)((int64_t)by * (rank + 1) / ranks); }
+void half_cut(int r0, int r1, int (&cut)[3]) { cut[0] = r0; cut[1] = (r1 - r0 >= 2) ? r0 + (r1 - r0 + 1) / 2 : r1; cut[2] = r1; }
 
 // Peer access from this rank's device to every other device, once per rank thread: without it hipMemcpyPeerAsync and
 // hipMemcpy2DAsync(hipMemcpyDefault) between two GPUs may stage through host memory instead of using xGMI.
@@ -146,15 +178,36 @@ void enable_peers(RankCtx& c)
     }
 }
 
-// Releases every rank that waits in an RCCL call of this invocation.  Called by the first rank that fails after PREPARE.
+// Releases every rank that waits for a peer in this invocation: in the PREPARE barrier, or inside an RCCL call.  Called by the
+// first rank that fails after PREPARE and by the watchdog.  ncclCommAbort frees the communicator, so it runs under the
+// communicator's mutex (every enqueue holds it and re-checks the abort flag inside); if the mutex cannot be had for two seconds
+// its holder sits inside RCCL -- the very thread the abort must release -- and the abort goes ahead.
 void abort_transfers(const Call& k)
 {
     g.abort.store(true);
+    { std::lock_guard<std::mutex> lk(g.m); g.ready_cv.notify_all(); }
     if (!k.use_rccl) return;
+    std::lock_guard<std::mutex> one(g.abort_mu);
+    for (int i = 0; i < MAX_RANKS; i++) {
+        if (!g.comms[i].load()) continue;
+        const bool locked = g.comm_mu[i].try_lock_for(std::chrono::seconds(2));
+        ncclComm_t c = g.comms[i].exchange(nullptr);
+        if (c) (void)g.rccl.CommAbort(c);
+        if (locked) g.comm_mu[i].unlock();
+    }
     std::lock_guard<std::mutex> lk(g.m);
-    if (g.comms_aborted) return;
     g.comms_aborted = true;
-    for (ncclComm_t c : g.comms) if (c) (void)g.rccl.CommAbort(c);
+}
+
+// One enqueue on rank `rank`'s communicator: handle read and used under its mutex, abort flag re-checked inside.
+template <class F>
+void with_comm(int rank, F&& f)
+{
+    std::lock_guard<std::timed_mutex> lk(g.comm_mu[rank]);
+    if (g.abort.load()) itw::fail_msg("stopped: another rank failed");
+    ncclComm_t c = g.comms[rank].load();
+    if (!c) itw::fail_msg("stopped: the communicator was aborted");
+    f(c);
 }
 
 void drain(RankCtx& c) noexcept
@@ -162,6 +215,12 @@ void drain(RankCtx& c) noexcept
     if (c.enc) (void)hipStreamSynchronize(c.enc);
     if (c.xfer) (void)hipStreamSynchronize(c.xfer);
     (void)hipGetLastError();
+}
+
+void mark(RankCtx& c, int kind, int half, int end, hipStream_t st)
+{
+    ITW_CHECK(hipEventRecord(c.ev[kind][half][end], st));
+    if (end) c.rec[kind][half] = true;
 }
 
 // rows [y0, y1) of the input surface -> pitched staging on this GPU.  A signed / overlapping stride (bottom-up surfaces: the
@@ -179,6 +238,24 @@ void upload_rows(uint8_t* dpos, size_t pitch, const Call& k, int64_t y0, int64_t
     }
 }
 
+// the rank's account of the call, from whatever event pairs were recorded (all complete: the streams were synchronised or drained)
+void account(RankCtx& c) noexcept
+{
+    float sums[T_KINDS] = {0, 0, 0, 0}, last = 0.f;
+    hipEvent_t first = nullptr;
+    for (int kind = 0; kind < T_KINDS && !first; kind++) for (int h = 0; h < 2 && !first; h++) if (c.rec[kind][h]) first = c.ev[kind][h][0];
+    for (int kind = 0; kind < T_KINDS; kind++)
+        for (int h = 0; h < 2; h++) {
+            if (!c.rec[kind][h]) continue;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c.ev[kind][h][0], c.ev[kind][h][1]) == hipSuccess) sums[kind] += ms;
+            if (first && hipEventElapsedTime(&ms, first, c.ev[kind][h][1]) == hipSuccess && ms > last) last = ms;
+            // (the very first event recorded is the band's first upload or, without uploads, its first encode: nothing starts earlier)
+        }
+    (void)hipGetLastError();
+    c.st.upload_ms = sums[T_UP]; c.st.encode_ms = sums[T_ENC]; c.st.gather_ms = sums[T_GATHER] + sums[T_RECV]; c.st.span_ms = last;
+}
+
 void run_rank(RankCtx& c, const Call& k)
 {
     const int w = k.input.width, h = k.input.height;
@@ -188,13 +265,16 @@ void run_rank(RankCtx& c, const Call& k)
     const bool idle = r1 <= r0;
     const size_t row_bytes = (size_t)w * k.texel_bytes;
     const size_t pitch = (row_bytes + 15) & ~(size_t)15;
-    const bool src_here = k.src_dev && k.src_device == c.device;
+    const bool src_here = k.bands || (k.src_dev && k.src_device == c.device);       // texels already on this GPU: encoded in place
     const bool dst_here = k.dst_dev && k.dst_device == c.device;
     const size_t band_out = idle ? 0 : (size_t)(r1 - r0) * bx * k.bpb;
     const int64_t first_row = (int64_t)r0 * 4;
     const int64_t last_row = (r1 == by) ? h : (int64_t)r1 * 4;                    // the last band keeps a partial block row (BC4/BC5)
     uint8_t* in = nullptr;
     uint8_t* out = nullptr;
+    std::memset(c.rec, 0, sizeof c.rec);
+    c.st = itw_multigpu_rank_stats{};
+    c.st.rank = c.rank; c.st.device = c.device; c.st.block_row0 = r0; c.st.block_rows = idle ? 0 : r1 - r0;
 
     // ---- PREPARE: everything that can fail for lack of resources, before any transfer is posted ----
     itw::Failure early;
@@ -203,31 +283,46 @@ void run_rank(RankCtx& c, const Call& k)
         if (!c.enc) {
             ITW_CHECK(hipStreamCreateWithFlags(&c.enc, hipStreamNonBlocking));
             ITW_CHECK(hipStreamCreateWithFlags(&c.xfer, hipStreamNonBlocking));
-            for (auto& e : c.ev) ITW_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            for (auto& kind : c.ev) for (auto& half : kind) for (auto& e : half) ITW_CHECK(hipEventCreate(&e));
         }
         enable_peers(c);
         if (!idle) {
+            if (k.bands) {
+                const rgba_surface& b = k.bands[c.rank];
+                if (!b.ptr || b.width != w || (int64_t)b.height < last_row - first_row)
+                    itw::fail_msg("resident band %d: %dx%d texels at %p, expected %d x %lld", c.rank, b.width, b.height, (void*)b.ptr, w, (long long)(last_row - first_row));
+                if (device_of(b.ptr) != c.device) itw::fail_msg("resident band %d is not on device %d (the device rank %d runs on)", c.rank, c.device, c.rank);
+            }
             in = src_here ? nullptr : (uint8_t*)grow(c.d_in, c.in_cap, pitch * (size_t)(last_row - first_row));
             out = dst_here ? k.output + (size_t)r0 * bx * k.bpb : (uint8_t*)grow(c.d_out, c.out_cap, band_out);
         }
-        if (k.fail_rank == c.rank && k.fail_stage == 1) itw::fail_msg("injected failure in PREPARE (ITW_MULTIGPU_TEST_FAIL)");
+        if (k.fail_rank == c.rank && k.fail_stage == 1) itw::fail_msg("injected failure in PREPARE (itwMultiGpuTestInjectFailure)");
     } catch (const itw::Failure& f) { early = f; early_failed = true; }
     catch (...) { std::snprintf(early.msg, sizeof early.msg, "unexpected C++ exception in PREPARE"); early_failed = true; }   // the barrier below must be reached
     {
         std::unique_lock<std::mutex> lk(g.m);
         if (early_failed) g.prepare_failed = true;
         if (++g.ready == k.ranks) g.ready_cv.notify_all();
-        else g.ready_cv.wait(lk, [&] { return g.ready >= k.ranks; });
+        else g.ready_cv.wait(lk, [&] { return g.ready >= k.ranks || g.abort.load(); });
         if (early_failed) throw early;
         if (g.prepare_failed) return;                    // another rank cannot take part: nobody sends, nobody waits
+        if (g.ready < k.ranks) itw::fail_msg("stopped: another rank never finished preparing (watchdog)");
     }
-    if (idle) return;
+    c.stage.store(1);
+    if (k.fail_rank == c.rank && k.fail_stage == 3)      // a rank that neither fails nor proceeds: the watchdog's case
+        for (int waited = 0; waited < k.stall_ms && !g.abort.load(); waited += 20) std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    if (idle) { c.posted_ms = ms_since(g.t0); c.stage.store(2); return; }
 
     // ---- TRANSFER + ENCODE ----
+    // Posting order: upload 0, encode 0 | upload 1 on the transfer stream (runs under encode 0), encode 1 | gather 0, gather 1 on
+    // the transfer stream (gather 0 runs under encode 1).  The gathers are posted last because a download into pageable host
+    // memory blocks the posting thread until the copy is done: posted earlier it would hold back the second encode's launch.
     try {
         itwSetStream(c.enc);
-        const int mid = r0 + (r1 - r0 + 1) / 2;
-        const int cut[3] = {r0, (r1 - r0 >= 2) ? mid : r1, r1};
+        int cut[3];
+        half_cut(r0, r1, cut);
+        uint8_t* o[2] = {nullptr, nullptr};
+        size_t nbytes[2] = {0, 0};
         for (int s = 0; s < 2; s++) {
             const int a = cut[s], b = cut[s + 1];
             if (b <= a) continue;
@@ -235,48 +330,69 @@ void run_rank(RankCtx& c, const Call& k)
             const int64_t y0 = (int64_t)a * 4, y1 = (b == by) ? h : (int64_t)b * 4;
             rgba_surface sub = k.input;
             sub.height = (int)(y1 - y0);
-            if (src_here) {
+            if (k.bands) {
+                const rgba_surface& band = k.bands[c.rank];
+                sub.ptr = band.ptr + (y0 - first_row) * (int64_t)band.stride;
+                sub.stride = band.stride;
+            } else if (src_here) {
                 sub.ptr = k.input.ptr + y0 * (int64_t)k.input.stride;
             } else {
-                // host -> this GPU over its own PCIe link, or owner GPU -> this GPU over xGMI
+                // host -> this GPU over its own PCIe link, or owner GPU -> this GPU over xGMI; the second half on the transfer stream
                 uint8_t* dpos = in + (size_t)(y0 - first_row) * pitch;
-                upload_rows(dpos, pitch, k, y0, y1, row_bytes, c.enc);
+                const hipStream_t up = (s == 0) ? c.enc : c.xfer;
+                mark(c, T_UP, s, 0, up);
+                upload_rows(dpos, pitch, k, y0, y1, row_bytes, up);
+                mark(c, T_UP, s, 1, up);
+                if (s == 1) ITW_CHECK(hipStreamWaitEvent(c.enc, c.ev[T_UP][1][1], 0));
                 sub.ptr = dpos;
                 sub.stride = (int32_t)pitch;
             }
-            uint8_t* o = out + (size_t)(a - r0) * bx * k.bpb;
-            const size_t nbytes = (size_t)(b - a) * bx * k.bpb;
+            o[s] = out + (size_t)(a - r0) * bx * k.bpb;
+            nbytes[s] = (size_t)(b - a) * bx * k.bpb;
             itwClearError();
-            k.fn(&sub, o);                                                            // device pointers: asynchronous on c.enc
+            mark(c, T_ENC, s, 0, c.enc);
+            k.fn(&sub, o[s]);                                                         // device pointers: asynchronous on c.enc
             if (const char* e = itwLastError()) itw::fail_msg("%s", e);
-            if (!dst_here) {                                                          // (else: encoded in place)
-                ITW_CHECK(hipEventRecord(c.ev[s], c.enc));
-                ITW_CHECK(hipStreamWaitEvent(c.xfer, c.ev[s], 0));                    // the gather of this half runs under the next half's encode
-                uint8_t* dpos = k.output + (size_t)a * bx * k.bpb;
-                if (!k.dst_dev)      ITW_CHECK(hipMemcpyAsync(dpos, o, nbytes, hipMemcpyDeviceToHost, c.xfer));
-                else if (k.use_rccl) ITW_NCCL(g.rccl.Send(o, nbytes, ncclUint8, k.dst_rank, g.comms[c.rank], c.xfer));
-                else                 ITW_CHECK(hipMemcpyPeerAsync(dpos, k.dst_device, o, c.device, nbytes, c.xfer));
+            mark(c, T_ENC, s, 1, c.enc);
+        }
+        if (!dst_here) {                                                              // (else: encoded in place)
+            for (int s = 0; s < 2; s++) {
+                if (!nbytes[s]) continue;
+                if (g.abort.load()) itw::fail_msg("stopped: another rank failed");
+                ITW_CHECK(hipStreamWaitEvent(c.xfer, c.ev[T_ENC][s][1], 0));
+                uint8_t* dpos = k.output + (size_t)cut[s] * bx * k.bpb;
+                mark(c, T_GATHER, s, 0, c.xfer);
+                if (!k.dst_dev)      ITW_CHECK(hipMemcpyAsync(dpos, o[s], nbytes[s], hipMemcpyDeviceToHost, c.xfer));
+                else if (k.use_rccl) with_comm(c.rank, [&](ncclComm_t comm) { ITW_NCCL(g.rccl.Send(o[s], nbytes[s], ncclUint8, k.dst_rank, comm, c.xfer)); });
+                else                 ITW_CHECK(hipMemcpyPeerAsync(dpos, k.dst_device, o[s], c.device, nbytes[s], c.xfer));
+                mark(c, T_GATHER, s, 1, c.xfer);
+                if (s == 0 && k.fail_rank == c.rank && k.fail_stage == 2) itw::fail_msg("injected failure after the first half-band (itwMultiGpuTestInjectFailure)");
             }
-            if (k.fail_rank == c.rank && k.fail_stage == 2) itw::fail_msg("injected failure after the first half-band (ITW_MULTIGPU_TEST_FAIL)");
+        } else if (k.fail_rank == c.rank && k.fail_stage == 2) {
+            itw::fail_msg("injected failure after the first half-band (itwMultiGpuTestInjectFailure)");
         }
         // the rank that owns `output` posts the matching receives, one group per half so halves complete independently
         if (k.use_rccl && k.dst_dev && c.rank == k.dst_rank) {
             for (int s = 0; s < 2; s++) {
-                if (g.abort.load()) itw::fail_msg("stopped: another rank failed");
-                ITW_NCCL(g.rccl.GroupStart());
-                for (int p = 0; p < k.ranks; p++) {
-                    if (p == c.rank) continue;
-                    int p0, p1;
-                    band_rows(by, p, k.ranks, p0, p1);
-                    if (p1 <= p0) continue;
-                    const int pm = p0 + (p1 - p0 + 1) / 2;
-                    const int pc[3] = {p0, (p1 - p0 >= 2) ? pm : p1, p1};
-                    if (pc[s + 1] <= pc[s]) continue;
-                    ITW_NCCL(g.rccl.Recv(k.output + (size_t)pc[s] * bx * k.bpb, (size_t)(pc[s + 1] - pc[s]) * bx * k.bpb, ncclUint8, p, g.comms[c.rank], c.xfer));
-                }
-                ITW_NCCL(g.rccl.GroupEnd());
+                mark(c, T_RECV, s, 0, c.xfer);
+                with_comm(c.rank, [&](ncclComm_t comm) {
+                    ITW_NCCL(g.rccl.GroupStart());
+                    for (int p = 0; p < k.ranks; p++) {
+                        if (p == c.rank) continue;
+                        int p0, p1, pc[3];
+                        band_rows(by, p, k.ranks, p0, p1);
+                        if (p1 <= p0) continue;
+                        half_cut(p0, p1, pc);
+                        if (pc[s + 1] <= pc[s]) continue;
+                        ITW_NCCL(g.rccl.Recv(k.output + (size_t)pc[s] * bx * k.bpb, (size_t)(pc[s + 1] - pc[s]) * bx * k.bpb, ncclUint8, p, comm, c.xfer));
+                    }
+                    ITW_NCCL(g.rccl.GroupEnd());
+                });
+                mark(c, T_RECV, s, 1, c.xfer);
             }
         }
+        c.posted_ms = ms_since(g.t0);
+        c.stage.store(2);
         ITW_CHECK(hipStreamSynchronize(c.enc));
         ITW_CHECK(hipStreamSynchronize(c.xfer));
         if (g.abort.load()) itw::fail_msg("stopped: another rank failed");           // an aborted communicator completes its streams without data
@@ -289,7 +405,8 @@ void run_rank(RankCtx& c, const Call& k)
 
 // Best effort: run the rank's host thread on the CPUs of its GPU's NUMA node, so that the pageable band uploads / downloads of the
 // host-pointer case stay on the socket the GPU hangs off.  PCI bus id -> sysfs numa_node -> that node's
-// cpulist -> sched_setaffinity.  Anything missing (no sysfs, node -1, one-node box): the thread keeps its affinity.
+// cpulist, INTERSECTED with the affinity the thread inherited (taskset / numactl / the job scheduler stay in charge: ADVICE r03)
+// -> sched_setaffinity.  Anything missing (no sysfs, node -1, one-node box, empty intersection): the thread keeps its affinity.
 // ITW_MULTIGPU_AFFINITY=0 disables it.
 void place_thread_near_device(int device)
 {
@@ -306,7 +423,9 @@ void place_thread_near_device(int device)
     std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
     char list[1024] = {0};
     if (FILE* f = std::fopen(path, "r")) { if (!std::fgets(list, (int)sizeof list, f)) list[0] = 0; std::fclose(f); }
-    cpu_set_t set;
+    cpu_set_t inherited, set;
+    CPU_ZERO(&inherited);
+    if (sched_getaffinity(0, sizeof inherited, &inherited) != 0) return;
     CPU_ZERO(&set);
     int any = 0;
     for (const char* p = list; *p;) {                            // "0-31,64-95"
@@ -315,7 +434,8 @@ void place_thread_near_device(int device)
         if (q == p) break;
         long b = a;
         if (*q == '-') { p = q + 1; b = std::strtol(p, &q, 10); }
-        for (long cpu = a; cpu <= b && cpu < CPU_SETSIZE; cpu++) { CPU_SET((int)cpu, &set); any = 1; }
+        for (long cpu = a; cpu <= b && cpu < CPU_SETSIZE; cpu++)
+            if (CPU_ISSET((int)cpu, &inherited)) { CPU_SET((int)cpu, &set); any = 1; }
         p = (*q == ',') ? q + 1 : q;
         if (*q != ',' ) break;
     }
@@ -338,6 +458,8 @@ void rank_main(RankCtx* c)
         catch (const itw::Failure& f) { fail = f; bad = true; }
         catch (const std::exception& e) { std::snprintf(fail.msg, sizeof fail.msg, "C++ exception: %s", e.what()); bad = true; abort_transfers(k); drain(*c); }
         catch (...) { std::snprintf(fail.msg, sizeof fail.msg, "unexpected C++ exception"); bad = true; abort_transfers(k); drain(*c); }
+        account(*c);
+        c->stage.store(3);
         lk.lock();
         c->pending = false;
         c->failed = bad;
@@ -359,21 +481,156 @@ void ensure_ranks(int n)          // g.submit held
     }
 }
 
-// RCCL is usable for a call when every rank sits on its own device; communicators are (re)built when the rank count changes
-// or after a call that had to abort them
+int env_seconds(const char* name, int dflt)
+{
+    const char* e = std::getenv(name);
+    const int v = e ? std::atoi(e) : 0;
+    return v > 0 ? v : dflt;
+}
+
+// RCCL is usable for a call when every rank sits on its own device (rank r on device r); communicators are (re)built when the
+// rank count changes or after a call that had to abort them.  Says why not in g.note.  ncclCommInitAll runs on a helper thread so
+// that a hang inside it (fabric manager, IPC) ends as "peer transport" instead of a hung host application.
 bool prepare_rccl(int ranks)
 {
+    auto no = [](const char* why) { std::snprintf(g.note, sizeof g.note, "%s", why); return false; };
     const char* t = std::getenv("ITW_MULTIGPU_TRANSPORT");
-    if (t && !std::strcmp(t, "peer")) return false;
-    if (ranks > g.devices || !g.rccl.load()) return false;
-    if (g.comms_aborted) { g.comms.clear(); g.comms_aborted = false; }        // ncclCommAbort released them already
-    if ((int)g.comms.size() == ranks) return true;
-    for (ncclComm_t c : g.comms) if (c) (void)g.rccl.CommDestroy(c);
-    g.comms.assign((size_t)ranks, nullptr);
-    std::vector<int> devs((size_t)ranks);
-    for (int i = 0; i < ranks; i++) devs[(size_t)i] = i;
-    if (g.rccl.CommInitAll(g.comms.data(), ranks, devs.data()) != ncclSuccess) { g.comms.clear(); return false; }
+    if (t && !std::strcmp(t, "peer")) return no("ITW_MULTIGPU_TRANSPORT=peer");
+    if (ranks > g.devices) return no("more ranks than devices: ranks share a device, peer copies");
+    if (g.rccl_dead) return no("ncclCommInitAll did not return earlier in this process");
+    if (!g.rccl.load()) return no("librccl.so could not be loaded");
+    if (g.comms_aborted) { g.ncomms = 0; g.comms_aborted = false; }        // ncclCommAbort released them already (handles are null)
+    if (g.ncomms == ranks) return true;
+    for (int i = 0; i < MAX_RANKS; i++) if (ncclComm_t c = g.comms[i].exchange(nullptr)) (void)g.rccl.CommDestroy(c);
+    g.ncomms = 0;
+    struct Init { std::vector<ncclComm_t> comms; std::vector<int> devs; ncclResult_t rc = ncclSuccess; };
+    auto init = std::make_shared<Init>();
+    init->comms.assign((size_t)ranks, nullptr);
+    init->devs.resize((size_t)ranks);
+    for (int i = 0; i < ranks; i++) init->devs[(size_t)i] = i;
+    auto fin = std::make_shared<std::promise<void>>();
+    std::future<void> fut = fin->get_future();
+    const auto fn = g.rccl.CommInitAll;
+    std::thread([init, fin, fn, ranks] { init->rc = fn(init->comms.data(), ranks, init->devs.data()); fin->set_value(); }).detach();
+    if (fut.wait_for(std::chrono::seconds(env_seconds("ITW_MULTIGPU_INIT_TIMEOUT_S", 120))) != std::future_status::ready) {
+        g.rccl_dead = true;
+        return no("ncclCommInitAll did not return in time");
+    }
+    if (init->rc != ncclSuccess) { std::snprintf(g.note, sizeof g.note, "ncclCommInitAll failed: %.60s", g.rccl.GetErrorString(init->rc)); return false; }
+    for (int i = 0; i < ranks; i++) g.comms[i].store(init->comms[(size_t)i]);
+    g.ncomms = ranks;
     return true;
+}
+
+bool compress_multi(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks,
+                    const rgba_surface* bands, itw_multigpu_stats* stats)
+{
+    bool ok = false;
+    itwClearError();
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    itw::guarded([&] {
+        if (!input || (!input->ptr && !bands) || !output || !cmpFunc) itw::fail_msg("itwCompressImageMultiGPU: null argument");
+        if (bands && ranks <= 0) itw::fail_msg("itwCompressImageMultiGPUEx: resident bands need an explicit rank count");
+        std::lock_guard<std::mutex> one(g.submit);
+        if (g.wedged) itw::fail_msg("itwCompressImageMultiGPU: a rank thread never returned from an earlier call (watchdog); restart the process");
+        Call k;
+        k.input = *input; k.output = output; k.fn = cmpFunc; k.bands = bands;
+        k.keep_partial = dxgi_format == ITW_DXGI_FORMAT_BC4_UNORM || dxgi_format == ITW_DXGI_FORMAT_BC5_UNORM;
+        k.bpb = GetBytesPerBlock(dxgi_format);
+        k.texel_bytes = (dxgi_format == ITW_DXGI_FORMAT_BC6H_UF16 || dxgi_format == ITW_DXGI_FORMAT_BC6H_SF16) ? 8 : 4;
+        const int by = k.keep_partial ? (input->height + 3) / 4 : input->height / 4;
+        if (by <= 0 || input->width < (k.keep_partial ? 1 : 4)) { ok = true; return; }
+        int n = ranks > 0 ? ranks : itwMultiGpuRanks();
+        n = n > MAX_RANKS ? MAX_RANKS : n;
+        if (bands && n > by) itw::fail_msg("itwCompressImageMultiGPUEx: %d resident bands for %d block rows", n, by);
+        n = n > by ? by : n;
+        k.ranks = n;
+        ensure_ranks(n);
+        k.src_device = bands ? -1 : device_of(input->ptr); k.src_dev = k.src_device >= 0;
+        k.dst_device = device_of(output);     k.dst_dev = k.dst_device >= 0;
+        k.dst_rank = k.dst_dev ? k.dst_device % g.devices : -1;                  // rank r lives on device r % devices: the lowest one there
+        if (k.dst_dev && k.dst_rank >= n) k.dst_rank = -1;                        // no rank on the owner: peer copies only
+        g.note[0] = 0;
+        if (!k.dst_dev) std::snprintf(g.note, sizeof g.note, "output in host memory: every GPU downloads its own band");
+        else if (n == 1) std::snprintf(g.note, sizeof g.note, "one rank: nothing to gather");
+        else if (k.dst_rank < 0) std::snprintf(g.note, sizeof g.note, "no rank runs on the device that owns the output: peer copies");
+        k.use_rccl = k.dst_dev && k.dst_rank >= 0 && n > 1 && prepare_rccl(n);
+        g.transport = k.use_rccl ? "rccl" : (k.dst_dev ? "peer" : "host");
+        k.fail_rank = g.inject_rank.exchange(-1); k.fail_stage = g.inject_stage.exchange(0); k.stall_ms = g.inject_stall.exchange(0);
+        {
+            std::lock_guard<std::mutex> lk(g.m);
+            g.call = k;
+            g.t0 = Clock::now();
+            g.ready = 0; g.prepare_failed = false; g.abort.store(false);
+            for (int i = 0; i < n; i++) { RankCtx* c = g.ranks[(size_t)i]; c->pending = true; c->failed = false; c->stage.store(0); c->posted_ms = 0.0; }
+            g.outstanding = n;
+        }
+        g.work.notify_all();
+        // The submitting thread only waits: it is the watchdog.
+        const double post_limit = 1e3 * env_seconds("ITW_MULTIGPU_POST_TIMEOUT_S", 30), total_limit = 1e3 * env_seconds("ITW_MULTIGPU_TIMEOUT_S", 600);
+        bool fired = false;
+        double fired_at = 0.0;
+        std::unique_lock<std::mutex> lk(g.m);
+        while (g.outstanding != 0) {
+            g.done.wait_for(lk, std::chrono::milliseconds(fired ? 100 : 250), [&] { return g.outstanding == 0; });
+            if (g.outstanding == 0) break;
+            const double t = ms_since(g.t0);
+            if (!fired) {
+                bool late = t > total_limit;
+                if (t > post_limit) for (int i = 0; i < n; i++) late = late || g.ranks[(size_t)i]->stage.load() < 2;
+                if (late) {
+                    fired = true; fired_at = t;
+                    lk.unlock();
+                    abort_transfers(k);              // releases the PREPARE barrier and every rank blocked inside RCCL
+                    lk.lock();
+                }
+            } else if (t > fired_at + 20e3) {
+                g.wedged = true;                     // a thread stuck in the driver cannot be recovered from here
+                break;
+            }
+        }
+        const double wall = ms_since(g.t0);
+        if (stats) {
+            stats->ranks = n; stats->devices = g.devices; stats->peer_links = g.peer_links.load();
+            stats->watchdog_fired = fired ? 1 : 0; stats->resident_bands = bands ? 1 : 0;
+            stats->wall_ms = (float)wall;
+            std::snprintf(stats->transport, sizeof stats->transport, "%s", g.transport);
+            std::snprintf(stats->transport_note, sizeof stats->transport_note, "%s", g.note);
+            double posted = 0.0;
+            for (int i = 0; i < n; i++) {
+                const RankCtx* c = g.ranks[(size_t)i];
+                if (c->stage.load() == 3) stats->rank[i] = c->st;
+                else { stats->rank[i] = itw_multigpu_rank_stats{}; stats->rank[i].rank = i; stats->rank[i].device = c->device; }
+                if (c->posted_ms > posted) posted = c->posted_ms;
+            }
+            stats->posted_ms = (float)posted;
+            if (k.use_rccl) {
+                ncclComm_t c0 = g.comms[k.dst_rank].load();
+                int cnt = 0;
+                if (c0 && g.rccl.CommCount(c0, &cnt) == ncclSuccess) stats->rccl_ranks = cnt;
+            }
+        }
+        if (g.wedged) {
+            itw::Failure f;
+            std::snprintf(f.msg, sizeof f.msg, "itwCompressImageMultiGPU: watchdog: a rank did not come back %.0f s after the call was aborted", (wall - fired_at) / 1e3);
+            lk.unlock();
+            throw f;
+        }
+        // report the rank that failed on its own, not one that merely stopped because of it
+        int first = -1;
+        for (int i = 0; i < n; i++)
+            if (g.ranks[(size_t)i]->failed && (first < 0 || std::strstr(g.ranks[(size_t)first]->msg, "stopped: "))) first = i;
+        if (first >= 0 || fired) {
+            itw::Failure f;
+            if (fired) std::snprintf(f.msg, sizeof f.msg, "watchdog: not every rank had posted its work after %.1f s (ITW_MULTIGPU_POST_TIMEOUT_S / _TIMEOUT_S); %.250s",
+                                     fired_at / 1e3, first >= 0 ? g.ranks[(size_t)first]->msg : "");
+            else std::snprintf(f.msg, sizeof f.msg, "%s", g.ranks[(size_t)first]->msg);
+            lk.unlock();
+            throw f;
+        }
+        ok = true;
+    });
+    return ok;
 }
 
 } // namespace
@@ -384,59 +641,27 @@ int itwMultiGpuRanks(void)
 {
     const char* e = std::getenv("ITW_MULTIGPU_RANKS");
     const int n = e ? std::atoi(e) : 0;
-    return n >= 1 ? (n > 64 ? 64 : n) : device_count();
+    return n >= 1 ? (n > MAX_RANKS ? MAX_RANKS : n) : device_count();
 }
 
 const char* itwMultiGpuTransport(void) { return g.transport; }
 
 int itwMultiGpuPeerLinks(void) { return g.peer_links.load(); }
 
+void itwMultiGpuTestInjectFailure(int rank, int stage, int stall_ms)
+{
+    g.inject_stage.store(stage); g.inject_stall.store(stall_ms); g.inject_rank.store(rank);
+}
+
 bool itwCompressImageMultiGPU(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks)
 {
-    bool ok = false;
-    itwClearError();
-    itw::guarded([&] {
-        if (!input || !input->ptr || !output || !cmpFunc) itw::fail_msg("itwCompressImageMultiGPU: null argument");
-        std::lock_guard<std::mutex> one(g.submit);
-        Call k;
-        k.input = *input; k.output = output; k.fn = cmpFunc;
-        k.keep_partial = dxgi_format == ITW_DXGI_FORMAT_BC4_UNORM || dxgi_format == ITW_DXGI_FORMAT_BC5_UNORM;
-        k.bpb = GetBytesPerBlock(dxgi_format);
-        k.texel_bytes = (dxgi_format == ITW_DXGI_FORMAT_BC6H_UF16 || dxgi_format == ITW_DXGI_FORMAT_BC6H_SF16) ? 8 : 4;
-        const int by = k.keep_partial ? (input->height + 3) / 4 : input->height / 4;
-        if (by <= 0 || input->width < (k.keep_partial ? 1 : 4)) { ok = true; return; }
-        int n = ranks > 0 ? ranks : itwMultiGpuRanks();
-        n = n > 64 ? 64 : (n > by ? by : n);
-        k.ranks = n;
-        ensure_ranks(n);
-        k.src_device = device_of(input->ptr); k.src_dev = k.src_device >= 0;
-        k.dst_device = device_of(output);     k.dst_dev = k.dst_device >= 0;
-        k.dst_rank = k.dst_dev ? k.dst_device % g.devices : -1;                  // rank r lives on device r % devices: the lowest one there
-        if (k.dst_dev && k.dst_rank >= n) k.dst_rank = -1;                        // no rank on the owner: peer copies only
-        k.use_rccl = k.dst_dev && k.dst_rank >= 0 && n > 1 && prepare_rccl(n);
-        g.transport = k.use_rccl ? "rccl" : "peer";
-        if (const char* e = std::getenv("ITW_MULTIGPU_TEST_FAIL")) {              // "rank:stage" (tests of the failure model)
-            int r = -1, st = 0;
-            if (std::sscanf(e, "%d:%d", &r, &st) == 2) { k.fail_rank = r; k.fail_stage = st; }
-        }
-        {
-            std::lock_guard<std::mutex> lk(g.m);
-            g.call = k;
-            g.ready = 0; g.prepare_failed = false; g.abort.store(false);
-            for (int i = 0; i < n; i++) { g.ranks[(size_t)i]->pending = true; g.ranks[(size_t)i]->failed = false; }
-            g.outstanding = n;
-        }
-        g.work.notify_all();
-        std::unique_lock<std::mutex> lk(g.m);
-        g.done.wait(lk, [&] { return g.outstanding == 0; });
-        // report the rank that failed on its own, not one that merely stopped because of it
-        int first = -1;
-        for (int i = 0; i < n; i++)
-            if (g.ranks[(size_t)i]->failed && (first < 0 || std::strstr(g.ranks[(size_t)first]->msg, "stopped: another rank failed"))) first = i;
-        if (first >= 0) { itw::Failure f; std::snprintf(f.msg, sizeof f.msg, "%s", g.ranks[(size_t)first]->msg); lk.unlock(); throw f; }
-        ok = true;
-    });
-    return ok;
+    return compress_multi(input, output, cmpFunc, dxgi_format, ranks, nullptr, nullptr);
+}
+
+bool itwCompressImageMultiGPUEx(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks,
+                                const rgba_surface* resident_bands, itw_multigpu_stats* stats)
+{
+    return compress_multi(input, output, cmpFunc, dxgi_format, ranks, resident_bands, stats);
 }
 
 } // extern "C"

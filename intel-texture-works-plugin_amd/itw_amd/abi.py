@@ -25,7 +25,8 @@ EXPORTED_SYMBOLS = tuple(
     + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
        "itwConvertToRGBA8Device", "itwConvertToRGBA16FDevice"]
     # include/itw_multigpu.h: one surface over all GPUs, one process
-    + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU"]
+    + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU", "itwCompressImageMultiGPUEx",
+       "itwMultiGpuTestInjectFailure"]
     # include/itw_bc45.h: the DirectXTex formats of the plugin
     + ["CompressBlocksBC4", "CompressBlocksBC5"]
     # include/itw_decode.h: device decoders
@@ -65,6 +66,29 @@ class DdsDesc(C.Structure):
     """struct ItwDdsDesc (itw_dds.h)."""
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("mip_levels", C.c_uint32), ("dxgi_format", C.c_uint32),
                 ("is_cubemap", C.c_uint32), ("array_size", C.c_uint32)]
+
+
+class MultiGpuRankStats(C.Structure):
+    """struct itw_multigpu_rank_stats (itw_multigpu.h)."""
+    _fields_ = [("rank", C.c_int32), ("device", C.c_int32), ("block_row0", C.c_int32), ("block_rows", C.c_int32),
+                ("upload_ms", C.c_float), ("encode_ms", C.c_float), ("gather_ms", C.c_float), ("span_ms", C.c_float)]
+
+
+class MultiGpuStats(C.Structure):
+    """struct itw_multigpu_stats (itw_multigpu.h)."""
+    _fields_ = [("ranks", C.c_int32), ("devices", C.c_int32), ("peer_links", C.c_int32), ("rccl_ranks", C.c_int32),
+                ("watchdog_fired", C.c_int32), ("resident_bands", C.c_int32), ("wall_ms", C.c_float), ("posted_ms", C.c_float),
+                ("transport", C.c_char * 8), ("transport_note", C.c_char * 96), ("rank", MultiGpuRankStats * 64)]
+
+    def as_dict(self):
+        n = max(0, min(int(self.ranks), 64))
+        return {"ranks": int(self.ranks), "devices": int(self.devices), "peer_links": int(self.peer_links), "rccl_ranks": int(self.rccl_ranks),
+                "watchdog_fired": bool(self.watchdog_fired), "resident_bands": bool(self.resident_bands),
+                "wall_ms": round(float(self.wall_ms), 4), "posted_ms": round(float(self.posted_ms), 4),
+                "transport": self.transport.decode(), "transport_note": self.transport_note.decode(),
+                "per_rank": [{"rank": int(r.rank), "device": int(r.device), "block_row0": int(r.block_row0), "block_rows": int(r.block_rows),
+                              "upload_ms": round(float(r.upload_ms), 4), "encode_ms": round(float(r.encode_ms), 4),
+                              "gather_ms": round(float(r.gather_ms), 4), "span_ms": round(float(r.span_ms), 4)} for r in self.rank[:n]]}
 
 
 COMPRESSION_FUNC = C.CFUNCTYPE(None, C.POINTER(RgbaSurface), C.c_void_p)
@@ -134,6 +158,11 @@ def lib():
         L.itwMultiGpuPeerLinks.restype = C.c_int
         L.itwCompressImageMultiGPU.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.itwCompressImageMultiGPU.restype = C.c_bool
+        L.itwCompressImageMultiGPUEx.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(RgbaSurface),
+                                                 C.POINTER(MultiGpuStats)]
+        L.itwCompressImageMultiGPUEx.restype = C.c_bool
+        L.itwMultiGpuTestInjectFailure.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.itwMultiGpuTestInjectFailure.restype = None
         L.itwPadToMultipleOf4.argtypes = [C.POINTER(RgbaSurface), C.c_int]
         L.itwPadToMultipleOf4.restype = RgbaSurface
         L.itwFreeSurface.argtypes = [C.POINTER(RgbaSurface)]
@@ -302,26 +331,45 @@ def compress_image(fmt, img, profile=None, multithreaded=True, slice_pixels=0, p
     return bool(ok), out
 
 
-def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None):
-    """itwCompressImageMultiGPU: img is a host numpy array or a CUDA torch tensor (H, W, 4); the block stream comes back in
-    the same kind of container (or in `out`, which may be the other kind).  Synchronous."""
+def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None, bands=None, stats=None):
+    """itwCompressImageMultiGPU[Ex]: img is a host numpy array or a CUDA torch tensor (H, W, 4); the block stream comes back in
+    the same kind of container (or in `out`, which may be the other kind).  Synchronous.
+    bands: optional list of CUDA tensors, band r of the image resident on device r % device_count (no scatter; `img` may then be
+    a (height, width) tuple).  stats: an optional MultiGpuStats to fill (stats.as_dict())."""
     import numpy as np
-    h, w = img.shape[:2]
+    if bands is not None:
+        import torch
+        h, w = (img if isinstance(img, tuple) else img.shape[:2])
+        ranks = len(bands)
+        for b in bands:
+            assert b.is_cuda and b.dim() == 3 and b.shape[2] == 4 and b.stride(2) == 1 and b.stride(1) == 4 and b.shape[1] == w
+            torch.cuda.synchronize(b.device)
+        arr = (RgbaSurface * ranks)(*[RgbaSurface(b.data_ptr(), w, b.shape[0], b.stride(0) * b.element_size()) for b in bands])
+        on_gpu, src_ptr, stride = True, None, w * 4 * bands[0].element_size()
+        first_dev = bands[0].device
+    else:
+        h, w = img.shape[:2]
+        arr = None
+        on_gpu = not isinstance(img, np.ndarray)
+        src_ptr, stride = (img.data_ptr(), img.stride(0) * img.element_size()) if on_gpu else (img.ctypes.data, img.strides[0])
+        first_dev = img.device if on_gpu else None
     nbytes = block_count(fmt, w, h) * BYTES_PER_BLOCK[fmt]
-    on_gpu = not isinstance(img, np.ndarray)
     if out is None:
         if on_gpu:
             import torch
-            out = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+            out = torch.empty(nbytes, dtype=torch.uint8, device=first_dev)
         else:
             out = np.empty(nbytes, dtype=np.uint8)
-    src_ptr, stride = (img.data_ptr(), img.stride(0) * img.element_size()) if on_gpu else (img.ctypes.data, img.strides[0])
     dst_ptr = out.ctypes.data if isinstance(out, np.ndarray) else out.data_ptr()
-    if on_gpu:
+    if on_gpu and bands is None:
         import torch
         torch.cuda.synchronize(img.device)            # the rank threads read the texels on their own streams
     surf = RgbaSurface(src_ptr, w, h, stride)
-    ok = lib().itwCompressImageMultiGPU(C.byref(surf), dst_ptr, image_func(fmt, profile), DXGI_FORMAT[fmt], ranks)
+    if bands is None and stats is None:
+        ok = lib().itwCompressImageMultiGPU(C.byref(surf), dst_ptr, image_func(fmt, profile), DXGI_FORMAT[fmt], ranks)
+    else:
+        ok = lib().itwCompressImageMultiGPUEx(C.byref(surf), dst_ptr, image_func(fmt, profile), DXGI_FORMAT[fmt], ranks, arr,
+                                              C.byref(stats) if stats is not None else None)
     if not ok:
         raise RuntimeError(last_error() or "itwCompressImageMultiGPU failed")
     return out

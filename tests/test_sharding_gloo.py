@@ -256,3 +256,26 @@ def test_bench_n_gt_1_control_flow_runs_end_to_end_on_cpu():
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 2 and j["config"]["ranks_seen_by_rccl"] == 2
     assert "512x512" in j["config"]["workload"] and j["weak_side"]["steps"] >= 3 and j["value"] > 0
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]          # only rank 0 prints
+
+
+@pytest.mark.parametrize("child", ["ok", "bad", "crash"])
+def test_bench_n_gt_1_cpp_host_job_control_flow(child):
+    """Round 4: for N > 1 bench.py runs the job a second time through the C++ host path -- rank 0 starts a child process
+    (`bench.py --cpp-worker`: one process, itwCompressImageMultiGPUEx over all N GPUs) while the other ranks wait at a CPU
+    (gloo) barrier -- and makes it the headline when it returns a verified image; the torch.distributed job stays as
+    `python_side`.  Here (no GPU) the child prints a canned account: what is under test is the control flow -- environment
+    scrubbing, barriers, the merge, and the fallback when the child reports an unverified image or dies."""
+    import json
+    env = {"ITW_BENCH_FAKE_CPP": {"ok": "1", "bad": "bad", "crash": "1"}[child]}
+    if child == "crash":
+        env["ITW_BENCH_CPP_WORKER_CRASH"] = "1"
+    outs = _run_bench_world2(env)
+    j = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert j["python_side"]["gather_verified"] is True and j["python_side"]["ranks_seen_by_rccl"] == 2 and j["python_side"]["value"] > 0
+    if child == "ok":
+        assert j["config"]["host"].startswith("cpp") and j["config"]["transport"] == "rccl" and j["config"]["ranks_seen_by_rccl"] == 2
+        assert j["ms_per_step"] == 2.0 and j["gather_verified"] is True and j["band_checks"] == 2 and "error" not in j["cpp_host"]
+    else:
+        assert j["config"]["host"].startswith("python") and j["value"] == j["python_side"]["value"] and "note" in j["cpp_host"]
+        assert ("error" in j["cpp_host"]) == (child == "crash")
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]
