@@ -696,6 +696,12 @@ int64_t itwBandForPartEx(int32_t width, int32_t height, int32_t bytes_per_block,
     return r0 * bx * bytes_per_block;
 }
 
+int itwTestBc45IndexTable(uint32_t* host_out)
+{
+    itwClearError();
+    return itw::guarded([&] { if (!host_out) itw::fail_msg("null pointer"); itw::copy_bc45_index_table(host_out, tls.user_stream); }) ? 0 : -1;
+}
+
 void itwTestRcp(const float* in, float* out, int64_t n)
 {
     if (n <= 0) return;

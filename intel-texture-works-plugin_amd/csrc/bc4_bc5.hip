@@ -7,90 +7,49 @@
 // evaluated in IEEE fp32 exactly as written, one rounding per operation (the library is built with -ffp-contract=off).
 //
 // Mapping: one lane per 8-byte channel block (BC5: lanes 2b and 2b+1 encode R and G of block b), so a wavefront writes
-// 512 contiguous bytes; each lane keeps its 16 texels in registers and runs the (at most eight) Newton iterations
-// with a per-lane exit.  The ramp weights k/5 and k/7 are compile-time fp32 quotients in the reference; k * (1/7)
-// is not bit-equal to k/7 for k = 3 and 6, so they come from a 14-entry LDS table instead of arithmetic.
-// HBM-bound in principle (64 B in, 8 or 16 B out per block); in practice VALU-bound like BC1 (~3 k fp32 ops/channel).
+// 512 contiguous bytes; each lane keeps its 16 texel codes in 8 registers (two per dword) and runs the (at most eight)
+// Newton iterations with a per-lane exit.
+//
+// Round 4 -- issue cycles, not instructions:
+//   * FindClosestUNORM as RUN LENGTHS.  The reference searches 8 decoded levels per texel for the first strictly smallest
+//     |level - texel| (16 x 8 x subtract / compare / two selects).  With 8-bit texels the function (red_0, red_1, v) -> index
+//     has a domain of 256^3 cases, and for every endpoint pair it is piecewise constant in v with AT MOST 8 runs
+//     (tests/test_bc45_index_table.py walks all 16.7 M cases against the reference's own FindClosestUNORM compiled from
+//     BC4BC5.cpp; the pairs with red_0 == red_1, where the interpolated levels differ from the endpoints by an ulp, have at
+//     most 5).  A kernel (bc45_build_index_table, once per device) runs the search AS WRITTEN for all 65 536 pairs and
+//     stores, per pair, the 7 run starts and the 8 run indices (16 B; 1 MiB per device, L2 resident).  A block then loads ONE
+//     entry and a texel's index is "how many run starts are <= v", looked up in the run-index word: two texels per dword,
+//     add / and / add per run start on 2-cycle VOP2 forms, no float, no compare, no select.
+//   * The Newton loop keeps a step's weights {c, d, c*c, d*d} (BC.h:729-732 quotients and their products: the same fp32
+//     multiplications, done once) in one 16-byte LDS entry addressed by the step itself: the scale carries a factor 16
+//     (exact: a power of two commutes with every rounding involved), so med3 / add / convert / and yield the entry's byte
+//     offset.  Waves without a 6-step block (no texel 0 or 255 in 64 blocks) run a loop without the 6-step cases.
+//   * Minimum / maximum of the 16 codes on packed halves (v_pk_min/max_u16: two texels per instruction), also for the 6-step
+//     ramp's "smallest code above 0 / largest below 255" ((v + 255) & 255 and (v + 1) & 255 move the excluded code to the
+//     other end of the range).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+#include <vector>
 #include "kernels.hpp"
+#include "host_rt.hpp"
 
 namespace itw {
 namespace {
 
-// k/7 (k = 0..7) then k/5 (k = 0..5): pD8, pD6 of BC.h:729-732; pC is the same table read backwards.
-__device__ const float RAMP_WEIGHTS[14] = {
-    0.0f / 7.0f, 1.0f / 7.0f, 2.0f / 7.0f, 3.0f / 7.0f, 4.0f / 7.0f, 5.0f / 7.0f, 6.0f / 7.0f, 7.0f / 7.0f,
-    0.0f / 5.0f, 1.0f / 5.0f, 2.0f / 5.0f, 3.0f / 5.0f, 4.0f / 5.0f, 5.0f / 5.0f };
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(uint32_t v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ uint32_t as_u32(u16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_min(as_u16x2(a), as_u16x2(b))); }
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_max(as_u16x2(a), as_u16x2(b))); }
 
-// OptimizeAlpha<false> (BC.h:727-856).  STEPS = 8: plain ramp; 6: ramp plus the exact codes 0 and 1.
-template <int STEPS>
-__device__ __forceinline__ void optimize_ramp(float& out_x, float& out_y, const float (&t)[16], const float* tab)
-{
-    const float* w = tab + (STEPS == 8 ? 0 : 8);
-    float fx = 1.0f, fy = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (STEPS == 8) {
-            if (t[i] < fx) fx = t[i];
-            if (t[i] > fy) fy = t[i];
-        } else {
-            if (t[i] < fx && t[i] > 0.0f) fx = t[i];
-            if (t[i] > fy && t[i] < 1.0f) fy = t[i];
-        }
-    }
-    if (STEPS == 6 && fx == fy) fy = 1.0f;
-    const float fsteps = (float)(STEPS - 1);
-#pragma unroll 1
-    for (int it = 0; it < 8; it++) {
-        if ((fy - fx) < (1.0f / 256.0f)) break;
-        const float scale = fsteps / (fy - fx);
-        float dx = 0.0f, dy = 0.0f, d2x = 0.0f, d2y = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const float dot = (t[i] - fx) * scale;
-            int s;
-            if (dot <= 0.0f) s = (STEPS == 6 && t[i] <= fx * 0.5f) ? 6 : 0;
-            else if (dot >= fsteps) s = (STEPS == 6 && t[i] >= (fy + 1.0f) * 0.5f) ? 7 : (STEPS - 1);
-            else s = (int)(dot + 0.5f);
-            if (s < STEPS) {
-                const float c = w[STEPS - 1 - s], d = w[s];
-                const float diff = (c * fx + d * fy) - t[i];
-                dx += c * diff;
-                d2x += c * c;
-                dy += d * diff;
-                d2y += d * d;
-            }
-        }
-        if (d2x > 0.0f) fx -= dx / d2x;
-        if (d2y > 0.0f) fy -= dy / d2y;
-        if (fx > fy) { const float f = fx; fx = fy; fy = f; }
-        if ((dx * dx < (1.0f / 64.0f)) && (dy * dy < (1.0f / 64.0f))) break;
-    }
-    out_x = (fx < 0.0f) ? 0.0f : (fx > 1.0f) ? 1.0f : fx;
-    out_y = (fy < 0.0f) ? 0.0f : (fy > 1.0f) ? 1.0f : fy;
-}
+constexpr float UNORM_SCALE = 1.0f / 255.0f;                     // XMLoadUByteN4's SSE path: integer * (1/255)
 
-// One channel of one block -> 8 bytes (D3DXEncodeBC4U, BC4BC5.cpp:403-421).
-__device__ __forceinline__ uint2 encode_channel(const float (&t)[16], const float* tab)
+// ---- FindClosestUNORM, tabulated ---------------------------------------------------------------------------------------------
+// BC4_UNORM::DecodeFromIndex (BC4BC5.cpp:50-72), as written
+__device__ __forceinline__ void decoded_levels(float (&g)[8], uint32_t r0, uint32_t r1)
 {
-    float bmin = t[0], bmax = t[0];
-#pragma unroll
-    for (int i = 1; i < 16; i++) { bmin = t[i] < bmin ? t[i] : bmin; bmax = t[i] > bmax ? t[i] : bmax; }
-    uint32_t r0, r1;
-    float fs, fe;
-    if (!(0.0f == bmin || 1.0f == bmax)) {                       // BC4BC5.cpp:213-237
-        optimize_ramp<8>(fs, fe, t, tab);
-        r0 = (uint32_t)(fe * 255.0f);
-        r1 = (uint32_t)(fs * 255.0f);
-    } else {
-        optimize_ramp<6>(fs, fe, t, tab);
-        r1 = (uint32_t)(fe * 255.0f);
-        r0 = (uint32_t)(fs * 255.0f);
-    }
-    // the eight decoded values, BC4_UNORM::DecodeFromIndex (BC4BC5.cpp:50-72)
     const float f0 = (float)r0 / 255.0f, f1 = (float)r1 / 255.0f;
-    float g[8];
     g[0] = f0; g[1] = f1;
     const bool eight = r0 > r1;
 #pragma unroll
@@ -99,41 +58,201 @@ __device__ __forceinline__ uint2 encode_channel(const float (&t)[16], const floa
         const float v6 = (k <= 4) ? (f0 * (float)(5 - k) + f1 * (float)k) / 5.0f : (k == 5 ? 0.0f : 1.0f);
         g[k + 1] = eight ? v8 : v6;
     }
-    // FindClosestUNORM (BC4BC5.cpp:314-337): first index with the strictly smallest |g - t|
-    uint64_t idx = 0;
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
+}
+
+// Entry of the run table for one endpoint pair: the index is constant on runs [T_j, T_j+1) of the texel code v, T_0 = 0.
+//   x, y   C_j = 256 - T_j for run j = 1..7, one byte each (C_1 in the low byte of x; 0 = no such run): v + C_j carries into
+//          bit 8 exactly when v >= T_j
+//   z      index of run j in nibble j
+//   w      number of runs (> 8 = the representation does not hold: checked once after the build)
+__global__ void __launch_bounds__(256) bc45_build_index_table(uint4* __restrict__ table)
+{
+    const uint32_t r0 = blockIdx.x, r1 = threadIdx.x;
+    float g[8];
+    decoded_levels(g, r0, r1);
+    uint32_t c[2] = {0u, 0u}, order = 0u, runs = 0u, prev = 8u;
+    for (uint32_t v = 0; v < 256u; v++) {
+        const float t = (float)v * UNORM_SCALE;
+        // FindClosestUNORM (BC4BC5.cpp:314-337): first index with the strictly smallest |g - t|
         uint32_t best = 0;
         float best_delta = 100000.0f;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const float d = fabsf(g[k] - t[i]);
+        for (uint32_t k = 0; k < 8u; k++) {
+            const float d = fabsf(g[k] - t);
             if (d < best_delta) { best = k; best_delta = d; }
         }
-        idx |= (uint64_t)best << (3 * i);
+        if (best != prev) {
+            if (runs >= 1u && runs < 8u) c[(runs - 1u) >> 2] |= (256u - v) << (8u * ((runs - 1u) & 3u));
+            if (runs < 8u) order |= best << (4u * runs);
+            runs++;
+            prev = best;
+        }
     }
-    const uint64_t data = (uint64_t)r0 | ((uint64_t)r1 << 8) | (idx << 16);
-    return make_uint2((uint32_t)data, (uint32_t)(data >> 32));
+    table[r0 * 256u + r1] = make_uint4(c[0], c[1], order, runs);
+}
+
+struct TableSlot { std::once_flag once; uint4* table = nullptr; };
+TableSlot g_tables[64];
+
+const uint4* index_table(hipStream_t st)
+{
+    int dev = 0;
+    ITW_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) fail_msg("BC4/BC5: device ordinal %d out of range", dev);
+    TableSlot& s = g_tables[dev];
+    std::call_once(s.once, [&] {                                  // an exception leaves the flag unset: the next call retries
+        uint4* t = nullptr;
+        ITW_CHECK(hipMalloc(&t, 65536 * sizeof(uint4)));
+        hipLaunchKernelGGL(bc45_build_index_table, dim3(256), dim3(256), 0, st, t);
+        std::vector<uint4> h(65536);
+        hipError_t e = hipMemcpyAsync(h.data(), t, 65536 * sizeof(uint4), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);        // later calls use the table from any stream
+        if (e != hipSuccess) { (void)hipFree(t); fail_hip("bc45_build_index_table", e, __FILE__, __LINE__); }
+        for (const uint4& v : h)
+            if (v.w < 1u || v.w > 8u) { (void)hipFree(t); fail_msg("BC4/BC5 index table: an endpoint pair has %u runs (at most 8 expected)", v.w); }
+        s.table = t;
+    });
+    return s.table;
+}
+
+// ---- OptimizeAlpha<false> (BC.h:727-856) ---------------------------------------------------------------------------------------
+// Step weights in LDS: entry s of table STEPS holds {c, d, c*c, d*d} with c = pC[s], d = pD[s] (BC.h:729-732: (STEPS-1-s)/(STEPS-1)
+// and s/(STEPS-1) as compile-time fp32 quotients).  Entries 6 and 7 of the 6-step table are zero: the reference skips the codes
+// "exactly 0" / "exactly 1" in its sums (`if (iStep < cSteps)`), and adding +-0 to an accumulator that started at +0 and only
+// ever received sums of finite terms changes nothing (x + (+-0) = x; (+0) + (-0) = +0).
+struct StepWeights { float c, d, cc, dd; };
+
+__device__ __forceinline__ StepWeights step_weights(int steps, int s)
+{
+    // the quotients as the reference's tables hold them: k/7 and k/5 (k * (1/7) is not bit-equal to k/7 for k = 3 and 6)
+    const float w8[8] = {0.0f / 7.0f, 1.0f / 7.0f, 2.0f / 7.0f, 3.0f / 7.0f, 4.0f / 7.0f, 5.0f / 7.0f, 6.0f / 7.0f, 7.0f / 7.0f};
+    const float w6[6] = {0.0f / 5.0f, 1.0f / 5.0f, 2.0f / 5.0f, 3.0f / 5.0f, 4.0f / 5.0f, 5.0f / 5.0f};
+    StepWeights r{0.f, 0.f, 0.f, 0.f};
+    if (steps == 8)  { r.c = w8[7 - s]; r.d = w8[s]; }
+    else if (s < 6)  { r.c = w6[5 - s]; r.d = w6[s]; }
+    r.cc = r.c * r.c; r.dd = r.d * r.d;
+    return r;
+}
+
+// One pass over the ramp for the lanes that are still iterating.  SIX = false: no lane of the wave has a 6-step block.
+// `six` (per lane) selects the 6-step ramp; t[] are the texels as floats.
+template <bool SIX>
+__device__ __forceinline__ void newton_loop(float& fx, float& fy, const float (&t)[16], bool six, const StepWeights* tab8, const StepWeights* tab6)
+{
+    const float fsteps = (SIX && six) ? 5.0f : 7.0f;
+    const float top16 = fsteps * 16.0f;
+    const char* base = reinterpret_cast<const char*>((SIX && six) ? tab6 : tab8);
+#pragma unroll 1
+    for (int it = 0; it < 8; it++) {
+        if ((fy - fx) < (1.0f / 256.0f)) break;
+        const float scale = fsteps / (fy - fx);
+        const float scale16 = scale * 16.0f;                      // exact: the step below comes out multiplied by 16 = its table offset
+        // 6-step ramp: below the ramp the texel goes to "exactly 0" when it is nearer, above it to "exactly 1" (BC.h:789-804);
+        // for 8-step lanes the two bounds are out of the texels' range
+        const float to_zero = (SIX && six) ? fx * 0.5f : -1.0f;
+        const float to_one  = (SIX && six) ? (fy + 1.0f) * 0.5f : 2.0f;
+        float dx = 0.0f, dy = 0.0f, d2x = 0.0f, d2y = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float dot16 = (t[i] - fx) * scale16;
+            // dot <= 0 -> step 0, dot >= fsteps -> the last step, else (int)(dot + 0.5): clamp first, the clamped ends convert to themselves
+            const float m = __builtin_amdgcn_fmed3f(dot16, 0.0f, top16);
+            uint32_t off = (uint32_t)(int32_t)(m + 8.0f) & 0x70u;
+            if (SIX) {
+                if (dot16 <= 0.0f && t[i] <= to_zero) off = 6u * 16u;
+                if (dot16 >= top16 && t[i] >= to_one) off = 7u * 16u;
+            }
+            const StepWeights w = *reinterpret_cast<const StepWeights*>(base + off);
+            const float diff = (w.c * fx + w.d * fy) - t[i];
+            dx += w.c * diff;
+            d2x += w.cc;
+            dy += w.d * diff;
+            d2y += w.dd;
+        }
+        if (d2x > 0.0f) fx -= dx / d2x;
+        if (d2y > 0.0f) fy -= dy / d2y;
+        if (fx > fy) { const float f = fx; fx = fy; fy = f; }
+        if ((dx * dx < (1.0f / 64.0f)) && (dy * dy < (1.0f / 64.0f))) break;
+    }
+}
+
+// One channel of one block -> 8 bytes (D3DXEncodeBC4U, BC4BC5.cpp:403-421).  P[j] = code of texel 2j | code of texel 2j+1 << 16.
+__device__ __forceinline__ uint2 encode_channel(const uint32_t (&P)[8], const StepWeights* tab8, const StepWeights* tab6, const uint4* __restrict__ runs)
+{
+    float t[16];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        t[2 * j]     = (float)(P[j] & 0xffffu) * UNORM_SCALE;
+        t[2 * j + 1] = (float)(P[j] >> 16) * UNORM_SCALE;
+    }
+    // smallest / largest code, and for the 6-step ramp the smallest above 0 / largest below 255 (BC.h:742-766; fX starts at
+    // 1.0 = code 255 and fY at 0.0 = code 0, which is also what "no such texel" leaves behind)
+    uint32_t mn = P[0], mx = P[0];
+    uint32_t lo6 = (P[0] + 0x00ff00ffu) & 0x00ff00ffu, hi6 = (P[0] + 0x00010001u) & 0x00ff00ffu;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+        mn = pk_min_u16(mn, P[j]); mx = pk_max_u16(mx, P[j]);
+        lo6 = pk_min_u16(lo6, (P[j] + 0x00ff00ffu) & 0x00ff00ffu);       // (v - 1) mod 256: code 0 becomes the largest
+        hi6 = pk_max_u16(hi6, (P[j] + 0x00010001u) & 0x00ff00ffu);       // (v + 1) mod 256: code 255 becomes the smallest
+    }
+    const uint32_t cmin = min(mn & 0xffffu, mn >> 16), cmax = max(mx & 0xffffu, mx >> 16);
+    const bool six = (cmin == 0u) || (cmax == 255u);                     // BC4BC5.cpp:213: 0.0f == fBlockMin || 1.0f == fBlockMax
+    uint32_t cx = cmin, cy = cmax;
+    if (six) {
+        const uint32_t l = min(lo6 & 0xffffu, lo6 >> 16), h = max(hi6 & 0xffffu, hi6 >> 16);
+        cx = min(l + 1u, 255u);
+        cy = h ? h - 1u : 0u;
+    }
+    float fx = (float)cx * UNORM_SCALE, fy = (float)cy * UNORM_SCALE;
+    if (six && fx == fy) fy = 1.0f;
+    if (__any(six)) newton_loop<true>(fx, fy, t, six, tab8, tab6);
+    else            newton_loop<false>(fx, fy, t, false, tab8, tab6);
+    const float ox = (fx < 0.0f) ? 0.0f : (fx > 1.0f) ? 1.0f : fx;
+    const float oy = (fy < 0.0f) ? 0.0f : (fy > 1.0f) ? 1.0f : fy;
+    // BC4BC5.cpp:213-237: the 8-step ramp stores (max, min), the 6-step ramp (min, max)
+    const uint32_t qx = (uint32_t)(ox * 255.0f), qy = (uint32_t)(oy * 255.0f);
+    const uint32_t r0 = six ? qx : qy, r1 = six ? qy : qx;
+
+    // FindClosestUNORM through the run table: count the run starts that are <= v, two texels per dword
+    const uint4 e = runs[(r0 << 8) | r1];
+    uint32_t C[7];
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+        C[j] = __builtin_amdgcn_perm(0u, j < 4 ? e.x : e.y, 0x0c000c00u | (uint32_t)((j & 3) * 0x00010001));   // byte j -> both halves
+    const uint32_t carry = 0x01000100u;
+    uint32_t part[2] = {0u, 0u};                                  // 3-bit indices of texels 0..7 / 8..15
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {                                // Horner from the last texel down: (acc << 3) | index
+        uint32_t s = (P[j] + C[0]) & carry;
+#pragma unroll
+        for (int k = 1; k < 7; k++) s += (P[j] + C[k]) & carry;
+        const uint32_t hi = (e.z >> ((s >> 22) & 0x1cu)) & 7u;    // run count x 4 = the nibble's shift
+        const uint32_t lo = (e.z >> ((s >> 6) & 0x1cu)) & 7u;
+        uint32_t& acc = part[j >> 2];
+        acc = (acc << 3) | hi;
+        acc = (acc << 3) | lo;
+    }
+    return make_uint2(r0 | (r1 << 8) | (part[0] << 16), (part[0] >> 16) | (part[1] << 8));
 }
 
 template <int NCH, bool VEC16>
 __global__ void __launch_bounds__(256)
 bc45_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t width, int32_t height, int32_t blocks_x,
-            int32_t nlanes, uint8_t* __restrict__ dst)
+            int32_t nlanes, uint8_t* __restrict__ dst, const uint4* __restrict__ runs)
 {
-    __shared__ float s_tab[16];
-    if (threadIdx.x < 14) s_tab[threadIdx.x] = RAMP_WEIGHTS[threadIdx.x];
+    __shared__ StepWeights s_tab[16];                             // [0..7] the 8-step ramp, [8..15] the 6-step ramp
+    if (threadIdx.x < 16) s_tab[threadIdx.x] = step_weights(threadIdx.x < 8 ? 8 : 6, threadIdx.x & 7);
     __syncthreads();
     const int32_t lane = blockIdx.x * 256 + threadIdx.x;
     if (lane >= nlanes) return;
     const int32_t b = (NCH == 2) ? (lane >> 1) : lane;
-    const uint32_t shift = (NCH == 2) ? (uint32_t)(lane & 1) * 8u : 0u;
+    const uint32_t ch = (NCH == 2) ? (uint32_t)(lane & 1) : 0u;   // byte of the RGBA8 word this lane encodes
     const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
     const int32_t pw = min(4, width - 4 * xx), ph = min(4, height - 4 * yy);
     const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 16;
-    const float scale = 1.0f / 255.0f;                           // XMLoadUByteN4's SSE path: integer * (1/255)
+    const uint32_t sel = 0x0c040c00u + ch * 0x00010001u;          // v_perm: byte ch of the first word | byte ch of the second << 16
 
-    float t[16];
+    uint32_t P[8];
     if (pw == 4 && ph == 4) {
 #pragma unroll
         for (int y = 0; y < 4; y++) {
@@ -145,8 +264,8 @@ bc45_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t width, int3
                 const uint32_t* q = reinterpret_cast<const uint32_t*>(p + y * stride);
                 w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
             }
-#pragma unroll
-            for (int x = 0; x < 4; x++) t[y * 4 + x] = (float)((w[x] >> shift) & 255u) * scale;
+            P[2 * y]     = __builtin_amdgcn_perm(w[1], w[0], sel);
+            P[2 * y + 1] = __builtin_amdgcn_perm(w[3], w[2], sel);
         }
     } else {
         // partial block: missing columns / rows repeat source column / row {0,0,0,1}[i], itself wrapped to 0 when
@@ -155,16 +274,18 @@ bc45_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t width, int3
         for (int y = 0; y < 4; y++) {
             int sy = y < ph ? y : (y == 3 ? 1 : 0);
             if (sy >= ph) sy = 0;
+            uint32_t w[4];
 #pragma unroll
             for (int x = 0; x < 4; x++) {
                 int sx = x < pw ? x : (x == 3 ? 1 : 0);
                 if (sx >= pw) sx = 0;
-                const uint32_t w = *reinterpret_cast<const uint32_t*>(p + sy * stride + sx * 4);
-                t[y * 4 + x] = (float)((w >> shift) & 255u) * scale;
+                w[x] = *reinterpret_cast<const uint32_t*>(p + sy * stride + sx * 4);
             }
+            P[2 * y]     = __builtin_amdgcn_perm(w[1], w[0], sel);
+            P[2 * y + 1] = __builtin_amdgcn_perm(w[3], w[2], sel);
         }
     }
-    const uint2 o = encode_channel(t, s_tab);
+    const uint2 o = encode_channel(P, s_tab, s_tab + 8, runs);
     *reinterpret_cast<uint2*>(dst + (int64_t)lane * 8) = o;
 }
 
@@ -175,14 +296,23 @@ void launch_bc45(const uint8_t* src, int64_t stride, int width, int height, uint
     const int bx = (width + 3) / 4, by = (height + 3) / 4;       // DirectXTex keeps partial blocks
     const int64_t n = (int64_t)bx * by * NCH;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 15) == 0;
+    const uint4* runs = index_table(st);
     const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
-    if (vec) hipLaunchKernelGGL((bc45_kernel<NCH, true>),  grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst);
-    else     hipLaunchKernelGGL((bc45_kernel<NCH, false>), grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst);
+    if (vec) hipLaunchKernelGGL((bc45_kernel<NCH, true>),  grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst, runs);
+    else     hipLaunchKernelGGL((bc45_kernel<NCH, false>), grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst, runs);
 }
 
 } // namespace
 
 void launch_bc4(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st) { launch_bc45<1>(src, stride, width, height, dst, st); }
 void launch_bc5(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st) { launch_bc45<2>(src, stride, width, height, dst, st); }
+
+// test hook (include/itw_bc45.h): the run table of the current device, 65 536 entries x 4 words, to host memory
+void copy_bc45_index_table(uint32_t* host_out, hipStream_t st)
+{
+    const uint4* t = index_table(st);
+    ITW_CHECK(hipMemcpyAsync(host_out, t, 65536 * sizeof(uint4), hipMemcpyDeviceToHost, st));
+    ITW_CHECK(hipStreamSynchronize(st));
+}
 
 } // namespace itw

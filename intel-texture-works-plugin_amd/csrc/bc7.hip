@@ -56,6 +56,7 @@
 #include <type_traits>
 #include "bc7_exact.hpp"
 #include "kernels.hpp"
+#include "host_rt.hpp"
 
 namespace itw {
 

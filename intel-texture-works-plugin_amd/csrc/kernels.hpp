@@ -14,6 +14,7 @@ void launch_bc3 (const uint8_t* src, int64_t stride, int width, int height, uint
 // width/height >= 1: ceil(width/4) x ceil(height/4) blocks, partial blocks replicated by DirectXTex's rule.
 void launch_bc4 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
 void launch_bc5 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
+void copy_bc45_index_table(uint32_t* host_out, hipStream_t st);   // test hook: the FindClosestUNORM run table of the current device
 // BC7 runs as up to seven kernels (search + finish per multi-subset mode family, one for modes 4/5/6) that hand
 // "best error so far" and the search winners to each other through
 // `workspace`: device memory, bc7_workspace_bytes(width, height) bytes, 16 B aligned, contents irrelevant on entry.

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = tuple(
     + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU", "itwCompressImageMultiGPUEx",
        "itwMultiGpuTestInjectFailure"]
     # include/itw_bc45.h: the DirectXTex formats of the plugin
-    + ["CompressBlocksBC4", "CompressBlocksBC5"]
+    + ["CompressBlocksBC4", "CompressBlocksBC5", "itwTestBc45IndexTable"]
     # include/itw_decode.h: device decoders
     + ["itwDecodeBlocks"]
     # include/itw_dds.h: DDS container
@@ -114,6 +114,8 @@ def lib():
         L.CompressBlocksBC4.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
         L.CompressBlocksBC5.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
         L.CompressBlocksBC4.restype = None
+        L.itwTestBc45IndexTable.argtypes = [C.c_void_p]
+        L.itwTestBc45IndexTable.restype = C.c_int
         L.CompressBlocksBC5.restype = None
         L.CompressBlocksBC3.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
         L.CompressBlocksBC7.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.POINTER(Bc7Settings)]

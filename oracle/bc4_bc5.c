@@ -141,6 +141,25 @@ void oracle_bc4_block(const float t[16], uint8_t out[8])
     for (int i = 0; i < 8; i++) out[i] = (uint8_t)(data >> (8 * i));
 }
 
+/* FindClosestUNORM (BC4BC5.cpp:314-337) as a function of the endpoint pair and ONE texel: out[v] = the index stored for a texel
+ * of code v (value v * (1/255.f), header note 1), v = 0..255.  The whole domain is 256^3 cases; tests/test_bc45_index_table.py
+ * walks it against the reference's own function and against the run-length form csrc/bc4_bc5.hip evaluates. */
+void oracle_bc4_find_closest_row(int r0, int r1, uint8_t out[256])
+{
+    float grad[8];
+    for (int i = 0; i < 8; i++) grad[i] = decode_from_index((uint8_t)r0, (uint8_t)r1, i);
+    for (int v = 0; v < 256; v++) {
+        const float t = (float)v * (1.0f / 255.0f);
+        int best = 0;
+        float best_delta = 100000;
+        for (int k = 0; k < 8; k++) {
+            const float d = fabsf(grad[k] - t);
+            if (d < best_delta) { best = k; best_delta = d; }
+        }
+        out[v] = (uint8_t)best;
+    }
+}
+
 /* DirectXTexCompress.cpp:105-168: load up to 4x4 texels of the RGBA8 surface, replicate into the missing columns and
  * rows with the source map {0,0,0,1}; channel -> float by XMLoadUByteN4's SSE path (header note 1). */
 static void load_block(const oracle_surface* src, int bx, int by, int channel, float t[16])

@@ -83,6 +83,7 @@ int  oracle_decode_bc6h(const uint8_t blk[16], uint16_t out_rgb[48]);  /* unsign
 void oracle_CompressBlocksBC4(const oracle_surface* src, uint8_t* dst);
 void oracle_CompressBlocksBC5(const oracle_surface* src, uint8_t* dst);
 void oracle_bc4_block(const float texels[16], uint8_t out[8]);
+void oracle_bc4_find_closest_row(int r0, int r1, uint8_t out[256]);   /* FindClosestUNORM for texel codes 0..255 */
 void oracle_decode_bc4_float(const uint8_t blk[8], float out[16]);   /* DirectXTex's float decode (BC4BC5.cpp:50-72) */
 void oracle_decode_bc4_rgba8(const uint8_t blk[8], uint8_t out_rgba[64]);   /* from the format definition, (R,0,0,255) */
 void oracle_decode_bc5_rgba8(const uint8_t blk[16], uint8_t out_rgba[64]);  /* (R,G,0,255) */

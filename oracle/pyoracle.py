@@ -74,6 +74,8 @@ def _bind(path):
         for n in ("oracle_CompressBlocksBC4", "oracle_CompressBlocksBC5", "oracle_bc4_block", "oracle_decode_bc4_float"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
             getattr(L, n).restype = None
+        L.oracle_bc4_find_closest_row.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.oracle_bc4_find_closest_row.restype = None
         return L
 
 
@@ -197,6 +199,16 @@ def bc4_block(texels):
     t = np.ascontiguousarray(texels, dtype=np.float32).reshape(16)
     out = np.zeros(8, dtype=np.uint8)
     lib().oracle_bc4_block(t.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def bc4_find_closest_table():
+    """FindClosestUNORM over its whole domain: uint8 [256 r0][256 r1][256 texel codes]."""
+    out = np.zeros((256, 256, 256), dtype=np.uint8)
+    fn = lib().oracle_bc4_find_closest_row
+    for r0 in range(256):
+        for r1 in range(256):
+            fn(r0, r1, out[r0, r1].ctypes.data_as(C.c_void_p))
     return out
 
 

@@ -115,3 +115,57 @@ def test_uniform_noise_2048(itw, gpu, oracle):
     got = gpu_encode(itw, gpu, "bc5", img)
     want = oracle.encode_bc45("bc5", img)
     assert first_mismatch(got, want, 8) is None, first_mismatch(got, want, 8)
+
+
+# ---- round 4: FindClosestUNORM through the device-built run table -----------------------------------------------------------
+
+def test_device_run_table_equals_the_table_of_the_search_as_written(itw, gpu, oracle):
+    """The table the device builds once (bc45_build_index_table: the reference's search, as written, for all 65 536 endpoint
+    pairs) is word for word the table derived on the CPU from the oracle's FindClosestUNORM over all 256^3 cases -- which
+    tests/test_bc45_index_table.py pins to the reference's own function and proves lossless."""
+    from _bc45_runs import runs_table
+    want, max_runs = runs_table(oracle.bc4_find_closest_table())
+    got = np.zeros((65536, 4), dtype=np.uint32)
+    assert itw.lib().itwTestBc45IndexTable(got.ctypes.data) == 0
+    assert max_runs == 8 and np.array_equal(got, want), np.flatnonzero((got != want).any(axis=1))[:8]
+
+
+@pytest.mark.parametrize("fmt", ["bc4", "bc5"])
+def test_every_texel_code_against_hand_picked_ramps(itw, gpu, oracle, fmt):
+    """Blocks built so that the optimiser lands on many different endpoint pairs while the 16 texels sweep the code range:
+    two texels pin the ramp's ends, the other fourteen walk through every code (incl. 0 and 255: the 6-step ramp)."""
+    rng = np.random.default_rng(45)
+    blocks = []
+    for lo in list(range(0, 256, 7)) + [0, 1, 254, 255]:
+        for hi in (lo, min(lo + 1, 255), min(lo + 3, 255), min(lo + 17, 255), min(lo + 90, 255), 255):
+            t = rng.integers(min(lo, hi), max(lo, hi) + 1, size=16)
+            t[rng.integers(0, 16)] = lo
+            t[rng.integers(0, 16)] = hi
+            blocks.append(t)
+    blocks = np.array(blocks, dtype=np.uint8)                                    # (n, 16)
+    n = blocks.shape[0]
+    cols = 32
+    rows = -(-n // cols)
+    img = np.zeros((rows * 4, cols * 4, 4), dtype=np.uint8)
+    for i, t in enumerate(blocks):
+        by, bx = divmod(i, cols)
+        img[by * 4:by * 4 + 4, bx * 4:bx * 4 + 4, 0] = t.reshape(4, 4)
+        img[by * 4:by * 4 + 4, bx * 4:bx * 4 + 4, 1] = t[::-1].reshape(4, 4)
+    got = gpu_encode(itw, gpu, fmt, img)
+    want = oracle.encode(fmt, img).reshape(-1)
+    assert first_mismatch(got, want, 8) is None, first_mismatch(got, want, 8)
+
+
+@pytest.mark.parametrize("fmt", ["bc4", "bc5"])
+def test_flat_and_two_level_blocks(itw, gpu, oracle, fmt):
+    """red_0 == red_1 is where the interpolated levels sit an ulp off the endpoints and the search is not monotone (70 pairs):
+    flat blocks of every code, and blocks of two adjacent codes."""
+    img = np.zeros((8, 256 * 4, 4), dtype=np.uint8)
+    for v in range(256):
+        img[0:4, v * 4:v * 4 + 4, 0] = v
+        img[0:4, v * 4:v * 4 + 4, 1] = 255 - v
+        img[4:8, v * 4:v * 4 + 4, 0] = np.array([v, min(v + 1, 255)] * 8, dtype=np.uint8).reshape(4, 4)
+        img[4:8, v * 4:v * 4 + 4, 1] = np.array([v, max(v - 1, 0)] * 8, dtype=np.uint8).reshape(4, 4)
+    got = gpu_encode(itw, gpu, fmt, img)
+    want = oracle.encode(fmt, img).reshape(-1)
+    assert first_mismatch(got, want, 8) is None, first_mismatch(got, want, 8)
