@@ -912,8 +912,11 @@ __device__ __forceinline__ int32_t encode_scalar(uint32_t (&qb)[2], int32_t (&qe
 }
 
 // one (mode, rotation, index-swap) candidate, given the rotation's line fit      [kernel.ispc:1565-1621]
+// `bound`: an error this candidate must stay below to matter at all (<= best_err).  The candidate's error is its vector part's plus
+// its scalar channel's (>= 0) and it is taken only on a strict `<`: where the vector part alone reaches the bound for all 64
+// blocks of the wave, the scalar channel (up to refineIterations_channel + 1 rounds over the 16 texels) is not encoded.
 template <int MODE, int SWAP>
-__device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const Lane& ln, Tex& rot, const float (&fit)[2][4], int32_t tt,
+__device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, int32_t bound, const Lane& ln, Tex& rot, const float (&fit)[2][4], int32_t tt,
                                          const bc7_enc_settings& S, int rotation)
 {
     constexpr int BITS = SWAP ? 3 : 2;
@@ -940,6 +943,8 @@ __device__ __forceinline__ void try_dual(Dual& best, int32_t& best_err, const La
         // point, further iterations reproduce exactly these values
         if (__all(qb[0] == was0 && qb[1] == was1)) break;
     }
+
+    if (__all(err >= bound)) return;
 
     int32_t aq[2];
     uint32_t aqb[2];
@@ -1009,9 +1014,11 @@ __device__ __forceinline__ void modes_45_scan(Lane& ln, const bc7_enc_settings& 
         fit[0][3] = 0.f; fit[1][3] = 0.f;
         fit_line<3>(fit, rot, 0xffffu, st, rcp_of_count(16), ln.T);
         const int32_t tt = st.m[0] + st.m[4] + st.m[7];          // |texel|^2 summed over the rotated colour block
-        if (which & 1) try_dual<4, 0>(best4, err4, ln, rot, fit, tt, S, r);
-        if (which & 2) try_dual<4, 1>(best4, err4, ln, rot, fit, tt, S, r);
-        if (which & 4) try_dual<5, 0>(best5, err5, ln, rot, fit, tt, S, r);
+        if (which & 1) try_dual<4, 0>(best4, err4, err4, ln, rot, fit, tt, S, r);
+        if (which & 2) try_dual<4, 1>(best4, err4, err4, ln, rot, fit, tt, S, r);
+        // mode 5's winner is admitted only below the error mode 4 leaves (modes_45; the wide path's commit order), and err4 only
+        // falls from here on: a mode 5 candidate at or above it can neither be admitted nor hide one that could
+        if (which & 4) try_dual<5, 0>(best5, err5, min(err5, err4), ln, rot, fit, tt, S, r);
     }
 }
 

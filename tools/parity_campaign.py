@@ -1,7 +1,7 @@
 """Large GPU-vs-oracle parity campaign (run on the GPU box): every format / profile on several megapixels of mixed
 content -- smooth + noise, uniform random bytes, posterised (tie-heavy), real alpha, adversarial half bits -- compared
 bit for bit with the multi-threaded scalar oracle.  Prints one line per case and a summary; exit code 1 on any mismatch.
-Usage: python tools/parity_campaign.py [megapixels_per_case] [oracle|ref]   (default 2, oracle; the oracle needs ~1 s per
+Usage: python tools/parity_campaign.py [megapixels_per_case] [oracle|ref] [fmt,fmt,...]   (default 2, oracle, every format; the oracle needs ~1 s per
 Mpix of BC7 slow on 16 cores).  `ref`: the checker is the reference's own kernel.ispc built as a scalar program
 (oracle/_ref/libispc_texcomp_ref_full.so) instead of the oracle's restatement; BC4/BC5, which kernel.ispc does not have, stay on the oracle."""
 import os, sys, time
@@ -45,6 +45,8 @@ def mixed_hdr(h, w):
     return np.ascontiguousarray(np.concatenate([a, b], axis=0))
 
 cases = [("bc1", None), ("bc3", None), ("bc4", None), ("bc5", None)] + [("bc7", p) for p in itw_amd.BC7_PROFILES] + [("bc6h", p) for p in itw_amd.BC6H_PROFILES]
+if len(sys.argv) > 3:
+    cases = [c for c in cases if c[0] in sys.argv[3].split(",")]
 torch.cuda.set_device(0)
 bad_total, blocks_total = 0, 0
 ldr, hdr = mixed_ldr(H, W), mixed_hdr(H, W)
