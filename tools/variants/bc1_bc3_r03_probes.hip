@@ -1,3 +1,10 @@
+// tools/variants/bc1_bc3_r03_probes.hip -- MEASUREMENT SOURCE, not part of the product build.
+// The round-3 state of csrc/bc1_bc3.hip with its A/B switches (ITW_BC1_PK / FQUANT / ASMCVT / EARLYLOAD / WAVES), the three
+// probe builds that do not encode (ITW_BC1_PROBE 1..3) and the ITW_BC13_LDS_PAD launch knob, kept so that the decomposition of a
+// BC1 launch in DESIGN.md 3.1 (profiles/r03_probe_bc1.txt) can be re-measured: tools/variants/build_bc1_probes.sh compiles it
+// with each switch into gpurun_variants/lib_bc1<name>.so, tools/gpu_probe_bc1.sh times them.  The shipped kernel
+// (csrc/bc1_bc3.hip) has one code path.
+//
 // bc1_bc3.hip -- BC1 / BC3 encoder kernels for gfx950 (MI355X).
 //
 // Replaces kernel.ispc:231-614 (CompressBlocksBC1_ispc / CompressBlocksBC3_ispc)
@@ -14,13 +21,29 @@
 //
 // Arithmetic is the pinned x86 model of x86_math.hpp; float sums run serially in
 // texel order k = 0..15 inside the lane, exactly like one ISPC program instance.
-#include "x86_math.hpp"
-#include "kernels.hpp"
+#include <cstdlib>
+#include "../../intel-texture-works-plugin_amd/csrc/x86_math.hpp"
+#include "../../intel-texture-works-plugin_amd/csrc/kernels.hpp"
 
-// Register allocation target: four waves per SIMD (measured round 3: 5 waves = 96 VGPRs + spills is 16 % slower, 3 and 2 waves
-// change nothing -- the kernel is bound by the issue cycles of its own instruction stream).  The A/B switches and
-// probe builds that measured this live in tools/variants/bc1_bc3_r03_probes.hip.
-constexpr int BC13_WAVES = 4;
+// A/B switches of tools/gpu_probe_bc1.sh (separate builds; the product build leaves them at their defaults)
+#ifndef ITW_BC1_PK
+#define ITW_BC1_PK 1             // projections / channel sums on v_pk_mul_f32 / v_pk_add_f32
+#endif
+#ifndef ITW_BC1_FQUANT
+#define ITW_BC1_FQUANT 1         // index clamp / floor / packing in the float domain
+#endif
+#ifndef ITW_BC1_ASMCVT
+#define ITW_BC1_ASMCVT 1         // texel bytes -> float as v_cvt_f32_ubyteN instructions
+#endif
+#ifndef ITW_BC1_EARLYLOAD
+#define ITW_BC1_EARLYLOAD 1      // first chunk's texel loads issued before the table staging
+#endif
+#ifndef ITW_BC1_WAVES
+#define ITW_BC1_WAVES 4          // waves per SIMD the register allocation targets
+#endif
+#ifndef ITW_BC1_PROBE
+#define ITW_BC1_PROBE 0          // 0 = product.  1..3: measurement probes of tools/gpu_probe_bc1.sh (separate builds)
+#endif
 
 namespace itw {
 
@@ -36,7 +59,7 @@ namespace itw {
 // One ready-made image (9 KiB), built at compile time: a workgroup stages it with plain 16-byte copies.
 namespace tables_src {
 #define X86_LUT_QUAL static constexpr
-#include "x86_luts_packed.h"
+#include "../../intel-texture-works-plugin_amd/csrc/x86_luts_packed.h"
 #undef X86_LUT_QUAL
 }
 struct Bc1Image {
@@ -117,6 +140,9 @@ __device__ __forceinline__ float rsqrt_nr_pos(float v, const Bc1Tables& B)
 
 template <int N> __device__ __forceinline__ float ubyte_f32(uint32_t w)
 {
+#if !ITW_BC1_ASMCVT
+    return (float)((w >> (8 * N)) & 255u);
+#endif
     float d;
     if (N == 0) asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(d) : "v"(w));
     if (N == 1) asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(d) : "v"(w));
@@ -203,23 +229,40 @@ __device__ __forceinline__ uint32_t project_indices(const Texels& px, const Endp
     // (dir0, dir1), B of a texel pair against dir2 -- and the sums keep the reference's order: (R*d0 + G*d1) + B*d2, then + bias.
     const f2 d01 = {dir[0], dir[1]}, d22 = {dir[2], dir[2]};
     float half[2] = {0.f, 0.f};
+    uint32_t ibits = 0; (void)ibits;
 #pragma unroll
     for (int j = 7; j >= 0; j--) {                   // Horner: texel k ends up at bits 2k
         const f2 bb = px.b2[j] * d22;
 #pragma unroll
         for (int t = 1; t >= 0; t--) {
             const int k = 2 * j + t;
+#if ITW_BC1_PK
             const f2 m = px.rg[k] * d01;
             float dot = m.x + m.y;                   // the reference's 0 + a = a: exact (the sign of a zero cannot reach q)
             dot += t ? bb.y : bb.x;
+#else
+            float dot = px.r(k) * dir[0];
+            dot += px.g(k) * dir[1]; dot += px.b(k) * dir[2];
+#endif
+#if ITW_BC1_FQUANT
             const float q = __builtin_floorf(fclamp_num(dot + bias, 0.f, 3.f));
             if (WANT_Q) { if (t) qf[j].y = q; else qf[j].x = q; }
             float& h = half[k >> 3];
             h = h * 4.0f;
             h = h + q;
+#else
+            const int32_t qi = iclamp(cvt_i32_sat(dot + bias), 0, 3);
+            ibits |= (uint32_t)qi << (2 * k);
+            if (WANT_Q) { if (t) qf[j].y = (float)qi; else qf[j].x = (float)qi; }
+#endif
         }
     }
+#if ITW_BC1_FQUANT
     return (uint32_t)half[0] | ((uint32_t)half[1] << 16);
+#else
+    (void)half;
+    return ibits;
+#endif
 }
 
 // Least-squares endpoint update for fixed indices.               [kernel.ispc:419-480]
@@ -266,12 +309,21 @@ __device__ __forceinline__ void encode_color(const Texels& px, uint32_t out[2], 
     // channel sums: integers <= 4080, exact in any order -- packed adds over the (R, G) pairs and the B pairs
     float acc[3], dc[3];
     {
+#if ITW_BC1_PK
         f2 srg = px.rg[0], sbb = px.b2[0];
 #pragma unroll
         for (int k = 1; k < 16; k++) srg = srg + px.rg[k];
 #pragma unroll
         for (int j = 1; j < 8; j++) sbb = sbb + px.b2[j];
         acc[0] = srg.x; acc[1] = srg.y; acc[2] = sbb.x + sbb.y;
+#else
+        for (int p = 0; p < 3; p++) {
+            float a = px.ch(p, 0);
+#pragma unroll
+            for (int k = 1; k < 16; k++) a += px.ch(p, k);
+            acc[p] = a;
+        }
+#endif
         for (int p = 0; p < 3; p++) dc[p] = acc[p] * 0.0625f;
     }
 
@@ -318,9 +370,15 @@ __device__ __forceinline__ void encode_color(const Texels& px, uint32_t out[2], 
         const f2 bb = (px.b2[j] - dc22) * v22;
 #pragma unroll
         for (int t = 0; t < 2; t++) {
+#if ITW_BC1_PK
             const f2 m = (px.rg[2 * j + t] - dc_rg) * v01;
             float dot = m.x + m.y;
             dot += t ? bb.y : bb.x;
+#else
+            const int k = 2 * j + t;
+            float dot = (px.r(k) - dc[0]) * v[0];
+            dot += (px.g(k) - dc[1]) * v[1]; dot += (px.b(k) - dc[2]) * v[2];
+#endif
             lo = __builtin_fminf(lo, dot);
             hi = __builtin_fmaxf(hi, dot);
         }
@@ -414,20 +472,58 @@ __device__ __forceinline__ void load_words(uint32_t (&w)[16], const uint8_t* __r
 }
 
 template <bool BC3, bool VEC16>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BC13_WAVES, BC13_WAVES)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ITW_BC1_WAVES, ITW_BC1_WAVES)))
 bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst)
 {
     __shared__ __attribute__((aligned(16))) unsigned char s_tables[BC1_LDS_BYTES];
+#if ITW_BC1_PROBE == 1 || ITW_BC1_PROBE == 3
+    // measurement probe (tools/gpu_probe_bc1.sh, never in the product build): the kernel's memory side alone -- same grid,
+    // same loads and stores, no encode (3: no table staging either)
+    {
+#if ITW_BC1_PROBE == 1
+        const Bc1Tables Bp = stage_bc1_tables(s_tables, threadIdx.x, 256);
+        __syncthreads();
+        const uint32_t salt = Bp.q5[threadIdx.x & 255];
+#else
+        const uint32_t salt = 0;
+#endif
+        for (int32_t b0 = blockIdx.x * 256; b0 < nblocks; b0 += gridDim.x * 256) {
+            const int32_t cur = b0 + threadIdx.x;
+            uint32_t w[16];
+            load_words<VEC16>(w, src, stride, blocks_x, cur < nblocks ? cur : nblocks - 1);
+            uint32_t o[4] = {salt, 0, 0, 0};
+            for (int k = 0; k < 16; k++) o[k & 3] ^= w[k];
+            if (cur < nblocks) {
+                if (BC3) *reinterpret_cast<uint4*>(dst + (int64_t)cur * 16) = make_uint4(o[0], o[1], o[2], o[3]);
+                else *reinterpret_cast<uint2*>(dst + (int64_t)cur * 8) = make_uint2(o[0] ^ o[2], o[1] ^ o[3]);
+            }
+        }
+        return;
+    }
+#endif
     // The first chunk's texels are requested BEFORE the tables are staged: at launch every wave of the chip stands in this
-    // prologue at once, and the HBM round trip of the texels then runs under the 9 KiB table copy instead of after it.
+    // prologue at once, and the HBM round trip of the texels then runs under the 21 KiB table copy instead of after it.
     int32_t base = blockIdx.x * 256;
     uint32_t w[16];
+#if ITW_BC1_EARLYLOAD
+    {
+        const int32_t cur = base + threadIdx.x;
+#if ITW_BC1_PROBE == 2
+        // measurement probe: the kernel's arithmetic alone -- texels made up from the block index, no global loads
+        for (int k = 0; k < 16; k++) w[k] = ((uint32_t)cur * 2654435761u) ^ ((uint32_t)k * 0x9e3779b9u);
+#else
+        load_words<VEC16>(w, src, stride, blocks_x, cur < nblocks ? cur : nblocks - 1);
+#endif
+    }
+#endif
+    const Bc1Tables B = stage_bc1_tables(s_tables, threadIdx.x, 256);
+    __syncthreads();
+#if !ITW_BC1_EARLYLOAD
     {
         const int32_t cur = base + threadIdx.x;
         load_words<VEC16>(w, src, stride, blocks_x, cur < nblocks ? cur : nblocks - 1);
     }
-    const Bc1Tables B = stage_bc1_tables(s_tables, threadIdx.x, 256);
-    __syncthreads();
+#endif
     for (;;) {
         const int32_t cur = base + threadIdx.x;
         // (requesting the NEXT chunk's texels before encoding this one was measured: the 16 extra live registers cost more
@@ -465,17 +561,29 @@ bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
         base += gridDim.x * 256;
         if (base >= nblocks) break;                                    // wave-uniform
         const int32_t nxt = base + threadIdx.x;
+#if ITW_BC1_PROBE == 2
+        for (int k = 0; k < 16; k++) w[k] = ((uint32_t)nxt * 2654435761u) ^ ((uint32_t)k * 0x9e3779b9u);
+#else
         load_words<VEC16>(w, src, stride, blocks_x, nxt < nblocks ? nxt : nblocks - 1);
+#endif
     }
 }
 
 // Persistent workgroups: at most 2048 (two per resident slot at 4 waves per SIMD), each walking chunks of 256 blocks (measured
 // round 3, tools/gpu_probe_bc1.sh: 1024 / 1536 / 2048 workgroups 29.4 / 28.7 / 28.9 us BC1 and 32.8 / 30.9 / 31.1 us BC3 at 4096^2).
-constexpr int64_t BC13_GRID = 2048;
+#ifndef ITW_BC13_GRID
+#define ITW_BC13_GRID 2048
+#endif
+// measurement knob (tools/gpu_probe_bc1.sh): dynamic LDS bytes added to every launch, to cap the workgroups a CU can hold
+static unsigned bc13_lds_pad()
+{
+    static const unsigned pad = [] { const char* e = std::getenv("ITW_BC13_LDS_PAD"); return e ? (unsigned)std::atoi(e) : 0u; }();
+    return pad;
+}
 static unsigned bc13_grid(int64_t n)
 {
     const int64_t chunks = (n + 255) / 256;
-    return (unsigned)(chunks < BC13_GRID ? chunks : BC13_GRID);
+    return (unsigned)(chunks < ITW_BC13_GRID ? chunks : ITW_BC13_GRID);
 }
 
 // VEC16 requires: src base and stride multiples of 16, dst multiple of 16 (BC3) / 8 (BC1).
@@ -486,8 +594,8 @@ void launch_bc1(const uint8_t* src, int64_t stride, int width, int height, uint8
     if (n <= 0) return;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
     const dim3 grid(bc13_grid(n)), blk(256);
-    if (vec) hipLaunchKernelGGL((bc13_kernel<false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
-    else     hipLaunchKernelGGL((bc13_kernel<false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+    if (vec) hipLaunchKernelGGL((bc13_kernel<false, true>),  grid, blk, bc13_lds_pad(), st, src, stride, bx, (int32_t)n, dst);
+    else     hipLaunchKernelGGL((bc13_kernel<false, false>), grid, blk, bc13_lds_pad(), st, src, stride, bx, (int32_t)n, dst);
 }
 
 void launch_bc3(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st)
@@ -497,8 +605,8 @@ void launch_bc3(const uint8_t* src, int64_t stride, int width, int height, uint8
     if (n <= 0) return;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const dim3 grid(bc13_grid(n)), blk(256);
-    if (vec) hipLaunchKernelGGL((bc13_kernel<true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
-    else     hipLaunchKernelGGL((bc13_kernel<true, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+    if (vec) hipLaunchKernelGGL((bc13_kernel<true, true>),  grid, blk, bc13_lds_pad(), st, src, stride, bx, (int32_t)n, dst);
+    else     hipLaunchKernelGGL((bc13_kernel<true, false>), grid, blk, bc13_lds_pad(), st, src, stride, bx, (int32_t)n, dst);
 }
 
 } // namespace itw
