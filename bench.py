@@ -258,22 +258,56 @@ def cpu_baseline_pair(fmt, prof, img, budget_s=2.0):
     return out
 
 
-def pmc_valu(workload):
-    """VALU wave-instructions per C-ABI call at 4096^2 from the latest committed rocprofv3 SQ pass: profiles/*_valu_by_workload.json
-    (one entry per workload, tools/profile_gpu.sh) or, for bc7_slow, the older profiles/*_valu.json."""
-    best = None
+def _latest_profile(suffix):
+    """(path, parsed JSON) of the latest committed profiles/*<suffix>, or (None, None)."""
     try:
-        for name in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
-            if name.endswith("_valu_by_workload.json"):
-                with open(os.path.join(ROOT, "profiles", name)) as f:
-                    v = json.load(f).get(workload, {}).get("SQ_INSTS_VALU")
-                best = v if v else best
-            elif name.endswith("_valu.json") and workload == "bc7_slow" and best is None:
-                with open(os.path.join(ROOT, "profiles", name)) as f:
-                    best = json.load(f).get("SQ_INSTS_VALU")
-    except (OSError, ValueError, AttributeError):
+        names = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith(suffix))
+        if not names:
+            return None, None
+        path = os.path.join(ROOT, "profiles", names[-1])
+        with open(path) as f:
+            return path, json.load(f)
+    except (OSError, ValueError):
+        return None, None
+
+
+def pmc_valu(workload):
+    """VALU wave-instructions per C-ABI call at 4096^2 from the latest committed rocprofv3 SQ pass (profiles/*_valu_by_workload.json,
+    tools/profile_gpu.sh): (instructions per call, {kernel name: instructions}, source stamp of the pass)."""
+    path, j = _latest_profile("_valu_by_workload.json")
+    if not j or workload not in j:
+        return None, None, None
+    return j[workload].get("SQ_INSTS_VALU"), j[workload].get("per_kernel"), j.get("_source_sha256")
+
+
+def issue_block(per_kernel, insts, kernel_ms, cur_sha):
+    """The roofline that binds, in the unit that binds: issue cycles the executed VALU instructions NEED --
+    every kernel's measured wave-instruction count x its cycles per instruction from the trip-count-weighted ISA model
+    (profiles/*_issue_model.json, tools/isa_weighted.py: 2 cycles for the plain VOP2 forms, 4 for the rest, 8 for rcp / sqrt /
+    64-bit multiplies) -- against the cycles the chip HAS during the call: time x 2.4 GHz x 1024 SIMDs."""
+    path, model = _latest_profile("_issue_model.json")
+    if not model or not insts:
         return None
-    return best
+    by_name = model.get("by_rocprof_name", {})
+    need, used, missing = 0.0, {}, []
+    for kname, n in (per_kernel or {}).items():
+        hit = [v for k, v in by_name.items() if k.split("(")[0].strip() in kname]
+        if hit:
+            need += n * hit[0]["cycles_per_instruction"]
+            used[kname[:60]] = hit[0]["cycles_per_instruction"]
+        else:
+            missing.append(kname[:60])
+    if not used:
+        return None
+    if missing:                                               # kernels without a model: the call's average mix
+        cpi = need / sum(n for k, n in per_kernel.items() if k[:60] in used)
+        need += sum(per_kernel[k] for k in per_kernel if k[:60] in missing) * cpi
+    avail = kernel_ms * 1e-3 * 2.4e9 * 1024
+    return {"cycles_needed": int(need), "cycles_available": int(avail), "frac": round(need / avail, 4),
+            "cycles_per_instruction": used, "model": os.path.relpath(path, ROOT),
+            "model_matches_source": model.get("_source_sha256") == cur_sha,
+            "unit": "SIMD issue cycles per C-ABI call (1 024 SIMDs x 2.4 GHz nominal; a wave64 VALU instruction holds its SIMD for 2, 4 or 8 cycles)",
+            "note": "1 - frac = issue slots the call leaves empty (dependency stalls, s_nop, LDS / memory waits, launch ramp and tail)"}
 
 
 def valu_block(insts, kernel_ms):
@@ -314,17 +348,26 @@ def rocprof_kernels(fmt):
                 if pat in r["Name"]:
                     m = re.search(r"(bc\w+<[^>]*>)", r["Name"])
                     out[m.group(1) if m else r["Name"][:48]] = round(float(r["AverageNs"]) / 1e6, 4)
-        return {"source": "profiles/" + names[-1], "avg_ms": out} if out else None
+        stamp = None
+        try:
+            stamp = open(os.path.join(ROOT, "profiles", names[-1] + ".sha256")).read().strip()
+        except OSError:
+            pass
+        return {"source": "profiles/" + names[-1], "avg_ms": out, "source_sha256": stamp} if out else None
     except (OSError, ValueError, KeyError):
         return None
 
 
-def pmc_traffic(workload):
-    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/pmc_traffic.json), if present."""
+def pmc_traffic(workload, cur_sha=None):
+    """HBM bytes per launch from a committed rocprofv3 --pmc pass (profiles/pmc_traffic.json) -- None when the pass was taken on other
+    kernel sources than the tree this runs from (its stamp, written by tools/profile_gpu.sh, differs)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+            j = json.load(f)
+        if cur_sha is not None and j.get("_source_sha256") != cur_sha:
+            return None
+        return j.get(workload, {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
 
@@ -464,6 +507,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     import itw_amd
     itw_amd.lib()                                   # fail loudly if the HIP library is missing
+    cur_sha = itw_amd.source_sha256()
     if FAKE:
         dev = torch.device("cpu")
     else:
@@ -578,7 +622,7 @@ def main():
                        "device": ("CONTROL-FLOW TEST ON CPU -- not a measurement" if FAKE else itw_amd.device_info()), "lib": itw_amd.version()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": pmc_traffic(args.workload) if (world == 1 and size == 4096) else None,   # PMC passes were taken at 4096^2
+                         "traffic": pmc_traffic(args.workload, cur_sha) if (world == 1 and size == 4096) else None,   # PMC passes were taken at 4096^2
                          "kernel_ms_avg": round(k_avg_ms, 4), "kernel_ms_min": round(k_min_ms, 4),
                          "algorithmic_bytes_per_launch": alg,
                          "note": "BC7/BC6H are VALU-issue bound (no MFMA-shaped work); the HBM fraction is reported "
@@ -597,18 +641,31 @@ def main():
                                                  "source": "profiles/" + names[-1]}
             except (OSError, ValueError, KeyError, IndexError):
                 result["same_job_on_one_gpu"] = None
+        # Counter values below come from COMMITTED profiling passes, not from this run: each pass carries the SHA-256 of the kernel
+        # sources it was taken on (tools/profile_gpu.sh) and is quoted only when that equals the tree this runs from
         rk = rocprof_kernels(fmt)
-        if rk and world == 1 and size == 4096 and scaling == "weak":
+        insts, per_kernel, valu_sha = pmc_valu(args.workload)
+        at_profile_size = world == 1 and size == 4096 and scaling == "weak"
+        if at_profile_size:
+            stamps = {"pmc_traffic": (_latest_profile("pmc_traffic.json")[1] or {}).get("_source_sha256"), "valu": valu_sha,
+                      "rocprof_kernels": rk.get("source_sha256") if rk else None}
+            result["roofline"]["profile_matches_source"] = {k: (v == cur_sha) for k, v in stamps.items()}
+            result["roofline"]["source_sha256"] = cur_sha
+        if rk and at_profile_size and rk.get("source_sha256") == cur_sha:
             # the call is several kernels for BC7; `achieved` uses the whole call.  For the slow / alpha_slow profiles the
             # kernels listed are exactly the call's (the ranked variants <.., 1|2, ..> belong to the faster presets).
             result["roofline"]["rocprof_kernels"] = rk
-        insts = pmc_valu(args.workload)
-        if insts and world == 1 and size == 4096 and scaling == "weak":
+        if insts and at_profile_size and valu_sha == cur_sha:
             result["roofline"]["valu"] = valu_block(insts, k_avg_ms)
             result["roofline"]["valu"]["note"] = (
                 "SQ_INSTS_VALU of one call (committed rocprofv3 pass) x 64 lanes / live kernel time; peak = 256 CU x 4 SIMD "
                 "x 32 lanes x 2.4 GHz, reached only by the 2-cycle VOP2 forms (v_mul/add_f32, v_add_u32, logic, shifts right); "
-                "cvt / cmp / fma / packed / dot forms issue at half that rate (tools/ubench)")
+                "cvt / cmp / fma / packed / dot forms issue at half that rate (tools/ubench): `issue` prices every form")
+            issue = issue_block(per_kernel, insts, k_avg_ms, cur_sha)
+            if issue:
+                result["roofline"]["issue"] = issue
+        else:
+            insts = None
 
     if rank == 0:
         per_block, method = op_counts(args.workload)
@@ -695,10 +752,13 @@ def main():
                 gbs = ALG_BYTES[f2] * nblocks / (avg * 1e-3) / 1e9
                 side[wl] = {"Mpixels/s": round(size * size / (avg * 1e-3) / 1e6, 1), "kernel_ms_avg": round(avg, 4),
                             "hbm_GBps": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 5),
-                            "traffic": pmc_traffic(wl)}
-                i2 = pmc_valu(wl)
-                if i2:                                         # the binding roofline of every format (SURVEY 8d asks for both)
+                            "traffic": pmc_traffic(wl, cur_sha)}
+                i2, pk2, sha2 = pmc_valu(wl)
+                if i2 and sha2 == cur_sha:                     # the binding roofline of every format (SURVEY 8d asks for both)
                     side[wl]["valu"] = valu_block(i2, avg)
+                    iss = issue_block(pk2, i2, avg, cur_sha)
+                    if iss:
+                        side[wl]["issue"] = {k: iss[k] for k in ("cycles_needed", "cycles_available", "frac", "model_matches_source")}
                 if light:
                     side[wl]["timing"] = "one HIP event pair around 200 back-to-back launches"
                 if wl == "bc7_alpha_slow":

@@ -197,6 +197,20 @@ def version():
     return lib().itwVersion().decode()
 
 
+def source_sha256():
+    """SHA-256 over the kernel sources (csrc/*.hip, *.hpp, *.h, Makefile: names and bytes, sorted).  Profiles taken on the GPU box
+    carry it (tools/profile_gpu.sh) and bench.py quotes committed counter values only when it equals the tree it runs from."""
+    import hashlib
+    d = os.path.normpath(os.path.join(_PKG, "..", "csrc"))
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp", ".h")) or name == "Makefile":
+            h.update(name.encode() + b"\0")
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 ON_ERROR_ABORT, ON_ERROR_RETURN = 0, 1
 BC7_PATH = {"auto": 0, "deep": 1, "wide": 2}
 

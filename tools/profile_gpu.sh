@@ -8,6 +8,9 @@ TAG=${1:-r01}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
+# every summary of this pass is stamped with the kernel sources it was taken on (bench.py drops committed counters whose stamp
+# differs from the tree it runs from: VERDICT r03 item 6)
+python -c "import sys; sys.path.insert(0, '$ROOT/intel-texture-works-plugin_amd'); import itw_amd; print(itw_amd.source_sha256())" > $OUT/source_sha256.txt
 cd /tmp && export TMPDIR=/tmp
 KERNELS='bc7_|bc13_kernel|bc6h_|bc45_kernel'
 

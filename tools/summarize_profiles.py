@@ -27,14 +27,37 @@ def per_call(path, counter):
     return total / calls, calls
 
 
+def per_call_by_kernel(path, counter):
+    """{kernel name: counter per C-ABI call} (same call count as per_call)."""
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    if not rows:
+        return {}
+    by_kernel = collections.Counter(r["Kernel_Name"] for r in rows)
+    calls = max(by_kernel.values())
+    out = collections.defaultdict(float)
+    for r in rows:
+        out[r["Kernel_Name"].split("(")[0].replace("void ", "").strip()] += float(r["Counter_Value"])
+    return {k: v / calls for k, v in out.items()}
+
+
 def main():
     tag = sys.argv[1]
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
+    try:
+        stamp = open(os.path.join(src, "source_sha256.txt")).read().strip()
+    except OSError:
+        stamp = None
     for name in sorted(os.listdir(src)):
         if name.endswith((".csv", ".json")):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{tag}_{name}"))
+            if stamp and name.startswith("kernel_stats"):            # csv files cannot carry the stamp themselves: a sidecar does
+                with open(os.path.join(dst, f"{tag}_{name}.sha256"), "w") as fh:
+                    fh.write(stamp + "\n")
+    if stamp:
+        with open(os.path.join(dst, f"{tag}_source_sha256.txt"), "w") as fh:
+            fh.write(stamp + "\n")
     traffic = {}
     for wl in ("bc1", "bc3", "bc4", "bc5", "bc7_slow", "bc6h_slow"):
         f = os.path.join(src, f"pmc_{wl}_FETCH_SIZE.csv")
@@ -50,6 +73,7 @@ def main():
         traffic[wl] = {"hbm_bytes_per_launch": int(fetch + write), "fetch_bytes_corrected_x2": int(fetch),
                        "write_bytes": int(write), "raw_FETCH_SIZE_KiB": fetch_kib, "raw_WRITE_SIZE_KiB": write_kib,
                        "calls_sampled": n, "source": f"profiles/{tag}_pmc_{wl}_FETCH_SIZE.csv, profiles/{tag}_pmc_{wl}_WRITE_SIZE.csv"}
+    traffic["_source_sha256"] = stamp
     traffic["_note"] = ("rocprofv3 --pmc, one counter per pass (TCC slots); per C-ABI call = all kernels of the call; gfx950 x2 "
                         "correction applied to FETCH_SIZE per MI355X_MICROARCH.md section HBM; calibrated on BC1: 2*FETCH = "
                         "texels read, WRITE = blocks written.")
@@ -62,6 +86,7 @@ def main():
             v, n = per_call(sq, c)
             if v is not None:
                 out[c] = v
+        out["_source_sha256"] = stamp
         out["_note"] = "per C-ABI call of bc7_slow at 4096x4096 (all kernels of the call); SQ cycle counters are in quad-cycles"
         with open(os.path.join(dst, f"{tag}_valu.json"), "w") as fh:
             json.dump(out, fh, indent=1)
@@ -76,8 +101,10 @@ def main():
             if v is not None:
                 row[c] = v
         if row:
+            row["per_kernel"] = per_call_by_kernel(sqf, "SQ_INSTS_VALU")      # bench.py prices each kernel with its own instruction mix
             by_wl[wl] = row
     if by_wl:
+        by_wl["_source_sha256"] = stamp
         by_wl["_note"] = ("per C-ABI call at 4096x4096 (all kernels of the call), rocprofv3 --pmc SQ pass of tools/profile_gpu.sh; SQ cycle "
                           "counters are in quad-cycles; bench.py turns SQ_INSTS_VALU into formats[*].valu")
         with open(os.path.join(dst, f"{tag}_valu_by_workload.json"), "w") as fh:
