@@ -62,15 +62,16 @@ __device__ __forceinline__ void decoded_levels(float (&g)[8], uint32_t r0, uint3
 
 // Entry of the run table for one endpoint pair: the index is constant on runs [T_j, T_j+1) of the texel code v, T_0 = 0.
 //   x, y   C_j = 256 - T_j for run j = 1..7, one byte each (C_1 in the low byte of x; 0 = no such run): v + C_j carries into
-//          bit 8 exactly when v >= T_j
-//   z      index of run j in nibble j
-//   w      number of runs (> 8 = the representation does not hold: checked once after the build)
+//          bit 8 exactly when v >= T_j.  The top byte of y holds the number of runs (> 8 = the representation does not hold:
+//          checked once after the build)
+//   z, w   index of run j in byte j (z: runs 0..3, w: runs 4..7): a v_perm_b32 with run counts as selector bytes looks up four
+//          texels at once
 __global__ void __launch_bounds__(256) bc45_build_index_table(uint4* __restrict__ table)
 {
     const uint32_t r0 = blockIdx.x, r1 = threadIdx.x;
     float g[8];
     decoded_levels(g, r0, r1);
-    uint32_t c[2] = {0u, 0u}, order = 0u, runs = 0u, prev = 8u;
+    uint32_t c[2] = {0u, 0u}, order[2] = {0u, 0u}, runs = 0u, prev = 8u;
     for (uint32_t v = 0; v < 256u; v++) {
         const float t = (float)v * UNORM_SCALE;
         // FindClosestUNORM (BC4BC5.cpp:314-337): first index with the strictly smallest |g - t|
@@ -83,12 +84,12 @@ __global__ void __launch_bounds__(256) bc45_build_index_table(uint4* __restrict_
         }
         if (best != prev) {
             if (runs >= 1u && runs < 8u) c[(runs - 1u) >> 2] |= (256u - v) << (8u * ((runs - 1u) & 3u));
-            if (runs < 8u) order |= best << (4u * runs);
+            if (runs < 8u) order[runs >> 2] |= best << (8u * (runs & 3u));
             runs++;
             prev = best;
         }
     }
-    table[r0 * 256u + r1] = make_uint4(c[0], c[1], order, runs);
+    table[r0 * 256u + r1] = make_uint4(c[0], c[1] | (min(runs, 255u) << 24), order[0], order[1]);
 }
 
 struct TableSlot { std::once_flag once; uint4* table = nullptr; };
@@ -109,7 +110,7 @@ const uint4* index_table(hipStream_t st)
         if (e == hipSuccess) e = hipStreamSynchronize(st);        // later calls use the table from any stream
         if (e != hipSuccess) { (void)hipFree(t); fail_hip("bc45_build_index_table", e, __FILE__, __LINE__); }
         for (const uint4& v : h)
-            if (v.w < 1u || v.w > 8u) { (void)hipFree(t); fail_msg("BC4/BC5 index table: an endpoint pair has %u runs (at most 8 expected)", v.w); }
+            if ((v.y >> 24) < 1u || (v.y >> 24) > 8u) { (void)hipFree(t); fail_msg("BC4/BC5 index table: an endpoint pair has %u runs (at most 8 expected)", v.y >> 24); }
         s.table = t;
     });
     return s.table;
@@ -181,9 +182,12 @@ __device__ __forceinline__ uint2 encode_channel(const uint32_t (&P)[8], const St
 {
     float t[16];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        t[2 * j]     = (float)(P[j] & 0xffffu) * UNORM_SCALE;
-        t[2 * j + 1] = (float)(P[j] >> 16) * UNORM_SCALE;
+    for (int j = 0; j < 8; j++) {                                 // one v_cvt_f32_ubyteN per texel, straight from the packed pair
+        float lo, hi;
+        asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(lo) : "v"(P[j]));
+        asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(hi) : "v"(P[j]));
+        t[2 * j] = lo * UNORM_SCALE;
+        t[2 * j + 1] = hi * UNORM_SCALE;
     }
     // smallest / largest code, and for the 6-step ramp the smallest above 0 / largest below 255 (BC.h:742-766; fX starts at
     // 1.0 = code 255 and fY at 0.0 = code 0, which is also what "no such texel" leaves behind)
@@ -219,18 +223,23 @@ __device__ __forceinline__ uint2 encode_channel(const uint32_t (&P)[8], const St
 #pragma unroll
     for (int j = 0; j < 7; j++)
         C[j] = __builtin_amdgcn_perm(0u, j < 4 ? e.x : e.y, 0x0c000c00u | (uint32_t)((j & 3) * 0x00010001));   // byte j -> both halves
+    // run indices as bytes (e.z: runs 0..3, e.w: runs 4..7): a v_perm_b32 whose selector bytes are the run counts (0..7) of FOUR
+    // texels looks all four up at once
+    const uint32_t tab_lo = e.z, tab_hi = e.w;
     const uint32_t carry = 0x01000100u;
     uint32_t part[2] = {0u, 0u};                                  // 3-bit indices of texels 0..7 / 8..15
 #pragma unroll
-    for (int j = 7; j >= 0; j--) {                                // Horner from the last texel down: (acc << 3) | index
-        uint32_t s = (P[j] + C[0]) & carry;
+    for (int q = 3; q >= 0; q--) {                                // four texels (two pairs) per step, from the last down: (acc << 12) | 12 bits
+        uint32_t sa = (P[2 * q] + C[0]) & carry, sb = (P[2 * q + 1] + C[0]) & carry;
 #pragma unroll
-        for (int k = 1; k < 7; k++) s += (P[j] + C[k]) & carry;
-        const uint32_t hi = (e.z >> ((s >> 22) & 0x1cu)) & 7u;    // run count x 4 = the nibble's shift
-        const uint32_t lo = (e.z >> ((s >> 6) & 0x1cu)) & 7u;
-        uint32_t& acc = part[j >> 2];
-        acc = (acc << 3) | hi;
-        acc = (acc << 3) | lo;
+        for (int k = 1; k < 7; k++) { sa += (P[2 * q] + C[k]) & carry; sb += (P[2 * q + 1] + C[k]) & carry; }
+        // the counts sit in bytes 1 and 3 of each sum: gather them in texel order, look the run indices up, squeeze 4 x 3 bits together
+        const uint32_t counts = __builtin_amdgcn_perm(sb, sa, 0x07050301u);
+        const uint32_t idx = __builtin_amdgcn_perm(tab_hi, tab_lo, counts);
+        const uint32_t two = (idx | (idx >> 5)) & 0x003f003fu;    // texels (0,1) in bits 0..5, (2,3) in bits 16..21
+        const uint32_t four = (two | (two >> 10)) & 0x0fffu;
+        uint32_t& acc = part[q >> 1];
+        acc = (acc << 12) | four;
     }
     return make_uint2(r0 | (r1 << 8) | (part[0] << 16), (part[0] >> 16) | (part[1] << 8));
 }

@@ -1492,6 +1492,10 @@ __device__ __forceinline__ void merge_parts(Win& w, Lane& ln, const uint4* __res
 #ifndef WIDE_SCAN_WAVES
 #define WIDE_SCAN_WAVES 4
 #endif
+// a scan is split until its waves fill 1 / WIDE_FILL_DIVISOR of the chip's wave slots (tuning constant, like the register budgets)
+#ifndef WIDE_FILL_DIVISOR
+#define WIDE_FILL_DIVISOR 2
+#endif
 // RANKED_LISTS: some family scans a PCA-ranked prefix (fast presets): that code keeps 16 sorted keys in registers and runs
 // at 3 waves per SIMD like its deep counterpart; the whole-table instantiation (slow presets) compiles it out.
 template <bool VEC16, bool RANKED_LISTS>
@@ -1728,7 +1732,7 @@ static void launch_bc7_wide(const uint8_t* src, int64_t stride, int bx, int64_t 
     const int families = (on02 ? 1 : 0) + (on13 ? 1 : 0) + (on7 ? 1 : 0);
     const int resident = 1024 * (any_ranked ? 3 : WIDE_SCAN_WAVES);
     int want = 1;
-    while (want < WIDE_MAX_PARTS && waves * families * want * 2 <= resident) want *= 2;
+    while (want < WIDE_MAX_PARTS && waves * families * want * WIDE_FILL_DIVISOR <= resident) want *= 2;
     auto cap = [&](int limit) { int p = want; while (p > limit) p /= 2; return p < 1 ? 1 : p; };
     const int p02 = cap(16);                                                        // 16 or 64 shapes
     const int list13 = ranked13 ? (S.fastSkipTreshold_mode1 > S.fastSkipTreshold_mode3 ? S.fastSkipTreshold_mode1 : S.fastSkipTreshold_mode3) : 64;
