@@ -153,22 +153,35 @@ __device__ __forceinline__ void newton_loop(float& fx, float& fy, const float (&
         const float to_zero = (SIX && six) ? fx * 0.5f : -1.0f;
         const float to_one  = (SIX && six) ? (fy + 1.0f) * 0.5f : 2.0f;
         float dx = 0.0f, dy = 0.0f, d2x = 0.0f, d2y = 0.0f;
+        // four texels per batch: their steps first, then their four table reads in flight together, then the sums in texel order
+        // (left to the compiler, every read was followed by its wait: sixteen serial LDS round trips per pass)
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const float dot16 = (t[i] - fx) * scale16;
-            // dot <= 0 -> step 0, dot >= fsteps -> the last step, else (int)(dot + 0.5): clamp first, the clamped ends convert to themselves
-            const float m = __builtin_amdgcn_fmed3f(dot16, 0.0f, top16);
-            uint32_t off = (uint32_t)(int32_t)(m + 8.0f) & 0x70u;
-            if (SIX) {
-                if (dot16 <= 0.0f && t[i] <= to_zero) off = 6u * 16u;
-                if (dot16 >= top16 && t[i] >= to_one) off = 7u * 16u;
+        for (int i0 = 0; i0 < 16; i0 += 4) {
+            uint32_t off[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u;
+                const float dot16 = (t[i] - fx) * scale16;
+                // dot <= 0 -> step 0, dot >= fsteps -> the last step, else (int)(dot + 0.5): clamp first, the clamped ends convert to themselves
+                const float m = __builtin_amdgcn_fmed3f(dot16, 0.0f, top16);
+                off[u] = (uint32_t)(int32_t)(m + 8.0f) & 0x70u;
+                if (SIX) {
+                    if (dot16 <= 0.0f && t[i] <= to_zero) off[u] = 6u * 16u;
+                    if (dot16 >= top16 && t[i] >= to_one) off[u] = 7u * 16u;
+                }
             }
-            const StepWeights w = *reinterpret_cast<const StepWeights*>(base + off);
-            const float diff = (w.c * fx + w.d * fy) - t[i];
-            dx += w.c * diff;
-            d2x += w.cc;
-            dy += w.d * diff;
-            d2y += w.dd;
+            StepWeights w[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) w[u] = *reinterpret_cast<const StepWeights*>(base + off[u]);
+            __builtin_amdgcn_sched_barrier(0);                    // keep the four reads ahead of the arithmetic that consumes them
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float diff = (w[u].c * fx + w[u].d * fy) - t[i0 + u];
+                dx += w[u].c * diff;
+                d2x += w[u].cc;
+                dy += w[u].d * diff;
+                d2y += w[u].dd;
+            }
         }
         if (d2x > 0.0f) fx -= dx / d2x;
         if (d2y > 0.0f) fy -= dy / d2y;
@@ -192,24 +205,28 @@ __device__ __forceinline__ uint2 encode_channel(const uint32_t (&P)[8], const St
     // smallest / largest code, and for the 6-step ramp the smallest above 0 / largest below 255 (BC.h:742-766; fX starts at
     // 1.0 = code 255 and fY at 0.0 = code 0, which is also what "no such texel" leaves behind)
     uint32_t mn = P[0], mx = P[0];
-    uint32_t lo6 = (P[0] + 0x00ff00ffu) & 0x00ff00ffu, hi6 = (P[0] + 0x00010001u) & 0x00ff00ffu;
 #pragma unroll
-    for (int j = 1; j < 8; j++) {
-        mn = pk_min_u16(mn, P[j]); mx = pk_max_u16(mx, P[j]);
-        lo6 = pk_min_u16(lo6, (P[j] + 0x00ff00ffu) & 0x00ff00ffu);       // (v - 1) mod 256: code 0 becomes the largest
-        hi6 = pk_max_u16(hi6, (P[j] + 0x00010001u) & 0x00ff00ffu);       // (v + 1) mod 256: code 255 becomes the smallest
-    }
+    for (int j = 1; j < 8; j++) { mn = pk_min_u16(mn, P[j]); mx = pk_max_u16(mx, P[j]); }
     const uint32_t cmin = min(mn & 0xffffu, mn >> 16), cmax = max(mx & 0xffffu, mx >> 16);
     const bool six = (cmin == 0u) || (cmax == 255u);                     // BC4BC5.cpp:213: 0.0f == fBlockMin || 1.0f == fBlockMax
+    const bool any_six = __any(six);                                     // wave-uniform: most waves have no 6-step block at all
     uint32_t cx = cmin, cy = cmax;
-    if (six) {
-        const uint32_t l = min(lo6 & 0xffffu, lo6 >> 16), h = max(hi6 & 0xffffu, hi6 >> 16);
-        cx = min(l + 1u, 255u);
-        cy = h ? h - 1u : 0u;
+    if (any_six) {
+        uint32_t lo6 = (P[0] + 0x00ff00ffu) & 0x00ff00ffu, hi6 = (P[0] + 0x00010001u) & 0x00ff00ffu;
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            lo6 = pk_min_u16(lo6, (P[j] + 0x00ff00ffu) & 0x00ff00ffu);   // (v - 1) mod 256: code 0 becomes the largest
+            hi6 = pk_max_u16(hi6, (P[j] + 0x00010001u) & 0x00ff00ffu);   // (v + 1) mod 256: code 255 becomes the smallest
+        }
+        if (six) {
+            const uint32_t l = min(lo6 & 0xffffu, lo6 >> 16), h = max(hi6 & 0xffffu, hi6 >> 16);
+            cx = min(l + 1u, 255u);
+            cy = h ? h - 1u : 0u;
+        }
     }
     float fx = (float)cx * UNORM_SCALE, fy = (float)cy * UNORM_SCALE;
     if (six && fx == fy) fy = 1.0f;
-    if (__any(six)) newton_loop<true>(fx, fy, t, six, tab8, tab6);
+    if (any_six) newton_loop<true>(fx, fy, t, six, tab8, tab6);
     else            newton_loop<false>(fx, fy, t, false, tab8, tab6);
     const float ox = (fx < 0.0f) ? 0.0f : (fx > 1.0f) ? 1.0f : fx;
     const float oy = (fy < 0.0f) ? 0.0f : (fy > 1.0f) ? 1.0f : fy;
@@ -244,8 +261,12 @@ __device__ __forceinline__ uint2 encode_channel(const uint32_t (&P)[8], const St
     return make_uint2(r0 | (r1 << 8) | (part[0] << 16), (part[0] >> 16) | (part[1] << 8));
 }
 
+// register budget (waves per SIMD), a tuning constant like the BC7 kernels'
+#ifndef BC45_WAVES
+#define BC45_WAVES 4
+#endif
 template <int NCH, bool VEC16>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BC45_WAVES, BC45_WAVES)))
 bc45_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t width, int32_t height, int32_t blocks_x,
             int32_t nlanes, uint8_t* __restrict__ dst, const uint4* __restrict__ runs)
 {
