@@ -104,6 +104,11 @@ __device__ __forceinline__ int32_t f2i(float f) { return SAFE ? (int32_t)f : f2i
 // 1003-1017: mode 7 compares raw 6-bit codes against 8-bit targets, a reference quirk), mode 0 its 5-bit expansion.
 // For b = 1 the reference's u = (t - 1)*0.5 + 0.5 equals t*0.5 exactly when t >= 0.5 (t - 1 is then exact, the rest
 // is scaling and an exactly representable sum); for t < 0.5 both floors are 0.  SAFE paths use floor(t*0.5) directly.
+// Round 4: mode 0 (4 bits + p-bit, compared through its 5-bit expansion) and mode 1 (shared p-bit, 7-bit expansion) take the same
+// float-domain route in the scans: a code c is an integer-valued float, and expand_to_byte(c, BITS) = c * 2^(8-BITS) + (c >> (2*BITS-8))
+// is c * 8 + floor(c / 4) for 5 bits and c * 2 + [c >= 64] for 7 bits -- exact in fp32 (small integers, power-of-two scalings) -- so
+// the hypotheses' decoded values are formed without a float -> int -> float round trip per value (the integer route costs a
+// conversion each way plus a shift, a bit-field extract and an add, all 4-cycle forms; tests/test_exact_forms.py walks every code).
 template <int MODE, bool SAFE>
 __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4], const float (&e)[2][4], int err_ch)
 {
@@ -111,14 +116,17 @@ __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4
     constexpr int L2 = (1 << BITS) * 2 - 1;
     #pragma unroll
     for (int i = 0; i < 2; i++) {
-        if (SAFE && MODE != 0) {
-            float db[2][4];
+        if (SAFE) {
+            float cb[2][4], db[2][4];          // code incl. p-bit / what the error is measured against, per hypothesis
             #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const float t = e[i][p] * INV255 * (float)L2;
                 const float v0 = __builtin_floorf(t * 0.5f + 0.5f) * 2.0f;
-                db[0][p] = __builtin_fminf(v0, (float)(L2 - 1));                   // v0 is an ordinary number here (SAFE)
-                db[1][p] = __builtin_floorf(t * 0.5f) * 2.0f + 1.0f;       // (t-1)/2 + 1/2 = t/2 exactly for t >= 0.5, floor 0 below
+                cb[0][p] = __builtin_fminf(v0, (float)(L2 - 1));                   // v0 is an ordinary number here (SAFE)
+                cb[1][p] = __builtin_floorf(t * 0.5f) * 2.0f + 1.0f;       // (t-1)/2 + 1/2 = t/2 exactly for t >= 0.5, floor 0 below
+                #pragma unroll
+                for (int b = 0; b < 2; b++)
+                    db[b][p] = (MODE == 0) ? cb[b][p] * 8.0f + __builtin_floorf(cb[b][p] * 0.25f) : cb[b][p];   // mode 0: 5-bit code -> byte
             }
             float err0 = 0.f, err1 = 0.f;
             #pragma unroll
@@ -127,8 +135,8 @@ __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4
             const bool first = err0 < err1;
             #pragma unroll
             for (int p = 0; p < 4; p++) {
-                q[i][p] = (int32_t)(first ? db[0][p] : db[1][p]);
-                d[i][p] = (MODE == 7) ? expand_to_byte(q[i][p], 6) : q[i][p];
+                q[i][p] = (int32_t)(first ? cb[0][p] : cb[1][p]);
+                d[i][p] = (MODE == 7) ? expand_to_byte(q[i][p], 6) : (MODE == 0) ? (int32_t)(first ? db[0][p] : db[1][p]) : q[i][p];
             }
             continue;
         }
@@ -139,9 +147,9 @@ __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4
             #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const float t = e[i][p] * INV255 * (float)L2;
-                const float u = (SAFE && b == 1) ? t * 0.5f : (t - (float)b) * 0.5f + 0.5f;
+                const float u = (t - (float)b) * 0.5f + 0.5f;
                 const uint32_t v = (uint32_t)f2i<SAFE>(u) * 2u + (uint32_t)b;
-                qb[b][p] = SAFE ? ((b == 0) ? min((int32_t)v, L2 - 1) : (int32_t)v) : iclamp((int32_t)v, b, L2 - 1 + b);
+                qb[b][p] = iclamp((int32_t)v, b, L2 - 1 + b);
                 // mode 0 compares in 8-bit space; modes 3/6 codes are 8-bit; mode 7 compares raw 6-bit codes
                 // against 8-bit targets (reference quirk, kernel.ispc:1003-1017)
                 db[b][p] = (float)((MODE == 0) ? expand_to_byte(qb[b][p], 5) : qb[b][p]);
@@ -163,6 +171,36 @@ __device__ __forceinline__ void quant_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4
 template <bool SAFE>
 __device__ __forceinline__ void quant_shared_pbit(int32_t (&q)[2][4], int32_t (&d)[2][4], const float (&e)[2][4])
 {
+    if (SAFE) {
+        // float domain (see quant_pbit): code c in [0, 127], decoded byte c * 2 + (c >> 6) = c + c + [c >= 64]
+        float cb[2][2][4], db[2][2][4];
+        #pragma unroll
+        for (int i = 0; i < 2; i++)
+            #pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const float t = e[i][p] * INV255 * 127.0f;
+                const float v0 = __builtin_floorf(t * 0.5f + 0.5f) * 2.0f;
+                cb[0][i][p] = __builtin_fminf(v0, 126.0f);
+                cb[1][i][p] = __builtin_floorf(t * 0.5f) * 2.0f + 1.0f;
+                #pragma unroll
+                for (int b = 0; b < 2; b++)
+                    db[b][i][p] = cb[b][i][p] * 2.0f + __builtin_floorf(cb[b][i][p] * 0.015625f);
+            }
+        float err0 = 0.f, err1 = 0.f;
+        #pragma unroll
+        for (int i = 0; i < 2; i++)
+            #pragma unroll
+            for (int p = 0; p < 3; p++) { err0 += sq(e[i][p] - db[0][i][p]); err1 += sq(e[i][p] - db[1][i][p]); }
+        const bool first = err0 < err1;
+        #pragma unroll
+        for (int i = 0; i < 2; i++)
+            #pragma unroll
+            for (int p = 0; p < 4; p++) {
+                q[i][p] = (int32_t)(first ? cb[0][i][p] : cb[1][i][p]);
+                d[i][p] = (int32_t)(first ? db[0][i][p] : db[1][i][p]);
+            }
+        return;
+    }
     int32_t qb[2][2][4];
     float db[2][2][4];
     #pragma unroll
@@ -172,9 +210,9 @@ __device__ __forceinline__ void quant_shared_pbit(int32_t (&q)[2][4], int32_t (&
             #pragma unroll
             for (int p = 0; p < 4; p++) {
                 const float t = e[i][p] * INV255 * 127.0f;
-                const float u = (SAFE && b == 1) ? t * 0.5f : (t - (float)b) * 0.5f + 0.5f;      // see quant_pbit
+                const float u = (t - (float)b) * 0.5f + 0.5f;
                 const uint32_t v = (uint32_t)f2i<SAFE>(u) * 2u + (uint32_t)b;
-                qb[b][i][p] = SAFE ? ((b == 0) ? min((int32_t)v, 126) : (int32_t)v) : iclamp((int32_t)v, b, 126 + b);
+                qb[b][i][p] = iclamp((int32_t)v, b, 126 + b);
                 db[b][i][p] = (float)expand_to_byte(qb[b][i][p], 7);
             }
     float err0 = 0.f, err1 = 0.f;

@@ -306,3 +306,32 @@ def test_bc6h_float_weight_form_is_exact():
             assert int(np.floor(f(x1))) == want1 and int(np.floor(f(x0))) == want0, (bits, q)
             for x in (x1, x0):
                 assert min(x - np.floor(x), np.ceil(x) - x) > 0.02 or x == np.floor(x), (bits, q, x)
+
+
+def test_round4_expand_to_byte_in_the_float_domain():
+    """csrc/bc7.hip quant_pbit<0> / quant_shared_pbit (scans): a code c is carried as an integer-valued float and its byte
+    expansion expand_to_byte(c, BITS) = (c << (8 - BITS)) + ((c << (8 - BITS)) >> BITS) (kernel.ispc:976-981) is formed as
+    c * 8 + floor(c * 0.25) for 5 bits (mode 0: 4 bits + p-bit) and c * 2 + floor(c * (1/64)) for 7 bits (mode 1: 6 bits + shared
+    p-bit).  Every code, in fp32 exactly as the kernel evaluates it."""
+    import numpy as np
+    f = np.float32
+    for bits, scale, frac in ((5, f(8.0), f(0.25)), (7, f(2.0), f(0.015625))):
+        for c in range(1 << bits):
+            vv = c << (8 - bits)
+            want = vv + (vv >> bits)
+            cf = f(c)
+            got = f(f(cf * scale) + np.floor(f(cf * frac)))
+            assert float(got) == float(want) and 0 <= want <= 255, (bits, c, got, want)
+    # the hypotheses themselves: for t = e/255 * L2 in [0, L2] the SAFE forms give the reference's clamped codes
+    for L2, hi0 in ((31, 30), (127, 126)):
+        for k in range(0, 4 * L2 + 1):
+            t = f(k) / f(4.0)                                   # quarter steps cover both sides of every rounding boundary
+            for b in (0, 1):
+                u = f(f(f(t - f(b)) * f(0.5)) + f(0.5))
+                v = int(np.trunc(u)) * 2 + b                    # (int) of the reference: truncation (u > -1 here)
+                ref = min(max(v, b), L2 - 1 + b)
+                if b == 0:
+                    got = min(float(np.floor(f(f(t * f(0.5)) + f(0.5))) * 2.0), float(hi0))
+                else:
+                    got = float(np.floor(f(t * f(0.5)))) * 2.0 + 1.0
+                assert got == ref, (L2, float(t), b, got, ref)
