@@ -67,7 +67,7 @@ def kernel_body(text, pattern):
         if m and cur is None:
             dem = subprocess.run(["c++filt", m.group(1)], stdout=subprocess.PIPE, text=True).stdout.strip()
             if pattern in dem:
-                name, cur = dem.split("(")[0], []
+                name, cur = dem.replace("(anonymous namespace)::", "").split("(")[0], []
                 continue
         if cur is not None:
             cur.append(line)

@@ -36,7 +36,7 @@ def per_call_by_kernel(path, counter):
     calls = max(by_kernel.values())
     out = collections.defaultdict(float)
     for r in rows:
-        out[r["Kernel_Name"].split("(")[0].replace("void ", "").strip()] += float(r["Counter_Value"])
+        out[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()] += float(r["Counter_Value"])
     return {k: v / calls for k, v in out.items()}
 
 
