@@ -261,62 +261,80 @@ __device__ __forceinline__ uint2 encode_channel(const uint32_t (&P)[8], const St
     return make_uint2(r0 | (r1 << 8) | (part[0] << 16), (part[0] >> 16) | (part[1] << 8));
 }
 
-// register budget (waves per SIMD), a tuning constant like the BC7 kernels'
+// register budget (waves per SIMD) and grid, tuning constants like the BC7 kernels'
 #ifndef BC45_WAVES
 #define BC45_WAVES 4
 #endif
+#ifndef BC45_GRID
+#define BC45_GRID 2048
+#endif
+
+// The sixteen texel words of channel-block `lane` (4 x dwordx4 when VEC16 and the block is whole).  Partial blocks: missing columns /
+// rows repeat source column / row {0,0,0,1}[i], itself wrapped to 0 when that one is missing too (DirectXTexCompress.cpp:140-168
+// applied in its own order).
+template <int NCH, bool VEC16>
+__device__ __forceinline__ void load_words45(uint32_t (&w)[16], const uint8_t* __restrict__ src, int64_t stride, int32_t width, int32_t height,
+                                             int32_t blocks_x, int32_t lane)
+{
+    const int32_t b = (NCH == 2) ? (lane >> 1) : lane;
+    const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
+    const int32_t pw = min(4, width - 4 * xx), ph = min(4, height - 4 * yy);
+    const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 16;
+    if (pw == 4 && ph == 4) {
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            if (VEC16) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p + y * stride);
+                w[4 * y] = v.x; w[4 * y + 1] = v.y; w[4 * y + 2] = v.z; w[4 * y + 3] = v.w;
+            } else {
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(p + y * stride);
+                w[4 * y] = q[0]; w[4 * y + 1] = q[1]; w[4 * y + 2] = q[2]; w[4 * y + 3] = q[3];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            int sy = y < ph ? y : (y == 3 ? 1 : 0);
+            if (sy >= ph) sy = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                int sx = x < pw ? x : (x == 3 ? 1 : 0);
+                if (sx >= pw) sx = 0;
+                w[4 * y + x] = *reinterpret_cast<const uint32_t*>(p + sy * stride + sx * 4);
+            }
+        }
+    }
+}
+
+// Persistent workgroups (round 4): a wave of this kernel executes ~630 VALU instructions per block -- a fifth of it waiting for its
+// own texels if it loads, encodes, stores and exits (measured: 55-62 % of the issue slots used).  So at most BC45_GRID workgroups walk
+// the surface in chunks of 256 channel blocks and request the NEXT chunk's texels before encoding the current one.
 template <int NCH, bool VEC16>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BC45_WAVES, BC45_WAVES)))
 bc45_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t width, int32_t height, int32_t blocks_x,
             int32_t nlanes, uint8_t* __restrict__ dst, const uint4* __restrict__ runs)
 {
     __shared__ StepWeights s_tab[16];                             // [0..7] the 8-step ramp, [8..15] the 6-step ramp
+    int32_t lane = blockIdx.x * 256 + threadIdx.x;
+    uint32_t w[16];
+    load_words45<NCH, VEC16>(w, src, stride, width, height, blocks_x, lane < nlanes ? lane : nlanes - 1);
     if (threadIdx.x < 16) s_tab[threadIdx.x] = step_weights(threadIdx.x < 8 ? 8 : 6, threadIdx.x & 7);
     __syncthreads();
-    const int32_t lane = blockIdx.x * 256 + threadIdx.x;
-    if (lane >= nlanes) return;
-    const int32_t b = (NCH == 2) ? (lane >> 1) : lane;
-    const uint32_t ch = (NCH == 2) ? (uint32_t)(lane & 1) : 0u;   // byte of the RGBA8 word this lane encodes
-    const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
-    const int32_t pw = min(4, width - 4 * xx), ph = min(4, height - 4 * yy);
-    const uint8_t* p = src + (int64_t)yy * 4 * stride + (int64_t)xx * 16;
+    const uint32_t ch = (NCH == 2) ? (uint32_t)(threadIdx.x & 1) : 0u;   // byte of the RGBA8 word this lane encodes (the grid step is even)
     const uint32_t sel = 0x0c040c00u + ch * 0x00010001u;          // v_perm: byte ch of the first word | byte ch of the second << 16
-
-    uint32_t P[8];
-    if (pw == 4 && ph == 4) {
+    const int32_t step = (int32_t)gridDim.x * 256;
+    for (;;) {
+        uint32_t P[8];
 #pragma unroll
-        for (int y = 0; y < 4; y++) {
-            uint32_t w[4];
-            if (VEC16) {
-                const uint4 v = *reinterpret_cast<const uint4*>(p + y * stride);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else {
-                const uint32_t* q = reinterpret_cast<const uint32_t*>(p + y * stride);
-                w[0] = q[0]; w[1] = q[1]; w[2] = q[2]; w[3] = q[3];
-            }
-            P[2 * y]     = __builtin_amdgcn_perm(w[1], w[0], sel);
-            P[2 * y + 1] = __builtin_amdgcn_perm(w[3], w[2], sel);
-        }
-    } else {
-        // partial block: missing columns / rows repeat source column / row {0,0,0,1}[i], itself wrapped to 0 when
-        // that one is missing too (DirectXTexCompress.cpp:140-168 applied in its own order)
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-            int sy = y < ph ? y : (y == 3 ? 1 : 0);
-            if (sy >= ph) sy = 0;
-            uint32_t w[4];
-#pragma unroll
-            for (int x = 0; x < 4; x++) {
-                int sx = x < pw ? x : (x == 3 ? 1 : 0);
-                if (sx >= pw) sx = 0;
-                w[x] = *reinterpret_cast<const uint32_t*>(p + sy * stride + sx * 4);
-            }
-            P[2 * y]     = __builtin_amdgcn_perm(w[1], w[0], sel);
-            P[2 * y + 1] = __builtin_amdgcn_perm(w[3], w[2], sel);
-        }
+        for (int j = 0; j < 8; j++) P[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], sel);
+        const int32_t cur = lane;
+        lane += step;
+        const bool more = (lane - (int32_t)threadIdx.x) < nlanes;         // wave-uniform per workgroup: some lane of the next chunk exists
+        if (more) load_words45<NCH, VEC16>(w, src, stride, width, height, blocks_x, lane < nlanes ? lane : nlanes - 1);
+        const uint2 o = encode_channel(P, s_tab, s_tab + 8, runs);
+        if (cur < nlanes) *reinterpret_cast<uint2*>(dst + (int64_t)cur * 8) = o;
+        if (!more) break;
     }
-    const uint2 o = encode_channel(P, s_tab, s_tab + 8, runs);
-    *reinterpret_cast<uint2*>(dst + (int64_t)lane * 8) = o;
 }
 
 template <int NCH>
@@ -327,7 +345,8 @@ void launch_bc45(const uint8_t* src, int64_t stride, int width, int height, uint
     const int64_t n = (int64_t)bx * by * NCH;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 15) == 0;
     const uint4* runs = index_table(st);
-    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
+    const int64_t chunks = (n + 255) / 256;
+    const dim3 grid((unsigned)(chunks < BC45_GRID ? chunks : BC45_GRID)), blk(256);
     if (vec) hipLaunchKernelGGL((bc45_kernel<NCH, true>),  grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst, runs);
     else     hipLaunchKernelGGL((bc45_kernel<NCH, false>), grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst, runs);
 }

@@ -284,6 +284,19 @@ def main():
         agg = model.setdefault("by_rocprof_name", {}).setdefault(name.replace("void ", ""), {"valu": 0.0, "cycles": 0.0, "parts": []})
         agg["valu"] += n_valu; agg["cycles"] += tot_cyc; agg["parts"].append(k["name"])
         agg["cycles_per_instruction"] = round(agg["cycles"] / max(agg["valu"], 1), 4)
+    summary = ["# executed VALU instructions per unit of work: weighted ISA model vs the SQ_INSTS_VALU counter (tools/isa_weighted.py)",
+               "# kernel | model instructions | measured | model / measured | cycles per instruction (what bench.py's roofline.issue uses)"]
+    for kname, meas in spec.get("measured", {}).items():
+        agg = model["by_rocprof_name"].get(kname)
+        if not agg:
+            continue
+        agg["measured_valu_per_unit"] = meas["valu_per_unit"]
+        agg["model_over_measured"] = round(agg["valu"] / meas["valu_per_unit"], 3)
+        agg["measured_unit"], agg["measured_source"] = meas["unit"], meas["source"]
+        summary.append(f"{kname} | {agg['valu']:,.0f} | {meas['valu_per_unit']:,} per {meas['unit']} | {agg['model_over_measured']} | {agg['cycles_per_instruction']}")
+    with open(os.path.join(ROOT, "profiles", f"{tag}_isa_summary.txt"), "w") as f:
+        f.write("\n".join(summary) + "\n")
+    print("\n".join(summary))
     for wl, parts in spec.get("workloads", {}).items():
         cyc = sum(model["kernels"][p["kernel"]]["issue_cycles_per_wave"] * p["waves_per_call"] for p in parts)
         valu = sum(model["kernels"][p["kernel"]]["valu_per_wave"] * p["waves_per_call"] for p in parts)
