@@ -108,8 +108,8 @@ class variant:
         global _override
         if self.name not in _variant_libs:
             path = os.path.join(_HERE, "_variants", f"liboracle_bcn_{self.name}.so")
-            if not os.path.exists(path):
-                subprocess.run(["make", "-C", _HERE, "-s", "variants"], check=True)
+            # make decides: a variant older than the sources (a function added since) is rebuilt, like the main library
+            subprocess.run(["make", "-C", _HERE, "-s", "variants"], check=True)
             _variant_libs[self.name] = _bind(path)
         self._saved, _override = _override, _variant_libs[self.name]
         return self
