@@ -68,7 +68,20 @@ WORKLOADS = {
 }
 
 
+_SURFACES = {}
+
+
 def make_surface(fmt, size, rank):
+    """Seeded synthetic surface (cached: the N > 1 jobs cut several bands from the same base)."""
+    key = (fmt == "bc6h", size, rank)
+    if key not in _SURFACES:
+        if len(_SURFACES) > 4:
+            _SURFACES.clear()
+        _SURFACES[key] = _make_surface(fmt, size, rank)
+    return _SURFACES[key]
+
+
+def _make_surface(fmt, size, rank):
     from itw_amd import surfaces
     if fmt == "bc6h":
         return surfaces.hdr_smooth(size, size, seed=surfaces.SEED + 3 + 100 * rank)
