@@ -309,7 +309,10 @@ __device__ __forceinline__ void load_words45(uint32_t (&w)[16], const uint8_t* _
 // Persistent workgroups (round 4): a wave of this kernel executes ~630 VALU instructions per block -- a fifth of it waiting for its
 // own texels if it loads, encodes, stores and exits (measured: 55-62 % of the issue slots used).  So at most BC45_GRID workgroups walk
 // the surface in chunks of 256 channel blocks and request the NEXT chunk's texels before encoding the current one.
-template <int NCH, bool VEC16>
+// WHOLE (the common case: width and height multiples of 4, the surface below 2 GiB): no partial blocks, and the walk keeps each
+// lane's block position and byte offset incrementally -- one division per workgroup instead of one per chunk, 32-bit offsets from the
+// uniform base instead of four 64-bit row pointers with their source-row / column selects (about 90 of the 630 instructions).
+template <int NCH, bool VEC16, bool WHOLE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BC45_WAVES, BC45_WAVES)))
 bc45_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t width, int32_t height, int32_t blocks_x,
             int32_t nlanes, uint8_t* __restrict__ dst, const uint4* __restrict__ runs)
@@ -317,20 +320,60 @@ bc45_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t width, int3
     __shared__ StepWeights s_tab[16];                             // [0..7] the 8-step ramp, [8..15] the 6-step ramp
     int32_t lane = blockIdx.x * 256 + threadIdx.x;
     uint32_t w[16];
-    load_words45<NCH, VEC16>(w, src, stride, width, height, blocks_x, lane < nlanes ? lane : nlanes - 1);
+    // WHOLE: block position of this lane and its byte offset from `src`; per chunk both advance by workgroup-uniform steps
+    const int32_t step_blocks = (int32_t)gridDim.x * (NCH == 2 ? 128 : 256);
+    const int32_t step_y = step_blocks / blocks_x, step_x = step_blocks - step_y * blocks_x;       // scalar, once
+    const uint32_t stride32 = (uint32_t)stride;
+    int32_t xx = 0;
+    uint32_t off = 0;
+    auto load_whole = [&](uint32_t o) {
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const uint8_t* p = src + (o + (uint32_t)y * stride32);
+            if (VEC16) {
+                const uint4 v = *reinterpret_cast<const uint4*>(p);
+                w[4 * y] = v.x; w[4 * y + 1] = v.y; w[4 * y + 2] = v.z; w[4 * y + 3] = v.w;
+            } else {
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+                w[4 * y] = q[0]; w[4 * y + 1] = q[1]; w[4 * y + 2] = q[2]; w[4 * y + 3] = q[3];
+            }
+        }
+    };
+    if (WHOLE) {
+        const int32_t l0 = lane < nlanes ? lane : nlanes - 1;
+        const int32_t b0 = (NCH == 2) ? (l0 >> 1) : l0;
+        const int32_t yy = b0 / blocks_x;
+        xx = b0 - yy * blocks_x;
+        off = (uint32_t)yy * 4u * stride32 + (uint32_t)xx * 16u;
+        load_whole(off);
+    } else {
+        load_words45<NCH, VEC16>(w, src, stride, width, height, blocks_x, lane < nlanes ? lane : nlanes - 1);
+    }
     if (threadIdx.x < 16) s_tab[threadIdx.x] = step_weights(threadIdx.x < 8 ? 8 : 6, threadIdx.x & 7);
     __syncthreads();
     const uint32_t ch = (NCH == 2) ? (uint32_t)(threadIdx.x & 1) : 0u;   // byte of the RGBA8 word this lane encodes (the grid step is even)
     const uint32_t sel = 0x0c040c00u + ch * 0x00010001u;          // v_perm: byte ch of the first word | byte ch of the second << 16
     const int32_t step = (int32_t)gridDim.x * 256;
+    const uint32_t off_step = (uint32_t)step_y * 4u * stride32 + (uint32_t)step_x * 16u;
+    const uint32_t off_wrap = 4u * stride32 - (uint32_t)blocks_x * 16u;           // one block row down, blocks_x blocks back
     for (;;) {
         uint32_t P[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) P[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], sel);
         const int32_t cur = lane;
         lane += step;
-        const bool more = (lane - (int32_t)threadIdx.x) < nlanes;         // wave-uniform per workgroup: some lane of the next chunk exists
-        if (more) load_words45<NCH, VEC16>(w, src, stride, width, height, blocks_x, lane < nlanes ? lane : nlanes - 1);
+        const bool more = (lane - (int32_t)threadIdx.x) < nlanes;         // uniform per workgroup: some lane of the next chunk exists
+        if (more) {
+            if (WHOLE) {
+                xx += step_x; off += off_step;
+                if (xx >= blocks_x) { xx -= blocks_x; off += off_wrap; }
+                // lanes past the end (last chunk only) re-read the surface's last block: clamp the offset like the lane index
+                const uint32_t last = (uint32_t)(height / 4 - 1) * 4u * stride32 + (uint32_t)(blocks_x - 1) * 16u;
+                load_whole(lane < nlanes ? off : last);
+            } else {
+                load_words45<NCH, VEC16>(w, src, stride, width, height, blocks_x, lane < nlanes ? lane : nlanes - 1);
+            }
+        }
         const uint2 o = encode_channel(P, s_tab, s_tab + 8, runs);
         if (cur < nlanes) *reinterpret_cast<uint2*>(dst + (int64_t)cur * 8) = o;
         if (!more) break;
@@ -347,8 +390,15 @@ void launch_bc45(const uint8_t* src, int64_t stride, int width, int height, uint
     const uint4* runs = index_table(st);
     const int64_t chunks = (n + 255) / 256;
     const dim3 grid((unsigned)(chunks < BC45_GRID ? chunks : BC45_GRID)), blk(256);
-    if (vec) hipLaunchKernelGGL((bc45_kernel<NCH, true>),  grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst, runs);
-    else     hipLaunchKernelGGL((bc45_kernel<NCH, false>), grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst, runs);
+    // WHOLE: no partial blocks and every texel offset fits 31 bits (a non-negative stride; 16384^2 RGBA8 is 1 GiB)
+    const bool whole = (width % 4 == 0) && (height % 4 == 0) && stride > 0 && (int64_t)height * stride < ((int64_t)1 << 31);
+    if (whole) {
+        if (vec) hipLaunchKernelGGL((bc45_kernel<NCH, true, true>),  grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst, runs);
+        else     hipLaunchKernelGGL((bc45_kernel<NCH, false, true>), grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst, runs);
+    } else {
+        if (vec) hipLaunchKernelGGL((bc45_kernel<NCH, true, false>),  grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst, runs);
+        else     hipLaunchKernelGGL((bc45_kernel<NCH, false, false>), grid, blk, 0, st, src, stride, width, height, bx, (int32_t)n, dst, runs);
+    }
 }
 
 } // namespace

@@ -169,3 +169,29 @@ def test_flat_and_two_level_blocks(itw, gpu, oracle, fmt):
     got = gpu_encode(itw, gpu, fmt, img)
     want = oracle.encode(fmt, img).reshape(-1)
     assert first_mismatch(got, want, 8) is None, first_mismatch(got, want, 8)
+
+
+@pytest.mark.parametrize("fmt", ["bc4", "bc5"])
+def test_whole_surface_walk_with_32_bit_offsets(itw, gpu, oracle, fmt):
+    """Surfaces whose sides are multiples of 4 and that span < 2 GiB take the kernel's WHOLE walk: each lane keeps its block position and
+    a 32-bit byte offset incrementally across the chunks its persistent workgroup visits.  Blocks are independent, so a 16384^2 surface
+    tiled from a 4096^2 one (offsets up to 2^30) must encode to 16 copies of the small surface's stream; a strided view (row stride larger
+    than the row, odd block counts) must equal its contiguous copy; and the small surface equals the oracle."""
+    import torch
+    from itw_amd import surfaces
+    bpb = BPB[fmt]
+    img = surfaces.ldr_smooth(1024, 1024)
+    want = oracle.encode(fmt, img).reshape(-1)
+    base = torch.from_numpy(img).to(gpu)
+    small = itw.compress(fmt, base)
+    torch.cuda.synchronize()
+    assert first_mismatch(small.cpu().numpy(), want, 8) is None
+    big = base.repeat(16, 16, 1).contiguous()                   # 16384 x 16384
+    out = itw.compress(fmt, big).view(4096, 4096, bpb)
+    torch.cuda.synchronize()
+    s2 = small.view(256, 256, bpb)
+    for i in (0, 3, 7, 15):
+        for j in (0, 5, 15):
+            assert torch.equal(out[256 * i:256 * (i + 1), 256 * j:256 * (j + 1)], s2), (i, j)
+    sub = big[8:8 + 4 * 777, 16:16 + 4 * 333]
+    assert torch.equal(itw.compress(fmt, sub), itw.compress(fmt, sub.contiguous()))
