@@ -413,7 +413,28 @@ __device__ __forceinline__ void load_words(uint32_t (&w)[16], const uint8_t* __r
     }
 }
 
-template <bool BC3, bool VEC16>
+// the same from a 32-bit byte offset (SMALL surfaces: every texel below 2 GiB from `src`, stride > 0): the uniform base stays in
+// SGPRs, a lane carries one offset
+template <bool VEC16>
+__device__ __forceinline__ void load_words_at(uint32_t (&w)[16], const uint8_t* __restrict__ src, uint32_t off, uint32_t stride32)
+{
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        const uint8_t* p = src + (off + (uint32_t)y * stride32);
+        if (VEC16) {
+            const uint4 v = *reinterpret_cast<const uint4*>(p);
+            w[4 * y] = v.x; w[4 * y + 1] = v.y; w[4 * y + 2] = v.z; w[4 * y + 3] = v.w;
+        } else {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+            w[4 * y] = q[0]; w[4 * y + 1] = q[1]; w[4 * y + 2] = q[2]; w[4 * y + 3] = q[3];
+        }
+    }
+}
+
+// SMALL (round 4; every surface below 2 GiB with a positive stride): a lane keeps its block's column and 32-bit byte offset and
+// advances them by workgroup-uniform steps from chunk to chunk -- one division per workgroup instead of one per chunk, no 64-bit row
+// pointers (v_mul_hi / v_mad_u64 / v_lshl_add_u64: 120 of the 2 820 issue cycles of a BC1 block-wave).
+template <bool BC3, bool VEC16, bool SMALL>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BC13_WAVES, BC13_WAVES)))
 bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst)
 {
@@ -422,9 +443,24 @@ bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
     // prologue at once, and the HBM round trip of the texels then runs under the 9 KiB table copy instead of after it.
     int32_t base = blockIdx.x * 256;
     uint32_t w[16];
+    const uint32_t stride32 = (uint32_t)stride;
+    const int32_t step_blocks = (int32_t)gridDim.x * 256;
+    const int32_t step_y = step_blocks / blocks_x, step_x = step_blocks - step_y * blocks_x;       // scalar, once
+    const uint32_t off_step = (uint32_t)step_y * 4u * stride32 + (uint32_t)step_x * 16u;
+    const uint32_t off_wrap = 4u * stride32 - (uint32_t)blocks_x * 16u;                            // one block row down, blocks_x blocks back
+    int32_t xx = 0;
+    uint32_t off = 0;
     {
         const int32_t cur = base + threadIdx.x;
-        load_words<VEC16>(w, src, stride, blocks_x, cur < nblocks ? cur : nblocks - 1);
+        const int32_t c0 = cur < nblocks ? cur : nblocks - 1;
+        if (SMALL) {
+            const int32_t yy = c0 / blocks_x;
+            xx = c0 - yy * blocks_x;
+            off = (uint32_t)yy * 4u * stride32 + (uint32_t)xx * 16u;
+            load_words_at<VEC16>(w, src, off, stride32);
+        } else {
+            load_words<VEC16>(w, src, stride, blocks_x, c0);
+        }
     }
     const Bc1Tables B = stage_bc1_tables(s_tables, threadIdx.x, 256);
     __syncthreads();
@@ -449,7 +485,7 @@ bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
             encode_alpha(al, &o[0], B);
             encode_color(px, &o[2], B);
             if (cur < nblocks) {
-                uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)cur * 16);
+                uint32_t* d = reinterpret_cast<uint32_t*>(SMALL ? dst + (uint32_t)cur * 16u : dst + (int64_t)cur * 16);
                 if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(o[0], o[1], o[2], o[3]);
                 else { d[0] = o[0]; d[1] = o[1]; d[2] = o[2]; d[3] = o[3]; }
             }
@@ -457,7 +493,7 @@ bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
             uint32_t o[2];
             encode_color(px, o, B);
             if (cur < nblocks) {
-                uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)cur * 8);
+                uint32_t* d = reinterpret_cast<uint32_t*>(SMALL ? dst + (uint32_t)cur * 8u : dst + (int64_t)cur * 8);
                 if (VEC16) *reinterpret_cast<uint2*>(d) = make_uint2(o[0], o[1]);
                 else { d[0] = o[0]; d[1] = o[1]; }
             }
@@ -465,7 +501,16 @@ bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
         base += gridDim.x * 256;
         if (base >= nblocks) break;                                    // wave-uniform
         const int32_t nxt = base + threadIdx.x;
-        load_words<VEC16>(w, src, stride, blocks_x, nxt < nblocks ? nxt : nblocks - 1);
+        if (SMALL) {
+            xx += step_x; off += off_step;
+            if (xx >= blocks_x) { xx -= blocks_x; off += off_wrap; }
+            // lanes past the end (last chunk only) re-read the last block, like the clamped block index of the general path
+            const int32_t ly = (nblocks - 1) / blocks_x;
+            const uint32_t last = (uint32_t)ly * 4u * stride32 + (uint32_t)(nblocks - 1 - ly * blocks_x) * 16u;
+            load_words_at<VEC16>(w, src, nxt < nblocks ? off : last, stride32);
+        } else {
+            load_words<VEC16>(w, src, stride, blocks_x, nxt < nblocks ? nxt : nblocks - 1);
+        }
     }
 }
 
@@ -478,6 +523,9 @@ static unsigned bc13_grid(int64_t n)
     return (unsigned)(chunks < BC13_GRID ? chunks : BC13_GRID);
 }
 
+// SMALL: positive stride and every texel row below 2 GiB from the base (16384^2 RGBA8 is 1 GiB): 32-bit offsets
+static bool bc13_small(int64_t stride, int height) { return stride > 0 && (int64_t)height * stride < ((int64_t)1 << 31); }
+
 // VEC16 requires: src base and stride multiples of 16, dst multiple of 16 (BC3) / 8 (BC1).
 void launch_bc1(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st)
 {
@@ -486,8 +534,13 @@ void launch_bc1(const uint8_t* src, int64_t stride, int width, int height, uint8
     if (n <= 0) return;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
     const dim3 grid(bc13_grid(n)), blk(256);
-    if (vec) hipLaunchKernelGGL((bc13_kernel<false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
-    else     hipLaunchKernelGGL((bc13_kernel<false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+    if (bc13_small(stride, height)) {
+        if (vec) hipLaunchKernelGGL((bc13_kernel<false, true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+        else     hipLaunchKernelGGL((bc13_kernel<false, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+    } else {
+        if (vec) hipLaunchKernelGGL((bc13_kernel<false, true, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+        else     hipLaunchKernelGGL((bc13_kernel<false, false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+    }
 }
 
 void launch_bc3(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st)
@@ -497,8 +550,13 @@ void launch_bc3(const uint8_t* src, int64_t stride, int width, int height, uint8
     if (n <= 0) return;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const dim3 grid(bc13_grid(n)), blk(256);
-    if (vec) hipLaunchKernelGGL((bc13_kernel<true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
-    else     hipLaunchKernelGGL((bc13_kernel<true, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+    if (bc13_small(stride, height)) {
+        if (vec) hipLaunchKernelGGL((bc13_kernel<true, true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+        else     hipLaunchKernelGGL((bc13_kernel<true, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+    } else {
+        if (vec) hipLaunchKernelGGL((bc13_kernel<true, true, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+        else     hipLaunchKernelGGL((bc13_kernel<true, false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
+    }
 }
 
 } // namespace itw
