@@ -80,6 +80,10 @@ int64_t itwBandForPartEx(int32_t width, int32_t height, int32_t bytes_per_block,
 void itwTestRcp  (const float* d_in, float* d_out, int64_t n);
 void itwTestRsqrt(const float* d_in, float* d_out, int64_t n);
 void itwTestF2I  (const float* d_in, int32_t* d_out, int64_t n);
+/* The bounded BC7 mode order's lower bound (csrc/bc7_exact.hpp two_subset_bound): for every 4x4 block of the device-resident RGBA8
+ * surface, the bound of each of the 64 two-subset shapes, d_out[block * 64 + shape] (device memory, raster block order).  tests/ check it
+ * against the oracle's error of every shape (it must never exceed one) and against its CPU restatement (oracle/bc7_bound.c). */
+void itwTestBc7TwoSubsetBounds(const rgba_surface* d_src, float* d_out);
 
 #ifdef __cplusplus
 }

@@ -702,6 +702,16 @@ int itwTestBc45IndexTable(uint32_t* host_out)
     return itw::guarded([&] { if (!host_out) itw::fail_msg("null pointer"); itw::copy_bc45_index_table(host_out, tls.user_stream); }) ? 0 : -1;
 }
 
+void itwTestBc7TwoSubsetBounds(const rgba_surface* d_src, float* d_out)
+{
+    itwClearError();
+    itw::guarded([&] {
+        if (!d_src || !d_src->ptr || !d_out) itw::fail_msg("null pointer");
+        itw::launch_bc7_test_bounds(d_src->ptr, d_src->stride, d_src->width, d_src->height, d_out, tls.user_stream);
+        ITW_CHECK(hipGetLastError());
+    });
+}
+
 void itwTestRcp(const float* in, float* out, int64_t n)
 {
     if (n <= 0) return;

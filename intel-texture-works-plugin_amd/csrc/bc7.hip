@@ -1359,31 +1359,60 @@ bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, 
     }
 }
 
+// appends block `b` of the lanes with `need` to a list: one atomic per wave, ranks within the wave by ballot (any order: blocks are independent)
+__device__ __forceinline__ void append_to_list(int32_t* __restrict__ list, int32_t* __restrict__ count, bool need, int32_t b)
+{
+    const unsigned long long m = __ballot(need);
+    if (m) {
+        const int lane = (int)(threadIdx.x & 63u);
+        int32_t base = 0;
+        if (lane == 0) base = atomicAdd(count, (int32_t)__popcll(m));
+        base = __shfl(base, 0);
+        if (need) list[base + (int32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
+    }
+}
+
 // PHASE 0: every mode, reference order (RGB profiles).  RGBA profiles run in two phases so that the three-channel modes can be
 // skipped where they cannot win: PHASE 1 = the alpha-capable modes 7,4,5,6 (their relative order kept), leaves the block and
 // its error; PHASE 2 = modes 0,2,1,3 for the waves that still need them, then the reference's choice between the two groups:
 // the first strict minimum over 0,2,1,3,7,4,5,6 is the RGB group's winner iff its error <= the alpha group's.
+//
+// Round 4, the BOUNDED order (profiles that scan every two-subset shape: `slow`, `alpha_slow`): modes 1 and 3 run LAST, and only for the
+// blocks where some two-subset shape's exact lower bound (two_subset_bound, bc7_exact.hpp) is still below what the other modes achieved.
+//   PHASE 3 (RGB profiles)   modes 0,2 then 4,5,6 -> block, and the incumbent `inc` modes 1/3 have to get strictly below: the error,
+//                            + 1 when it belongs to mode 4/5/6 (those come after 1/3 in the reference's order, so a tie goes to 1/3);
+//                            then the list of blocks with min over shapes of the bound < inc;
+//   PHASE 5 (RGBA profiles)  the same on the list PHASE 1 left: modes 0,2, the choice against the alpha group (ties to 0/2), inc, list;
+//   PHASE 4                  modes 1,3 over that list, starting from best_err = inc: the block is replaced iff one of them gets below.
+// The final block is the reference's first strict minimum over 0,2,1,3,7,4,5,6 either way: a mode's result enters only through
+// `err < best_err`, the groups keep their internal order, and a skipped block's modes 1/3 cannot reach inc whatever shape their scan would
+// have picked (every encoding of every shape is bounded).
 #ifndef FINISH_ALL_WAVES
 #define FINISH_ALL_WAVES 2
 #endif
 template <bool VEC16, int PHASE>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FINISH_ALL_WAVES, FINISH_ALL_WAVES)))
 bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst,
-               const uint32_t* __restrict__ wins4, const bc7_enc_settings S, int32_t* __restrict__ alpha_err,
-               int32_t* __restrict__ rgb_list, int32_t* __restrict__ rgb_count)
+               const uint32_t* __restrict__ wins4, const bc7_enc_settings S, int32_t* __restrict__ inc_err,
+               const int32_t* __restrict__ in_list, const int32_t* __restrict__ in_count, int32_t* __restrict__ out_list, int32_t* __restrict__ out_count)
 {
+    constexpr bool LISTED = PHASE == 2 || PHASE == 4 || PHASE == 5;          // walks a compacted list of an earlier phase
+    constexpr bool DO02 = PHASE == 0 || PHASE == 2 || PHASE == 3 || PHASE == 5;
+    constexpr bool DO13 = PHASE == 0 || PHASE == 2 || PHASE == 4;
+    constexpr bool DO7 = PHASE == 0 || PHASE == 1;
+    constexpr bool DO456 = PHASE == 0 || PHASE == 1 || PHASE == 3;
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
     __shared__ uint2 s_pal[(ITW_BC7_LANE_PAL ? LANE_PAL_LEVELS : 8) * TPB];   // refinement: a palette per subset of the lane's winner
-    const int32_t nact = (PHASE == 2) ? *rgb_count : nblocks;        // PHASE 2 walks the compacted list of finish<1>
-    if (PHASE == 2 && (int32_t)(blockIdx.x * TPB) >= nact) return;   // whole workgroup, before any barrier
+    const int32_t nact = LISTED ? *in_count : nblocks;
+    if (LISTED && (int32_t)(blockIdx.x * TPB) >= nact) return;       // whole workgroup, before any barrier
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
     const int32_t gid = blockIdx.x * TPB + threadIdx.x;
     const bool live = gid < nact;
     const int32_t slot = live ? gid : nact - 1;
-    const int32_t b = (PHASE == 2) ? rgb_list[slot] : slot;
+    const int32_t b = LISTED ? in_list[slot] : slot;
     ln.keys = nullptr;
     ln.pal = s_pal + threadIdx.x;
     load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
@@ -1399,39 +1428,54 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
     }
     const bool on13 = S.mode_selection[1];
     int32_t e_alpha = ERR_MAX;
-    if (PHASE == 2) e_alpha = alpha_err[b];                  // every listed block has opaque_err <= e_alpha: its winners exist
+    if (PHASE == 2 || PHASE == 5) e_alpha = inc_err[b];      // every listed block has opaque_err <= e_alpha: its winners exist
+    if (PHASE == 4) ln.best_err = inc_err[b];                // what modes 1/3 have to get strictly below
     Win w;
-    if (PHASE != 1) {
-        if (S.mode_selection[0]) {
-            unpack_win(w, wins4[(int64_t)wide_win_slot(0) * nblocks + b]);
-            refine_and_commit<0>(ln, w, S.refineIterations[0], S.channels);
-            if (!S.skip_mode2) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(2) * nblocks + b]); refine_and_commit<2>(ln, w, S.refineIterations[2], S.channels); }
-        }
+    if (DO02 && S.mode_selection[0]) {
+        unpack_win(w, wins4[(int64_t)wide_win_slot(0) * nblocks + b]);
+        refine_and_commit<0>(ln, w, S.refineIterations[0], S.channels);
+        if (!S.skip_mode2) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(2) * nblocks + b]); refine_and_commit<2>(ln, w, S.refineIterations[2], S.channels); }
+    }
+    const int32_t e02 = ln.best_err;
+    if (DO13) {
         if (on13 && S.fastSkipTreshold_mode1 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(1) * nblocks + b]); refine_and_commit<1>(ln, w, S.refineIterations[1], S.channels); }
         if (on13 && S.fastSkipTreshold_mode3 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(3) * nblocks + b]); refine_and_commit<3>(ln, w, S.refineIterations[3], S.channels); }
     }
-    if (PHASE != 2) {
-        if (on13 && S.fastSkipTreshold_mode7 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(7) * nblocks + b]); refine_and_commit<7>(ln, w, S.refineIterations[7], S.channels); }
+    if (DO7 && on13 && S.fastSkipTreshold_mode7 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(7) * nblocks + b]); refine_and_commit<7>(ln, w, S.refineIterations[7], S.channels); }
+    if (DO456) {
         ln.tx.fence();
         if (S.mode_selection[2]) modes_45(ln, S);
         if (S.mode_selection[3]) { if (S.channels == 4) mode_6<4>(ln, S); else mode_6<3>(ln, S); }
     }
     if (PHASE == 1) {
-        if (live) alpha_err[b] = ln.best_err;
+        if (live) inc_err[b] = ln.best_err;
         // the blocks where a three-channel mode can still win or tie (its error carries sum (255 - a)^2): appended to the list the
         // RGB scans and finish<2> walk -- one atomic per wave, ranks within the wave by ballot
-        const bool need = live && ln.opaque_err <= ln.best_err;
-        const unsigned long long m = __ballot(need);
-        if (m) {
-            const int lane = (int)(threadIdx.x & 63u);
-            int32_t base = 0;
-            if (lane == 0) base = atomicAdd(rgb_count, (int32_t)__popcll(m));
-            base = __shfl(base, 0);
-            if (need) rgb_list[base + (int32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
-        }
+        append_to_list(out_list, out_count, live && ln.opaque_err <= ln.best_err, b);
     }
-    if (PHASE == 2 && !(ln.best_err <= e_alpha)) return;     // the alpha group's block stands (ties go to the earlier, RGB, group)
-    if (live) {
+    if (PHASE == 3 || PHASE == 5) {
+        // incumbent of modes 1/3 (see the header), then the blocks whose modes 1/3 can still get below it
+        int32_t inc;
+        if (PHASE == 3) inc = ln.best_err + (ln.best_err < e02 ? 1 : 0);
+        else            inc = (e02 <= e_alpha) ? e02 : e_alpha + 1;
+        if (live) inc_err[b] = inc;
+        ln.tx.fence();
+        IStats<3> full;
+        stats_int<3>(full, ln.tx.pl, whole_block());
+        const float lim = (float)(inc - ln.opaque_err) - 0.5f;      // errors are integers: a bound above inc - 1 already rules the shape out
+        bool need = !live;                                           // idle lanes never hold the loop up
+#pragma unroll 1
+        for (int shape = 0; shape < 64; shape++) {
+            if (__all(need)) break;
+            const float lb = two_subset_bound(shape, ln.tx.pl, full);
+            need = need || !(lb >= lim);
+        }
+        append_to_list(out_list, out_count, live && need, b);
+    }
+    bool store = live;
+    if (PHASE == 2 || PHASE == 5) store = store && ln.best_err <= e_alpha;   // else the alpha group's block stands (ties go to the earlier, RGB, group)
+    if (PHASE == 4) store = store && ln.improved;
+    if (store) {
         uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
         if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(ln.best[0], ln.best[1], ln.best[2], ln.best[3]);
         else { d[0] = ln.best[0]; d[1] = ln.best[1]; d[2] = ln.best[2]; d[3] = ln.best[3]; }
@@ -1681,6 +1725,33 @@ static void launch_finish(Bc7Launch& L)
 
 // 0 = by size, 1 = deep always, 2 = wide whenever it supports the settings (itwSetBc7Path / ITW_BC7_PATH=deep|wide:
 // tests and probes)
+// test hook (itwTestBc7TwoSubsetBounds): two_subset_bound of every two-subset shape of every block, out[block * 64 + shape]
+template <bool VEC16>
+__global__ void __launch_bounds__(TPB) bc7_test_bounds(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, float* __restrict__ out)
+{
+    const int32_t gid = blockIdx.x * TPB + threadIdx.x;
+    const int32_t b = gid < nblocks ? gid : nblocks - 1;
+    Tex tx;
+    load_block<VEC16>(tx, src, stride, blocks_x, b);
+    IStats<3> full;
+    stats_int<3>(full, tx.pl, whole_block());
+#pragma unroll 1
+    for (int shape = 0; shape < 64; shape++) {
+        const float lb = two_subset_bound(shape, tx.pl, full);
+        if (gid < nblocks) out[(int64_t)b * 64 + shape] = lb;
+    }
+}
+void launch_bc7_test_bounds(const uint8_t* src, int64_t stride, int width, int height, float* out, hipStream_t st)
+{
+    const int bx = width / 4;
+    const int64_t n = (int64_t)bx * (height / 4);
+    if (n <= 0) return;
+    const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 15) == 0;
+    const dim3 grid((unsigned)((n + TPB - 1) / TPB));
+    if (vec) hipLaunchKernelGGL((bc7_test_bounds<true>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, out);
+    else     hipLaunchKernelGGL((bc7_test_bounds<false>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, out);
+}
+
 static std::atomic<int> g_bc7_path{-1};
 static int bc7_path_override()
 {
@@ -1696,6 +1767,12 @@ void set_bc7_path(int v) { g_bc7_path.store(v == 1 || v == 2 ? v : 0, std::memor
 
 // RGBA profile with both groups of modes: the fused shape runs the alpha-capable modes first and skips the three-channel
 // modes where they cannot win (bc7_finish_all).  ITW_BC7_ALPHA_PRUNE=0: always the reference's order.
+// ITW_BC7_BOUND=0: modes 1/3 in the reference's place instead of last-and-bounded (same bytes; tools/gpu_env_matrix.sh runs both)
+static bool bc7_bounded_order()
+{
+    static const bool on = [] { const char* e = std::getenv("ITW_BC7_BOUND"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static bool bc7_alpha_first(const bc7_enc_settings& S)
 {
     static const bool on = [] { const char* e = std::getenv("ITW_BC7_ALPHA_PRUNE"); return !(e && e[0] == '0'); }();
@@ -1740,7 +1817,9 @@ static size_t wide_workspace_bytes(size_t n)
 size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks)
 {
     const size_t n = (size_t)(width / 4) * (size_t)(height / 4);
-    const size_t deep = ((n * sizeof(int32_t) + 15) & ~(size_t)15) + 2 * n * sizeof(uint4);
+    size_t deep = ((n * sizeof(int32_t) + 15) & ~(size_t)15) + 2 * n * sizeof(uint4);
+    const size_t fused = (size_t)8 * n * sizeof(int32_t) + 2 * sizeof(int32_t);     // 5 winner rows, incumbents, two block lists + their lengths
+    if (fused > deep) deep = fused;
     const size_t limit = bc7_path_override() == 2 ? ((size_t)1 << 20) : (wide_max_blocks > 0 ? (size_t)wide_max_blocks : (size_t)ITW_BC7_WIDE_MAX_BLOCKS);
     const bool may_wide = bc7_path_override() != 1 && n <= limit && n <= ((size_t)1 << 20);
     const size_t wide = may_wide ? wide_workspace_bytes(n) : 0;
@@ -1881,15 +1960,17 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             if (grain > chunks8) grain = chunks8;
             const int32_t groups = (chunks8 + grain - 1) / grain;
             const int a13 = r13 ? 1 : 0, a7 = r7 ? 1 : 0;
-            int32_t* alpha_err = reinterpret_cast<int32_t*>(wins4 + (size_t)5 * n);            // [n] x 4 B behind the winner rows
-            int32_t* rgb_list = alpha_err + n;                                                 // [n] block ids + their count (RGBA profiles)
-            int32_t* rgb_count = rgb_list + n;
+            int32_t* alpha_err = reinterpret_cast<int32_t*>(wins4 + (size_t)5 * n);            // [n] x 4 B behind the winner rows: a phase's error / incumbent
+            int32_t* rgb_list = alpha_err + n;                                                 // [n] block ids (RGBA profiles: where an RGB mode can win; RGB: where modes 1/3 can)
+            int32_t* list13 = rgb_list + n;                                                    // [n] block ids (RGBA profiles, bounded order)
+            int32_t* rgb_count = list13 + n;                                                   // the two lists' lengths
+            int32_t* count13 = rgb_count + 1;
             const dim3 blk(TPB);
-            auto scan_rgb = [&](const int32_t* list, const int32_t* count) {
+            auto scan_rgb = [&](const int32_t* list, const int32_t* count, bool do13, bool do02) {
                 ScanTasks T;
                 T.n = 0;
-                if (on13) T.kind[T.n++] = WK_SCAN13;                           // longest first
-                if (on02) T.kind[T.n++] = WK_SCAN02;
+                if (on13 && do13) T.kind[T.n++] = WK_SCAN13;                   // longest first
+                if (on02 && do02) T.kind[T.n++] = WK_SCAN02;
                 if (T.n == 0) return;
                 const dim3 grid((unsigned)(groups * grain * T.n));
                 if (r13) {
@@ -1913,21 +1994,37 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                     else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr, nullptr);
                 }
             };
-            auto finish = [&](auto phase) {
+            auto finish = [&](auto phase, const int32_t* in_list, const int32_t* in_count, int32_t* out_list, int32_t* out_count) {
                 constexpr int PH = decltype(phase)::value;
-                if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true, PH>),  L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, rgb_list, rgb_count);
-                else       hipLaunchKernelGGL((bc7_finish_all<false, PH>), L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, rgb_list, rgb_count);
+                if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true, PH>),  L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, in_list, in_count, out_list, out_count);
+                else       hipLaunchKernelGGL((bc7_finish_all<false, PH>), L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, in_list, in_count, out_list, out_count);
             };
+            // the bounded order (bc7_finish_all's header): profiles whose modes 1/3 scan every shape -- a ranked list already spends
+            // a bound's worth of arithmetic per shape on its keys and then fits a few shapes only
+            const bool bounded = bc7_bounded_order() && on02 && on13 && !r13;
             if (bc7_alpha_first(S)) {
-                ITW_CHECK(hipMemsetAsync(rgb_count, 0, sizeof(int32_t), st));      // finish<1> appends to the list through it
+                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 2 * sizeof(int32_t), st));  // finish<1> / finish<5> append to the lists through them
                 scan_7();
-                finish(std::integral_constant<int, 1>{});
-                scan_rgb(rgb_list, rgb_count);
-                finish(std::integral_constant<int, 2>{});
+                finish(std::integral_constant<int, 1>{}, nullptr, nullptr, rgb_list, rgb_count);
+                if (bounded) {
+                    scan_rgb(rgb_list, rgb_count, false, true);
+                    finish(std::integral_constant<int, 5>{}, rgb_list, rgb_count, list13, count13);
+                    scan_rgb(list13, count13, true, false);
+                    finish(std::integral_constant<int, 4>{}, list13, count13, nullptr, nullptr);
+                } else {
+                    scan_rgb(rgb_list, rgb_count, true, true);
+                    finish(std::integral_constant<int, 2>{}, rgb_list, rgb_count, nullptr, nullptr);
+                }
+            } else if (bounded && !on7) {
+                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 2 * sizeof(int32_t), st));
+                scan_rgb(nullptr, nullptr, false, true);
+                finish(std::integral_constant<int, 3>{}, nullptr, nullptr, list13, count13);
+                scan_rgb(list13, count13, true, false);
+                finish(std::integral_constant<int, 4>{}, list13, count13, nullptr, nullptr);
             } else {
-                scan_rgb(nullptr, nullptr);
+                scan_rgb(nullptr, nullptr, true, true);
                 scan_7();
-                finish(std::integral_constant<int, 0>{});
+                finish(std::integral_constant<int, 0>{}, nullptr, nullptr, nullptr, nullptr);
             }
             return;
         }

@@ -167,6 +167,57 @@ __device__ __forceinline__ void stats_sub(IStats<CH>& a, const IStats<CH>& b)   
     a.n -= b.n;
 }
 
+// ---- an exact LOWER BOUND of every two-subset encoding of a block (round 4: the bounded mode order, bc7.hip) ----------------
+// Whatever endpoints a mode 1 / 3 encoding of a shape ends with (first fit or any refinement), each subset decodes to ROUNDED points of
+// one segment: level = floor(L + 1/2) per channel with L on the segment between the two integer endpoints (kernel.ispc:1164-1170).  So a
+// texel's error is >= (dist(texel, line) - sqrt(3)/2)_+^2, a subset's error is >= (sqrt(R) - sqrt(3)/2 sqrt(n))_+^2 with R = the sum of
+// squared distances of its texels to their best line = trace - largest eigenvalue of the subset's scatter matrix, and the shape's error is
+// the sum over its subsets (plus sum (255 - alpha)^2 under an RGBA profile).  The largest eigenvalue is bounded from ABOVE by
+// ||M^4||_F^(1/4) (M = n x scatter as exact integers, scaled by 1 / trace so that nothing overflows or underflows), and every float
+// rounding below is covered by a margin of 1e-5 of the trace: the value returned never exceeds the true bound.  CPU restatement and its
+// check against part_fast's error of every shape: oracle/bc7_bound.c, tests/test_bc7_bound.py.
+__device__ const float BOUND_SLACK3[17] = {     // sqrt(3)/2 sqrt(n), rounded up
+    0.f, 0.866026282f, 1.22474611f, 1.50000155f, 1.73205256f, 1.93649364f, 2.12132239f, 2.29129004f, 2.44949222f, 2.59807873f,
+    2.73861551f, 2.87228417f, 3.0000031f, 3.12250209f, 3.24037361f, 3.35410523f, 3.46410513f};
+
+// n x (residual of the subset about its best line), from below; >= 0
+__device__ __forceinline__ float subset_residual_bound(const IStats<3>& st)
+{
+    const int32_t n = st.n;
+    // n x scatter matrix: n sum(xy) - sum(x) sum(y) <= 16 x 1 040 400 < 2^24: exact integers, exact as floats
+    const int32_t c00 = n * st.m[0] - st.s[0] * st.s[0], c01 = n * st.m[1] - st.s[0] * st.s[1], c02 = n * st.m[2] - st.s[0] * st.s[2];
+    const int32_t c11 = n * st.m[4] - st.s[1] * st.s[1], c12 = n * st.m[5] - st.s[1] * st.s[2], c22 = n * st.m[7] - st.s[2] * st.s[2];
+    const float t = (float)(c00 + c11 + c22);
+    const float inv = __builtin_amdgcn_rcpf(fmaxf(t, 1.0f));
+    const float a = (float)c00 * inv, b = (float)c01 * inv, c = (float)c02 * inv, d = (float)c11 * inv, e = (float)c12 * inv, f = (float)c22 * inv;
+    // M^2, then M^4 (symmetric: six entries each)
+    const float bb = b * b, cc = c * c, ee = e * e;
+    const float A = a * a + bb + cc, B = a * b + b * d + c * e, C = a * c + b * e + c * f;
+    const float D = bb + d * d + ee, E = b * c + d * e + e * f, F = cc + ee + f * f;
+    const float BB = B * B, CC = C * C, EE = E * E;
+    const float A2 = A * A + BB + CC, B2 = A * B + B * D + C * E, C2 = A * C + B * E + C * F;
+    const float D2 = BB + D * D + EE, E2 = B * C + D * E + E * F, F2 = CC + EE + F * F;
+    const float off = B2 * B2 + C2 * C2 + E2 * E2;
+    const float fro2 = (A2 * A2 + D2 * D2 + F2 * F2) + (off + off);
+    const float lam = __builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(__builtin_amdgcn_sqrtf(fro2)));     // >= largest eigenvalue / trace
+    const float r = ((a + d + f) - lam) - 1e-5f;
+    return fmaxf(r, 0.0f) * t;
+}
+
+// lower bound of the error of any mode 1 / 3 encoding of two-subset shape `shape` (wave-uniform), without the opaque term
+__device__ __forceinline__ float two_subset_bound(int shape, const uint32_t (&pl)[4][4], const IStats<3>& full)
+{
+    const SubsetMask sm = subset_of(shape, 0);
+    IStats<3> s0, s1 = full;
+    stats_int<3>(s0, pl, sm);
+    stats_sub<3>(s1, s0);
+    // rcp_of_count(n) lies just below 1 / n; v_sqrt_f32 is good to 1 ulp: the factor below covers it
+    const float d0 = __builtin_amdgcn_sqrtf(subset_residual_bound(s0) * rcp_of_count(s0.n)) * 0.999999f - BOUND_SLACK3[s0.n];
+    const float d1 = __builtin_amdgcn_sqrtf(subset_residual_bound(s1) * rcp_of_count(s1.n)) * 0.999999f - BOUND_SLACK3[s1.n];
+    const float e0 = fmaxf(d0, 0.0f), e1 = fmaxf(d1, 0.0f);
+    return (e0 * e0 + e1 * e1) * 0.999999f;
+}
+
 template <int CH>
 __device__ __forceinline__ void stats_float(Stats<CH>& f, const IStats<CH>& st)
 {

@@ -27,6 +27,8 @@ void set_bc7_path(int path);
 struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; };   // wide_max_blocks: 0 = the library default
 void launch_bc7 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                  const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux = nullptr);
+// test hook: bc7_exact.hpp's two_subset_bound of all 64 two-subset shapes of every block, out[block * 64 + shape] (device memory)
+void launch_bc7_test_bounds(const uint8_t* src, int64_t stride, int width, int height, float* out, hipStream_t st);
 // `workspace`: device memory of bc6h_workspace_bytes(width, height, s) bytes (0 for most calls: only small calls of the slow
 // profiles, which take the wide shape, need any); nullptr keeps the one-kernel path.
 size_t bc6h_workspace_bytes(int width, int height, const bc6h_enc_settings& s);

@@ -17,7 +17,7 @@ EXPORTED_SYMBOLS = tuple(
     + ["GetProfile_" + p for p in BC7_PROFILES] + ["GetProfile_bc6h_" + p for p in BC6H_PROFILES]
     + ["itwSetStream", "itwGetStream", "itwAvailable", "itwSetErrorMode", "itwLastError", "itwClearError", "itwSetBc7Path",
        "itwDeviceInfo", "itwVersion", "itwBandForPart", "itwBandForPartEx",
-       "itwTestRcp", "itwTestRsqrt", "itwTestF2I"]
+       "itwTestRcp", "itwTestRsqrt", "itwTestF2I", "itwTestBc7TwoSubsetBounds"]
     # include/itw_dispatch.h: the reference's dispatch layer (win32Threads.h), slice loop, pad pre-pass
     + ["GetProcessorCount", "InitWin32Threads", "DestroyThreads", "GetBytesPerBlock", "CompressImageMT", "CompressImageST",
        "CompressImageBC1", "CompressImageBC3", "CompressImageBC4", "CompressImageBC5"]
@@ -141,6 +141,8 @@ def lib():
         for n in ("itwTestRcp", "itwTestRsqrt", "itwTestF2I"):
             getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
             getattr(L, n).restype = None
+        L.itwTestBc7TwoSubsetBounds.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
+        L.itwTestBc7TwoSubsetBounds.restype = None
         # dispatch layer (itw_dispatch.h)
         L.GetProcessorCount.restype = C.c_int
         L.GetBytesPerBlock.argtypes = [C.c_int]
@@ -324,6 +326,24 @@ def compress(fmt, img, settings=None, out=None):
         L.itwSetStream(torch.cuda.current_stream(img.device).cuda_stream)
         surf = RgbaSurface(img.data_ptr(), w, h, img.stride(0) * es)
         _call(fmt, surf, out.data_ptr(), settings)
+    return out
+
+
+def bc7_two_subset_bounds(img):
+    """Test hook: the bounded BC7 mode order's lower bound of each two-subset shape (itwTestBc7TwoSubsetBounds).
+    img: CUDA tensor (H, W, 4) uint8 -> float32 CUDA tensor (blocks, 64), raster block order."""
+    import torch
+    assert img.is_cuda and img.dim() == 3 and img.shape[2] == 4 and img.element_size() == 1
+    assert img.stride(2) == 1 and img.stride(1) == 4
+    h, w = img.shape[:2]
+    out = torch.empty(((h // 4) * (w // 4), 64), dtype=torch.float32, device=img.device)
+    L = lib()
+    with torch.cuda.device(img.device):
+        L.itwSetStream(torch.cuda.current_stream(img.device).cuda_stream)
+        surf = RgbaSurface(img.data_ptr(), w, h, img.stride(0))
+        L.itwTestBc7TwoSubsetBounds(C.byref(surf), out.data_ptr())
+    if last_error():
+        raise RuntimeError(last_error())
     return out
 
 

@@ -1158,6 +1158,29 @@ void oracle_bc7_block(const float block[64], const oracle_bc7_settings* settings
     if (best_err) *best_err = state.best_err;
 }
 
+/* Study hook (tools/variants/bc7_bound_study.py, tests): bc7_enc_mode01237_part_fast's error for every shape of one mode, and the
+ * sort key bc7_enc_mode13 / mode7 order the shapes by (kernel.ispc:1403-1410; 0..63 for modes 0 / 2). */
+void oracle_bc7_part_fast_errors(const float block[64], int mode, float err[64], int32_t key[64])
+{
+    const int pairs = (mode == 0 || mode == 2) ? 3 : 2;
+    const int channels = mode == 7 ? 4 : 3;
+    const int count = mode == 0 ? 16 : 64;
+    float full_stats[15];
+    compute_stats_masked(full_stats, block, -1, channels);
+    for (int part = 0; part < 64; part++) {
+        err[part] = -1.0f;
+        key[part] = part;
+        if (pairs == 2) {
+            float bound12 = block_pca_bound_split(block, get_pattern_mask(part, 0), full_stats, channels);
+            key[part] = (int32_t)((uint32_t)part + (uint32_t)f2i_x86(bound12) * 64u);
+        }
+        if (part >= count) continue;
+        int32_t qep[24];
+        uint32_t qblock[2];
+        err[part] = bc7_enc_mode01237_part_fast(qep, qblock, block, part + (pairs == 3 ? 64 : 0), mode);
+    }
+}
+
 /* kernel.ispc:2014-2037 */
 void oracle_CompressBlocksBC7(const oracle_surface* src, uint8_t* dst, const oracle_bc7_settings* settings)
 {

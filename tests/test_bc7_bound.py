@@ -1,0 +1,160 @@
+"""The bounded BC7 mode order rests on ONE property: for every block and every two-subset shape, two_subset_bound(shape) never exceeds the
+error of any mode 1 / 3 encoding of that shape.  CPU side: the bound's restatement (oracle/bc7_bound.c, the same float operations as
+csrc/bc7_exact.hpp) against the oracle's own errors -- bc7_enc_mode01237_part_fast for every shape (kernel.ispc:1279-1297), the refined
+result of a modes-1/3-only encode (:1329-1362), and brute-force palettes from arbitrary endpoints.  The device function is compared with
+the restatement in tests/test_gpu_bc7_bound.py."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "intel-texture-works-plugin_amd"))
+from oracle import pyoracle  # noqa: E402
+from itw_amd import surfaces  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def planar_blocks(img):
+    h, w = img.shape[0] // 4 * 4, img.shape[1] // 4 * 4
+    t = img[:h, :w].astype(np.float32).reshape(h // 4, 4, w // 4, 4, 4).transpose(0, 2, 4, 1, 3).reshape(-1, 64)   # [block][16 c + k]
+    return np.ascontiguousarray(t)
+
+
+def adversarial_blocks(rng):
+    """flat, two-level, checkerboards, extreme contrast, single outliers, noise of several amplitudes, ramps"""
+    out = []
+    for v in (0, 1, 127, 254, 255):
+        out.append(np.full((4, 4, 4), v, np.uint8))
+    for a, b in ((0, 255), (0, 1), (100, 101), (17, 240)):
+        c = np.zeros((4, 4, 4), np.uint8)
+        c[...] = a
+        c[::2, ::2] = b
+        c[1::2, 1::2] = b
+        out.append(c)
+        c = np.full((4, 4, 4), a, np.uint8)
+        c[2, 3] = b
+        out.append(c)
+        c = np.full((4, 4, 4), a, np.uint8)
+        c[:, 2:] = b
+        out.append(c)
+        c = np.full((4, 4, 4), a, np.uint8)
+        c[:2, :, 0] = b
+        c[:, :2, 1] = b
+        c[::2, :, 2] = b
+        out.append(c)
+    for amp in (1, 2, 4, 16, 64, 255):
+        for _ in range(40):
+            base = rng.integers(0, 256, 3)
+            c = np.clip(base[None, None, :] + rng.integers(-amp, amp + 1, (4, 4, 3)), 0, 255).astype(np.uint8)
+            out.append(np.concatenate([c, np.full((4, 4, 1), 255, np.uint8)], axis=2))
+    for _ in range(40):
+        g = np.linspace(0, 1, 4)
+        d0, d1 = rng.integers(-80, 81, 3), rng.integers(-80, 81, 3)
+        c = rng.integers(60, 196, 3)[None, None, :] + g[:, None, None] * d0[None, None, :] + g[None, :, None] * d1[None, None, :] + rng.normal(0, 3, (4, 4, 3))
+        out.append(np.concatenate([np.clip(c, 0, 255).astype(np.uint8), np.full((4, 4, 1), 255, np.uint8)], axis=2))
+    for step, d in ((17, (1, 1, 1)), (17, (1, 0, 0)), (8, (1, 2, 0)), (5, (3, 1, 2)), (1, (1, 1, 0)), (17, (1, -1, 0))):
+        # exactly collinear texels (residual 0, large trace): the bound has to come out as 0, not as rounding noise
+        k = np.arange(16).reshape(4, 4, 1) * step
+        c = np.clip(np.where(np.array(d) < 0, 255, 0)[None, None, :] + k * np.array(d)[None, None, :], 0, 255)
+        for perm in range(3):
+            cc = rng.permuted(c.reshape(16, 3), axis=0).reshape(4, 4, 3) if perm else c
+            out.append(np.concatenate([cc.astype(np.uint8), np.full((4, 4, 1), 255, np.uint8)], axis=2))
+    img = np.concatenate(out, axis=1)
+    return np.ascontiguousarray(img)
+
+
+def sample_images():
+    rng = np.random.default_rng(20260927)
+    z = np.load(os.path.join(GOLDEN, "inputs.npz"))
+    z2 = np.load(os.path.join(GOLDEN, "samples2.npz"))
+    yield "adversarial", adversarial_blocks(rng)
+    yield "ldr_smooth", surfaces.ldr_smooth(128, 128)
+    yield "baboon", np.ascontiguousarray(z["baboon"][64:160, 64:160])
+    yield "monkey", np.ascontiguousarray(z["monkey"][40:104, 40:104])
+    yield "edge_cases", z["edge_cases"]
+    yield "colors260k", np.ascontiguousarray(z2["colors260k"][:64, :64])
+    yield "normals", np.ascontiguousarray(z2["normals"][96:160, 96:160])
+    yield "landscape", np.ascontiguousarray(z2["landscape_detail"][:96, :96])
+
+
+def lib():
+    L = pyoracle.lib()
+    L.oracle_bc7_two_subset_bound.argtypes = [C.c_void_p, C.c_int]
+    L.oracle_bc7_two_subset_bound.restype = C.c_float
+    L.oracle_bc7_part_fast_errors.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.oracle_bc7_part_fast_errors.restype = None
+    return L
+
+
+def bounds_of(L, block):
+    return np.array([L.oracle_bc7_two_subset_bound(block.ctypes.data, p) for p in range(64)], dtype=np.float64)
+
+
+@pytest.mark.parametrize("name,img", list(sample_images()), ids=[n for n, _ in sample_images()])
+def test_bound_never_exceeds_the_oracles_error_of_any_shape(name, img):
+    L = lib()
+    blocks = planar_blocks(img)
+    err = np.zeros(64, np.float32)
+    key = np.zeros(64, np.int32)
+    only13 = pyoracle.bc7_profile("slow")
+    only13.mode_selection[0] = 0; only13.mode_selection[2] = 0; only13.mode_selection[3] = 0
+    data = (C.c_uint32 * 4)()
+    e = C.c_float()
+    L.oracle_bc7_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_bc7_block.restype = None
+    tight = 0
+    for b in range(blocks.shape[0]):
+        lb = bounds_of(L, blocks[b])
+        assert (lb >= 0).all() and np.isfinite(lb).all()
+        for mode in (1, 3):
+            L.oracle_bc7_part_fast_errors(blocks[b].ctypes.data, mode, err.ctypes.data, key.ctypes.data)
+            assert (lb <= err.astype(np.float64)).all(), (name, b, mode, int(np.argmax(lb - err)), float((lb - err).max()))
+        # the refined winner of a modes-1/3-only encode is an encoding of SOME shape: it cannot get below the smallest bound
+        L.oracle_bc7_block(blocks[b].ctypes.data, C.byref(only13), data, C.byref(e))
+        assert lb.min() <= e.value, (name, b, float(lb.min()), e.value)
+        tight += lb.min() > 0.5 * e.value
+    assert blocks.shape[0] > 0
+    if name == "ldr_smooth":
+        assert tight > 0.5 * blocks.shape[0]          # on noisy content the bound is within a factor of two of what the modes achieve
+
+
+def test_bound_never_exceeds_brute_force_palettes_from_arbitrary_endpoints():
+    """any integer endpoints, both index widths, best level per texel: still above the bound (the property needs no optimality)"""
+    rng = np.random.default_rng(7)
+    L = lib()
+    weights = {2: np.array([0, 21, 43, 64]), 3: np.array([0, 9, 18, 27, 37, 46, 55, 64])}
+    import re
+    t = open(os.path.join(ROOT, "oracle", "bc7_tables.h")).read()
+    m = re.search(r"BCN_SUBSET_MASKS\[128\]\s*=\s*\{([^}]*)\}", t)
+    masks = [int(x, 16) & 0xffff for x in re.findall(r"0x([0-9a-fA-F]+)u", m.group(1))][:64]
+    img = np.concatenate([adversarial_blocks(rng)[:, :400], surfaces.ldr_smooth(4, 400)], axis=1)
+    blocks = planar_blocks(img)
+    worst = np.inf
+    for b in range(blocks.shape[0]):
+        lb = bounds_of(L, blocks[b])
+        tex = blocks[b].reshape(4, 16)[:3].T.astype(np.int64)              # [texel][rgb]
+        for shape in rng.choice(64, 6, replace=False):
+            in0 = np.array([(masks[shape] >> k) & 1 for k in range(16)], bool)
+            for bits in (2, 3):
+                for trial in range(6):
+                    total = 0
+                    for sel in (in0, ~in0):
+                        pts = tex[sel]
+                        if trial < 3:                                      # endpoints near the subset's own extremes: the competitive ones
+                            a = pts[rng.integers(len(pts))] + rng.integers(-3, 4, 3)
+                            c = pts[rng.integers(len(pts))] + rng.integers(-3, 4, 3)
+                        else:
+                            a, c = rng.integers(0, 256, 3), rng.integers(0, 256, 3)
+                        a, c = np.clip(a, 0, 255), np.clip(c, 0, 255)
+                        w = weights[bits][:, None]
+                        pal = ((64 - w) * a[None, :] + w * c[None, :] + 32) >> 6
+                        d = ((pts[:, None, :] - pal[None, :, :]) ** 2).sum(axis=2).min(axis=1)
+                        total += int(d.sum())
+                    assert lb[shape] <= total, (b, shape, bits, trial, lb[shape], total)
+                    worst = min(worst, total - lb[shape])
+    assert worst >= 0

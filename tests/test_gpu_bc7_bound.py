@@ -1,0 +1,90 @@
+"""The device side of the bounded BC7 mode order (csrc/bc7.hip bc7_finish_all phases 3-5, csrc/bc7_exact.hpp two_subset_bound):
+the bound as the GPU computes it never exceeds the oracle's error of any shape (kernel.ispc:1279-1297) and agrees with its CPU
+restatement (oracle/bc7_bound.c); content built to hit the order's tie rules encodes to the oracle's bytes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import first_mismatch
+from test_bc7_bound import sample_images, planar_blocks, lib as oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,img", list(sample_images()), ids=[n for n, _ in sample_images()])
+def test_device_bound_is_below_every_oracle_error_and_matches_its_restatement(itw, gpu, name, img):
+    import torch
+    h, w = img.shape[0] // 4 * 4, img.shape[1] // 4 * 4
+    img = np.ascontiguousarray(img[:h, :w])
+    got = itw.bc7_two_subset_bounds(torch.from_numpy(img).to(gpu)).cpu().numpy().astype(np.float64)
+    L = oracle_lib()
+    blocks = planar_blocks(img)
+    assert got.shape == (blocks.shape[0], 64)
+    err = np.zeros(64, np.float32)
+    key = np.zeros(64, np.int32)
+    for b in range(blocks.shape[0]):
+        cpu = np.array([L.oracle_bc7_two_subset_bound(blocks[b].ctypes.data, p) for p in range(64)], dtype=np.float64)
+        # v_rcp_f32 / v_sqrt_f32 against 1/x / sqrtf, and rcp-of-count constants against 1/n: a few ulp, far inside the bound's margins
+        assert np.allclose(got[b], cpu, rtol=2e-4, atol=0.02), (name, b, int(np.argmax(np.abs(got[b] - cpu))), got[b].max(), cpu.max())
+        for mode in (1, 3):
+            L.oracle_bc7_part_fast_errors(blocks[b].ctypes.data, mode, err.ctypes.data, key.ctypes.data)
+            assert (got[b] <= err.astype(np.float64)).all(), (name, b, mode, float((got[b] - err).max()))
+
+
+def _encode(itw, gpu, img, prof):
+    import torch
+    out = itw.compress("bc7", torch.from_numpy(img).to(gpu), prof)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.fixture
+def deep(itw):
+    itw.set_bc7_path("deep")            # the fused shape (whole surfaces): where the bounded order lives
+    yield
+    itw.set_bc7_path("auto")
+
+
+@pytest.mark.parametrize("prof", ["slow", "alpha_slow"])
+def test_bounded_order_tie_rules(itw, gpu, oracle, deep, prof):
+    """Few-level content: many blocks reach the same error (often 0) in several modes, so who keeps the block is decided by the
+    reference's order 0,2,1,3,7,4,5,6 with strict `<` -- modes 1/3 must lose ties against 0/2 and win them against 4/5/6/7."""
+    from itw_amd import surfaces
+    rng = np.random.default_rng(11)
+    tiles = []
+    for levels in (2, 3, 4, 8):
+        base = surfaces.ldr_smooth(64, 256, seed=surfaces.SEED + levels)
+        step = 256 // levels
+        tiles.append((base // step * step).astype(np.uint8))
+    two = np.zeros((64, 256, 4), np.uint8)                # two flat colours per block along every two-subset shape boundary-ish pattern
+    for by in range(16):
+        for bx in range(64):
+            a, b = rng.integers(0, 256, 4), rng.integers(0, 256, 4)
+            m = rng.integers(0, 2, (4, 4)).astype(bool)
+            blk = np.where(m[..., None], a[None, None, :], b[None, None, :])
+            two[by * 4:by * 4 + 4, bx * 4:bx * 4 + 4] = blk
+    tiles.append(two)
+    img = np.concatenate(tiles, axis=0)
+    if prof == "slow":
+        img[..., 3] = 255
+    else:
+        img[::8, :, 3] = 255                              # opaque and translucent blocks mixed
+    want = oracle.encode_mt("bc7", img, prof)
+    got = _encode(itw, gpu, img, prof)
+    assert first_mismatch(got, want, 16) is None, first_mismatch(got, want, 16)
+
+
+@pytest.mark.parametrize("prof", ["slow", "alpha_slow"])
+def test_bounded_order_on_noisy_and_natural_content(itw, gpu, oracle, deep, golden_inputs, prof):
+    """noisy content: most blocks never reach modes 1/3 (the list is short); natural content: nearly all do"""
+    from itw_amd import surfaces
+    noisy = surfaces.ldr_smooth(256, 256, seed=surfaces.SEED + 41)
+    nat = np.ascontiguousarray(golden_inputs["baboon"])
+    for img in (noisy, nat):
+        img = img.copy()
+        if prof == "alpha_slow":
+            img[64:192, 64:192, 3] = 255
+        want = oracle.encode_mt("bc7", img, prof)
+        got = _encode(itw, gpu, img, prof)
+        assert first_mismatch(got, want, 16) is None, first_mismatch(got, want, 16)
