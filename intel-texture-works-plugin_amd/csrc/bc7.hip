@@ -1279,6 +1279,30 @@ bc7_finish_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t block
 enum WideKind { WK_SCAN02 = 0, WK_SCAN13 = 1, WK_SCAN7 = 2 };          // scan tasks of the fused and the wide path
 __host__ __device__ constexpr int wide_win_slot(int mode) { return mode == 0 ? 0 : mode == 2 ? 1 : mode == 1 ? 2 : mode == 3 ? 3 : 4; }   // winner rows: m0 m2 m1 m3 m7
 
+// the ranking's view of the whole block, for rank keys evaluated at merge time (same construction as search_two_subset)
+template <int FIT_CH, int RANK_CH>
+__device__ __forceinline__ void whole_block_rank_stats(Stats<RANK_CH>& rfull, const Tex& tx)
+{
+    IStats<FIT_CH> full;
+    stats_int<FIT_CH>(full, tx.pl, whole_block());
+    IStats<RANK_CH> t;
+    #pragma unroll
+    for (int i = 0; i < 10; i++) t.m[i] = full.m[i];
+    #pragma unroll
+    for (int i = 0; i < 4; i++) t.s[i] = full.s[i];
+    t.n = 16;
+    stats_float<RANK_CH>(rfull, t);
+}
+
+template <int FIT_CH, int RANK_CH>
+__device__ __forceinline__ int32_t merge_key(const Win& w, const Tex& tx, const SeedTables& T)
+{
+    if (w.key >= 0) return w.key;
+    Stats<RANK_CH> rfull;
+    whole_block_rank_stats<FIT_CH, RANK_CH>(rfull, tx);
+    return rank_key<RANK_CH>(w.shape, tx, rfull, T);
+}
+
 // ---- FUSED deep path: whole surfaces in two launches --------------------------------------------------------------------
 // The kernels above run as up to seven launches, each re-reading the 64 B block from HBM and handing winners, best error
 // and the current block to the next through the workspace: 5.4x the algorithmic bytes for a `slow` call.  Nothing in
@@ -1306,6 +1330,34 @@ __device__ __forceinline__ void unpack_win(Win& w, uint32_t v)
     w.key = -1;
 }
 
+#ifndef LIST_SCAN_MAX_PARTS
+#define LIST_SCAN_MAX_PARTS 8
+#endif
+// split scans of the fused path (bounded order, modes 1/3 over a short list): how many strided shares of the 64 shapes each listed block's
+// scan is cut into so that a short list still fills the chip -- a function of the list length alone, computed alike by the scan and by
+// the refinement that merges the shares.  parts x listed blocks <= nblocks: the shares' winners fit the mode's winner row, [part][slot].
+__device__ __forceinline__ int32_t list_scan_parts(int32_t count, int32_t nblocks)
+{
+    const int32_t chunks = (count + TPB - 1) / TPB;
+    if (chunks <= 0) return 1;
+    const int32_t p = nblocks / (chunks * TPB);
+    return p < 1 ? 1 : (p > LIST_SCAN_MAX_PARTS ? LIST_SCAN_MAX_PARTS : p);
+}
+// ordered argmin over the shares' winners of mode 1 / 3 (packed: the rank key is evaluated on a tie only, as in the wide path)
+template <int FIT_CH, int RANK_CH>
+__device__ __forceinline__ void merge_packed_parts(Win& w, Lane& ln, const uint32_t* __restrict__ row, int32_t count, int parts, int32_t slot)
+{
+    unpack_win(w, row[slot]);
+    for (int p = 1; p < parts; p++) {
+        Win x;
+        unpack_win(x, row[(int64_t)p * count + slot]);
+        if (x.err < w.err) { w = x; continue; }
+        if (x.err != w.err || x.err == ERR_MAX) continue;
+        w.key = merge_key<FIT_CH, RANK_CH>(w, ln.tx, ln.T); x.key = merge_key<FIT_CH, RANK_CH>(x, ln.tx, ln.T);
+        if (x.key < w.key) w = x;
+    }
+}
+
 struct ScanTasks { int n; int kind[3]; };      // WK_SCAN02 / WK_SCAN13 / WK_SCAN7 in launch order
 
 // FAM7 = false: the three-channel families {0,2} and {1,3} (4 waves per SIMD; ranked lists 3); FAM7 = true: the mode 7 scan
@@ -1315,11 +1367,40 @@ template <bool VEC16, bool RANKED_LISTS, bool FAM7>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(scan_all_waves(RANKED_LISTS, FAM7), scan_all_waves(RANKED_LISTS, FAM7))))
 bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint32_t* __restrict__ wins4,
              const bc7_enc_settings S, const ScanTasks tasks, const int ranked13, const int ranked7, const int32_t nchunks, const int32_t grain,
-             const int32_t* __restrict__ rgb_list, const int32_t* __restrict__ rgb_count)
+             const int32_t* __restrict__ rgb_list, const int32_t* __restrict__ rgb_count, const int32_t split)
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
     __shared__ uint2 s_pal[((RANKED_LISTS && ITW_BC7_LANE_PAL) ? 16 : 12) * TPB];   // ranked lists: 2 subsets x 8 levels (3 waves per SIMD: 3 x 44 KiB)
+    if (!RANKED_LISTS && split) {
+        // bounded order: modes 1/3 (or mode 7: FAM7) over the list bc7_finish_all<.., 3 | 5 | 6> left, each listed block's 64 shapes cut
+        // into `parts` strided shares (list_scan_parts) so that a short list still fills the chip; winners go to [part][slot] of the modes' rows
+        const int32_t count = *rgb_count;
+        const int32_t parts = list_scan_parts(count, nblocks);
+        const int32_t chunk = (int32_t)(blockIdx.x / (uint32_t)parts), part = (int32_t)(blockIdx.x % (uint32_t)parts);
+        if (chunk * TPB >= count) return;                                // whole workgroup: no barrier is pending
+        Lane ln;
+        ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
+        __syncthreads();
+        const int32_t gid = chunk * TPB + threadIdx.x;
+        const bool live = gid < count;
+        const int32_t slot = live ? gid : count - 1;
+        ln.keys = nullptr;
+        ln.pal = s_pal + threadIdx.x;
+        load_block<VEC16>(ln.tx, src, stride, blocks_x, rgb_list[slot]);
+        Win wa, wb;
+        if (FAM7) {
+            search_two_subset<true, 4, 0>(ln, S, wa, wb, part, parts);             // RGBA profiles only (launch_bc7)
+            if (live) wins4[(int64_t)wide_win_slot(7) * nblocks + (int64_t)part * count + slot] = pack_win(wa);
+        } else {
+            search_two_subset<false, 3, 0>(ln, S, wa, wb, part, parts);
+            if (live) {
+                wins4[(int64_t)wide_win_slot(1) * nblocks + (int64_t)part * count + slot] = pack_win(wa);
+                wins4[(int64_t)wide_win_slot(3) * nblocks + (int64_t)part * count + slot] = pack_win(wb);
+            }
+        }
+        return;
+    }
     // `grain` chunks of one family, then the same chunks of the next family (grain is a multiple of 8, so a chunk's
     // families run on the same XCD: workgroup w -> XCD w % 8)
     const uint32_t w = blockIdx.x, per = (uint32_t)grain * (uint32_t)tasks.n, group = w / per, r = w % per;
@@ -1384,23 +1465,38 @@ __device__ __forceinline__ void append_to_list(int32_t* __restrict__ list, int32
 //                            then the list of blocks with min over shapes of the bound < inc;
 //   PHASE 5 (RGBA profiles)  the same on the list PHASE 1 left: modes 0,2, the choice against the alpha group (ties to 0/2), inc, list;
 //   PHASE 4                  modes 1,3 over that list, starting from best_err = inc: the block is replaced iff one of them gets below.
+// RGBA profiles whose mode 7 scans every shape too (`alpha_slow`) bound it with the same number (a mode 7 encoding's colour part is one more
+// set of rounded points of a segment per subset; its error has no opaque term):
+//   PHASE 6                  modes 4,5,6 alone -> block, error; the list of blocks where a three-channel mode can still win or tie, as
+//                            PHASE 1 leaves it (judged against modes 4,5,6 only: a longer list, the same final comparison), and for the
+//                            other blocks inc = error + 1 and a place on mode 7's list (translucent content: not bounded, mode 7 is its mode);
+//   PHASE 5                  as above, and it also appends the blocks whose mode 7 bound is below inc to mode 7's list;
+//   PHASE 4                  as above, and leaves inc = its error where it replaced the block (mode 7 comes after 1/3: strictly below);
+//   PHASE 7                  mode 7 over its list from best_err = inc.
 // The final block is the reference's first strict minimum over 0,2,1,3,7,4,5,6 either way: a mode's result enters only through
 // `err < best_err`, the groups keep their internal order, and a skipped block's modes 1/3 cannot reach inc whatever shape their scan would
 // have picked (every encoding of every shape is bounded).
 #ifndef FINISH_ALL_WAVES
 #define FINISH_ALL_WAVES 2
 #endif
+#ifndef BOUND_BAIL_AFTER
+#define BOUND_BAIL_AFTER 4
+#endif
+#ifndef BOUND_BAIL_LANES
+#define BOUND_BAIL_LANES 40
+#endif
 template <bool VEC16, int PHASE>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FINISH_ALL_WAVES, FINISH_ALL_WAVES)))
 bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst,
                const uint32_t* __restrict__ wins4, const bc7_enc_settings S, int32_t* __restrict__ inc_err,
-               const int32_t* __restrict__ in_list, const int32_t* __restrict__ in_count, int32_t* __restrict__ out_list, int32_t* __restrict__ out_count)
+               const int32_t* __restrict__ in_list, const int32_t* __restrict__ in_count, int32_t* __restrict__ out_list, int32_t* __restrict__ out_count,
+               int32_t* __restrict__ out_list7, int32_t* __restrict__ out_count7)
 {
-    constexpr bool LISTED = PHASE == 2 || PHASE == 4 || PHASE == 5;          // walks a compacted list of an earlier phase
+    constexpr bool LISTED = PHASE == 2 || PHASE == 4 || PHASE == 5 || PHASE == 7;   // walks a compacted list of an earlier phase
     constexpr bool DO02 = PHASE == 0 || PHASE == 2 || PHASE == 3 || PHASE == 5;
     constexpr bool DO13 = PHASE == 0 || PHASE == 2 || PHASE == 4;
     constexpr bool DO7 = PHASE == 0 || PHASE == 1;
-    constexpr bool DO456 = PHASE == 0 || PHASE == 1 || PHASE == 3;
+    constexpr bool DO456 = PHASE == 0 || PHASE == 1 || PHASE == 3 || PHASE == 6;
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
     __shared__ uint2 s_pal[(ITW_BC7_LANE_PAL ? LANE_PAL_LEVELS : 8) * TPB];   // refinement: a palette per subset of the lane's winner
@@ -1429,7 +1525,7 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
     const bool on13 = S.mode_selection[1];
     int32_t e_alpha = ERR_MAX;
     if (PHASE == 2 || PHASE == 5) e_alpha = inc_err[b];      // every listed block has opaque_err <= e_alpha: its winners exist
-    if (PHASE == 4) ln.best_err = inc_err[b];                // what modes 1/3 have to get strictly below
+    if (PHASE == 4 || PHASE == 7) ln.best_err = inc_err[b];  // what modes 1/3 (mode 7) have to get strictly below
     Win w;
     if (DO02 && S.mode_selection[0]) {
         unpack_win(w, wins4[(int64_t)wide_win_slot(0) * nblocks + b]);
@@ -1437,9 +1533,20 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
         if (!S.skip_mode2) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(2) * nblocks + b]); refine_and_commit<2>(ln, w, S.refineIterations[2], S.channels); }
     }
     const int32_t e02 = ln.best_err;
-    if (DO13) {
+    if (DO13 && PHASE != 4) {
         if (on13 && S.fastSkipTreshold_mode1 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(1) * nblocks + b]); refine_and_commit<1>(ln, w, S.refineIterations[1], S.channels); }
         if (on13 && S.fastSkipTreshold_mode3 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(3) * nblocks + b]); refine_and_commit<3>(ln, w, S.refineIterations[3], S.channels); }
+    }
+    if (PHASE == 4) {                                        // the list scan left [part][slot] winners (bc7_scan_all, split)
+        const int parts = list_scan_parts(nact, nblocks);
+        if (S.fastSkipTreshold_mode1 > 0) { ln.tx.fence(); merge_packed_parts<3, 3>(w, ln, wins4 + (int64_t)wide_win_slot(1) * nblocks, nact, parts, slot); refine_and_commit<1>(ln, w, S.refineIterations[1], S.channels); }
+        if (S.fastSkipTreshold_mode3 > 0) { ln.tx.fence(); merge_packed_parts<3, 3>(w, ln, wins4 + (int64_t)wide_win_slot(3) * nblocks, nact, parts, slot); refine_and_commit<3>(ln, w, S.refineIterations[3], S.channels); }
+    }
+    if (PHASE == 7) {                                        // the list scan left [part][slot] winners
+        const int parts = list_scan_parts(nact, nblocks);
+        ln.tx.fence();
+        merge_packed_parts<4, 4>(w, ln, wins4 + (int64_t)wide_win_slot(7) * nblocks, nact, parts, slot);
+        refine_and_commit<7>(ln, w, S.refineIterations[7], S.channels);
     }
     if (DO7 && on13 && S.fastSkipTreshold_mode7 > 0) { ln.tx.fence(); unpack_win(w, wins4[(int64_t)wide_win_slot(7) * nblocks + b]); refine_and_commit<7>(ln, w, S.refineIterations[7], S.channels); }
     if (DO456) {
@@ -1453,6 +1560,12 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
         // RGB scans and finish<2> walk -- one atomic per wave, ranks within the wave by ballot
         append_to_list(out_list, out_count, live && ln.opaque_err <= ln.best_err, b);
     }
+    if (PHASE == 6) {
+        const bool rgb = ln.opaque_err <= ln.best_err;               // a three-channel mode can still win or tie (PHASE 1's rule)
+        if (live) inc_err[b] = rgb ? ln.best_err : ln.best_err + 1; // PHASE 5 reads the error; PHASE 7 reads what mode 7 has to get below
+        append_to_list(out_list, out_count, live && rgb, b);
+        append_to_list(out_list7, out_count7, live && !rgb, b);
+    }
     if (PHASE == 3 || PHASE == 5) {
         // incumbent of modes 1/3 (see the header), then the blocks whose modes 1/3 can still get below it
         int32_t inc;
@@ -1463,18 +1576,26 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
         IStats<3> full;
         stats_int<3>(full, ln.tx.pl, whole_block());
         const float lim = (float)(inc - ln.opaque_err) - 0.5f;      // errors are integers: a bound above inc - 1 already rules the shape out
-        bool need = !live;                                           // idle lanes never hold the loop up
+        const float lim7 = (float)inc - 0.5f;                        // mode 7 carries no opaque term
+        const bool with7 = PHASE == 5 && out_list7 != nullptr;       // wave-uniform
+        bool need = !live, need7 = !live || !with7;                  // idle lanes never hold the loop up
 #pragma unroll 1
         for (int shape = 0; shape < 64; shape++) {
-            if (__all(need)) break;
+            if (__all(need && need7)) break;
+            // a wave most of whose blocks need the modes anyway stops bounding the others (visiting a block is always allowed):
+            // content the bound does not separate pays for a few shapes, not for 64
+            if (shape == BOUND_BAIL_AFTER && __popcll(__ballot(need && need7)) >= BOUND_BAIL_LANES) { need = true; need7 = true; break; }
             const float lb = two_subset_bound(shape, ln.tx.pl, full);
             need = need || !(lb >= lim);
+            need7 = need7 || !(lb >= lim7);
         }
         append_to_list(out_list, out_count, live && need, b);
+        if (with7) append_to_list(out_list7, out_count7, live && need7, b);
     }
     bool store = live;
     if (PHASE == 2 || PHASE == 5) store = store && ln.best_err <= e_alpha;   // else the alpha group's block stands (ties go to the earlier, RGB, group)
-    if (PHASE == 4) store = store && ln.improved;
+    if (PHASE == 4 || PHASE == 7) store = store && ln.improved;
+    if (PHASE == 4 && store) inc_err[b] = ln.best_err;         // mode 7 (PHASE 7, RGBA profiles) comes after modes 1/3: strictly below them
     if (store) {
         uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
         if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(ln.best[0], ln.best[1], ln.best[2], ln.best[3]);
@@ -1523,30 +1644,6 @@ __device__ __forceinline__ void store_candidate(int32_t* __restrict__ cerr, uint
 {
     cerr[(int64_t)slot * nblocks + b] = err;
     cblk[(int64_t)slot * nblocks + b] = make_uint4(blk[0], blk[1], blk[2], blk[3]);
-}
-
-// the ranking's view of the whole block, for rank keys evaluated at merge time (same construction as search_two_subset)
-template <int FIT_CH, int RANK_CH>
-__device__ __forceinline__ void whole_block_rank_stats(Stats<RANK_CH>& rfull, const Tex& tx)
-{
-    IStats<FIT_CH> full;
-    stats_int<FIT_CH>(full, tx.pl, whole_block());
-    IStats<RANK_CH> t;
-    #pragma unroll
-    for (int i = 0; i < 10; i++) t.m[i] = full.m[i];
-    #pragma unroll
-    for (int i = 0; i < 4; i++) t.s[i] = full.s[i];
-    t.n = 16;
-    stats_float<RANK_CH>(rfull, t);
-}
-
-template <int FIT_CH, int RANK_CH>
-__device__ __forceinline__ int32_t merge_key(const Win& w, const Tex& tx, const SeedTables& T)
-{
-    if (w.key >= 0) return w.key;
-    Stats<RANK_CH> rfull;
-    whole_block_rank_stats<FIT_CH, RANK_CH>(rfull, tx);
-    return rank_key<RANK_CH>(w.shape, tx, rfull, T);
 }
 
 // Ordered argmin over the parts of one mode's split scan.
@@ -1818,7 +1915,7 @@ size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks)
 {
     const size_t n = (size_t)(width / 4) * (size_t)(height / 4);
     size_t deep = ((n * sizeof(int32_t) + 15) & ~(size_t)15) + 2 * n * sizeof(uint4);
-    const size_t fused = (size_t)8 * n * sizeof(int32_t) + 2 * sizeof(int32_t);     // 5 winner rows, incumbents, two block lists + their lengths
+    const size_t fused = (size_t)9 * n * sizeof(int32_t) + 4 * sizeof(int32_t);     // 5 winner rows, incumbents, three block lists + their lengths
     if (fused > deep) deep = fused;
     const size_t limit = bc7_path_override() == 2 ? ((size_t)1 << 20) : (wide_max_blocks > 0 ? (size_t)wide_max_blocks : (size_t)ITW_BC7_WIDE_MAX_BLOCKS);
     const bool may_wide = bc7_path_override() != 1 && n <= limit && n <= ((size_t)1 << 20);
@@ -1963,10 +2060,12 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             int32_t* alpha_err = reinterpret_cast<int32_t*>(wins4 + (size_t)5 * n);            // [n] x 4 B behind the winner rows: a phase's error / incumbent
             int32_t* rgb_list = alpha_err + n;                                                 // [n] block ids (RGBA profiles: where an RGB mode can win; RGB: where modes 1/3 can)
             int32_t* list13 = rgb_list + n;                                                    // [n] block ids (RGBA profiles, bounded order)
-            int32_t* rgb_count = list13 + n;                                                   // the two lists' lengths
+            int32_t* list7 = list13 + n;                                                       // [n] block ids (RGBA profiles, bounded order incl. mode 7)
+            int32_t* rgb_count = list7 + n;                                                    // the three lists' lengths
             int32_t* count13 = rgb_count + 1;
+            int32_t* count7 = rgb_count + 2;
             const dim3 blk(TPB);
-            auto scan_rgb = [&](const int32_t* list, const int32_t* count, bool do13, bool do02) {
+            auto scan_rgb = [&](const int32_t* list, const int32_t* count, bool do13, bool do02, int32_t split = 0) {
                 ScanTasks T;
                 T.n = 0;
                 if (on13 && do13) T.kind[T.n++] = WK_SCAN13;                   // longest first
@@ -1974,52 +2073,64 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                 if (T.n == 0) return;
                 const dim3 grid((unsigned)(groups * grain * T.n));
                 if (r13) {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count, split);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count, split);
                 } else {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count, split);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count, split);
                 }
             };
-            auto scan_7 = [&]() {
+            auto scan_7 = [&](const int32_t* list = nullptr, const int32_t* count = nullptr, int32_t split = 0) {
                 if (!on7) return;
                 ScanTasks T7;
                 T7.n = 1; T7.kind[0] = WK_SCAN7;
                 const dim3 grid((unsigned)chunks8);
                 if (r7) {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr, nullptr);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr, nullptr);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split);
                 } else {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr, nullptr);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, nullptr, nullptr);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split);
                 }
             };
-            auto finish = [&](auto phase, const int32_t* in_list, const int32_t* in_count, int32_t* out_list, int32_t* out_count) {
+            auto finish = [&](auto phase, const int32_t* in_list, const int32_t* in_count, int32_t* out_list, int32_t* out_count,
+                              int32_t* out_list7 = nullptr, int32_t* out_count7 = nullptr) {
                 constexpr int PH = decltype(phase)::value;
-                if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true, PH>),  L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, in_list, in_count, out_list, out_count);
-                else       hipLaunchKernelGGL((bc7_finish_all<false, PH>), L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, in_list, in_count, out_list, out_count);
+                if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true, PH>),  L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, in_list, in_count, out_list, out_count, out_list7, out_count7);
+                else       hipLaunchKernelGGL((bc7_finish_all<false, PH>), L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, in_list, in_count, out_list, out_count, out_list7, out_count7);
             };
             // the bounded order (bc7_finish_all's header): profiles whose modes 1/3 scan every shape -- a ranked list already spends
             // a bound's worth of arithmetic per shape on its keys and then fits a few shapes only
             const bool bounded = bc7_bounded_order() && on02 && on13 && !r13;
             if (bc7_alpha_first(S)) {
-                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 2 * sizeof(int32_t), st));  // finish<1> / finish<5> append to the lists through them
-                scan_7();
-                finish(std::integral_constant<int, 1>{}, nullptr, nullptr, rgb_list, rgb_count);
-                if (bounded) {
+                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 3 * sizeof(int32_t), st));  // the finish phases append to the lists through them
+                if (bounded && on7 && !r7 && (S.mode_selection[2] || S.mode_selection[3])) {
+                    // mode 7 bounded too: modes 4,5,6 | 0,2 first, then 1,3 and 7 each over its own list
+                    finish(std::integral_constant<int, 6>{}, nullptr, nullptr, rgb_list, rgb_count, list7, count7);
                     scan_rgb(rgb_list, rgb_count, false, true);
-                    finish(std::integral_constant<int, 5>{}, rgb_list, rgb_count, list13, count13);
-                    scan_rgb(list13, count13, true, false);
+                    finish(std::integral_constant<int, 5>{}, rgb_list, rgb_count, list13, count13, list7, count7);
+                    scan_rgb(list13, count13, true, false, 1);
                     finish(std::integral_constant<int, 4>{}, list13, count13, nullptr, nullptr);
+                    scan_7(list7, count7, 1);
+                    finish(std::integral_constant<int, 7>{}, list7, count7, nullptr, nullptr);
                 } else {
-                    scan_rgb(rgb_list, rgb_count, true, true);
-                    finish(std::integral_constant<int, 2>{}, rgb_list, rgb_count, nullptr, nullptr);
+                    scan_7();
+                    finish(std::integral_constant<int, 1>{}, nullptr, nullptr, rgb_list, rgb_count);
+                    if (bounded) {
+                        scan_rgb(rgb_list, rgb_count, false, true);
+                        finish(std::integral_constant<int, 5>{}, rgb_list, rgb_count, list13, count13);
+                        scan_rgb(list13, count13, true, false, 1);
+                        finish(std::integral_constant<int, 4>{}, list13, count13, nullptr, nullptr);
+                    } else {
+                        scan_rgb(rgb_list, rgb_count, true, true);
+                        finish(std::integral_constant<int, 2>{}, rgb_list, rgb_count, nullptr, nullptr);
+                    }
                 }
             } else if (bounded && !on7) {
-                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 2 * sizeof(int32_t), st));
+                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 3 * sizeof(int32_t), st));
                 scan_rgb(nullptr, nullptr, false, true);
                 finish(std::integral_constant<int, 3>{}, nullptr, nullptr, list13, count13);
-                scan_rgb(list13, count13, true, false);
+                scan_rgb(list13, count13, true, false, 1);
                 finish(std::integral_constant<int, 4>{}, list13, count13, nullptr, nullptr);
             } else {
                 scan_rgb(nullptr, nullptr, true, true);

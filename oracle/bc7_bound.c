@@ -10,7 +10,7 @@
  * Why it is a bound: a subset decodes to levels floor(L + 1/2) per channel, L on the segment between the integer endpoints
  * (kernel.ispc:1164-1170), i.e. to points within sqrt(3)/2 of one line.  With d_t = distance of texel t to that line, the subset's error is
  * sum (d_t - sqrt(3)/2)_+^2 >= (sqrt(sum d_t^2) - sqrt(3)/2 sqrt(n))_+^2 and sum d_t^2 >= R = trace - lambda_max of the subset's scatter
- * matrix (the best line of all).  lambda_max <= ||M^4||_F^(1/4) for the (scaled) scatter matrix M. */
+ * matrix (the best line of all).  lambda_max <= ||M^2||_F^(1/2) for the (scaled) scatter matrix M. */
 #include <math.h>
 #include <stdint.h>
 #include "oracle.h"
@@ -26,12 +26,9 @@ static float residual_bound_n(const int32_t m[6], const int32_t s[3], int32_t n)
     const float bb = b * b, cc = c * c, ee = e * e;
     const float A = a * a + bb + cc, B = a * b + b * d + c * e, C = a * c + b * e + c * f;
     const float D = bb + d * d + ee, E = b * c + d * e + e * f, F = cc + ee + f * f;
-    const float BB = B * B, CC = C * C, EE = E * E;
-    const float A2 = A * A + BB + CC, B2 = A * B + B * D + C * E, C2 = A * C + B * E + C * F;
-    const float D2 = BB + D * D + EE, E2 = B * C + D * E + E * F, F2 = CC + EE + F * F;
-    const float off = B2 * B2 + C2 * C2 + E2 * E2;
-    const float fro2 = (A2 * A2 + D2 * D2 + F2 * F2) + (off + off);
-    const float lam = sqrtf(sqrtf(sqrtf(fro2)));
+    const float off = B * B + C * C + E * E;
+    const float fro = (A * A + D * D + F * F) + (off + off);
+    const float lam = sqrtf(sqrtf(fro));                                     /* ||M^2||_F^(1/2) >= largest eigenvalue / trace */
     const float r = ((a + d + f) - lam) - 1e-5f;
     return fmaxf(r, 0.0f) * t;
 }

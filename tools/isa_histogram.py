@@ -36,10 +36,11 @@ def main():
             name, cur = m.group(1), []
             continue
         if cur is not None:
-            cur.append(line)
-            if "s_endpgm" in line:
+            if line.startswith(".Lfunc_end"):             # (an early `return` puts an s_endpgm in the middle of the function)
                 kernels[name] = cur
                 cur = None
+            else:
+                cur.append(line)
     demangle = lambda n: subprocess.run(["c++filt", n], stdout=subprocess.PIPE, text=True).stdout.split("(")[0].strip()
     for i, (n, body) in enumerate(kernels.items()):
         ops = collections.Counter()

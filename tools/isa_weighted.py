@@ -70,9 +70,9 @@ def kernel_body(text, pattern):
                 name, cur = dem.replace("(anonymous namespace)::", "").split("(")[0], []
                 continue
         if cur is not None:
-            cur.append(line)
-            if "s_endpgm" in line:
+            if line.startswith(".Lfunc_end"):             # (an early `return` puts an s_endpgm in the middle of the function)
                 return name, cur
+            cur.append(line)
     raise SystemExit(f"no kernel matching {pattern!r}")
 
 
