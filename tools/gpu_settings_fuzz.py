@@ -53,6 +53,12 @@ for t in range(trials):
             "refineIterations_channel": int(rng.integers(0, 6)), "channels": int(rng.choice([3, 4]))}
     sel = [bool(rng.integers(0, 2)) for _ in range(4)]
     if not any(sel): sel[int(rng.integers(0, 4))] = True
+    if rng.random() < 0.35:
+        # the bounded mode order (csrc/bc7.hip: modes 1/3, and 7 under RGBA profiles, last and only where their bound allows) needs both
+        # multi-subset groups on and whole-table scans: a third of the trials are drawn from there
+        sel[0] = sel[1] = True
+        vals["fastSkipTreshold_mode1"] = int(rng.choice([0, 64, 64, 70])); vals["fastSkipTreshold_mode3"] = int(rng.choice([0, 64, 64, 70]))
+        vals["fastSkipTreshold_mode7"] = int(rng.choice([0, 5, 64, 64, 70]))
     ref = [int(rng.integers(0, 6)) for _ in range(8)]
     for x in (s, so):
         for k, v in vals.items(): setattr(x, k, v)

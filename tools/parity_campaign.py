@@ -1,7 +1,7 @@
 """Large GPU-vs-oracle parity campaign (run on the GPU box): every format / profile on several megapixels of mixed
 content -- smooth + noise, uniform random bytes, posterised (tie-heavy), real alpha, adversarial half bits -- compared
 bit for bit with the multi-threaded scalar oracle.  Prints one line per case and a summary; exit code 1 on any mismatch.
-Usage: python tools/parity_campaign.py [megapixels_per_case] [oracle|ref] [fmt,fmt,...]   (default 2, oracle, every format; the oracle needs ~1 s per
+Usage: python tools/parity_campaign.py [megapixels_per_case] [oracle|ref] [fmt,fmt,...] [profile,...]   (default 2, oracle, every format; the oracle needs ~1 s per
 Mpix of BC7 slow on 16 cores).  `ref`: the checker is the reference's own kernel.ispc built as a scalar program
 (oracle/_ref/libispc_texcomp_ref_full.so) instead of the oracle's restatement; BC4/BC5, which kernel.ispc does not have, stay on the oracle."""
 import os, sys, time
@@ -26,9 +26,23 @@ def posterised(h, w, levels):
     return ((img // step) * step + step // 2).astype(np.uint8)
 
 def mixed_ldr(h, w):
-    q = h // 4 // 4 * 4
+    q = h // 5 // 4 * 4
+    # natural images (the reference's samples among them): the bounded BC7 order visits nearly every block there, bails out of its bound
+    # loop, and ties between modes are the content's own
+    z, z2 = np.load(os.path.join(ROOT, "tests", "golden", "inputs.npz")), np.load(os.path.join(ROOT, "tests", "golden", "samples2.npz"))
+    tiles = [z["baboon"], z["monkey"][:216, :216], z2["normals"], z2["landscape_detail"][:336, :124], z2["gradients"], z2["test_a"][:256, :256]]
+    nat = np.zeros((q, w, 4), np.uint8)
+    x = 0
+    while x < w:
+        for t in tiles:
+            if x >= w:
+                break
+            tw = min(t.shape[1], w - x)
+            col = np.tile(t[:, :tw], (-(-q // t.shape[0]), 1, 1))[:q]
+            nat[:, x:x + tw] = col
+            x += tw
     parts = [surfaces.ldr_smooth(q, w, seed=surfaces.SEED + 31).copy(), rng.integers(0, 256, size=(q, w, 4), dtype=np.uint8),
-             posterised(q, w, 4), posterised(h - 3 * q, w, 2)]
+             posterised(q, w, 4), nat, posterised(h - 4 * q, w, 2)]
     # alpha of the smooth quarter: real alpha | opaque | 254/255 speckles | per-block mix -- the RGBA profiles' order of
     # mode groups and the skipped RGB scans (bc7_finish_all) see whole waves of each kind and mixed ones
     a = parts[0][..., 3]
@@ -47,6 +61,8 @@ def mixed_hdr(h, w):
 cases = [("bc1", None), ("bc3", None), ("bc4", None), ("bc5", None)] + [("bc7", p) for p in itw_amd.BC7_PROFILES] + [("bc6h", p) for p in itw_amd.BC6H_PROFILES]
 if len(sys.argv) > 3:
     cases = [c for c in cases if c[0] in sys.argv[3].split(",")]
+if len(sys.argv) > 4:                                        # profile filter, e.g. slow,alpha_slow
+    cases = [c for c in cases if c[1] in sys.argv[4].split(",")]
 torch.cuda.set_device(0)
 bad_total, blocks_total = 0, 0
 ldr, hdr = mixed_ldr(H, W), mixed_hdr(H, W)
