@@ -17,12 +17,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def per_call(path, counter):
     """Sum of `counter` over all kernels of one C-ABI call = total over the trace / number of calls, where the number
-    of calls is the dispatch count of the most frequent kernel name."""
+    of calls is the dispatch count of the LEAST frequent kernel name (every kernel of a call runs at least once per call; the bounded
+    BC7 order launches bc7_scan_all twice)."""
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     if not rows:
         return None, 0
     by_kernel = collections.Counter(r["Kernel_Name"] for r in rows)
-    calls = max(by_kernel.values())
+    calls = min(by_kernel.values())
     total = sum(float(r["Counter_Value"]) for r in rows)
     return total / calls, calls
 
@@ -33,7 +34,7 @@ def per_call_by_kernel(path, counter):
     if not rows:
         return {}
     by_kernel = collections.Counter(r["Kernel_Name"] for r in rows)
-    calls = max(by_kernel.values())
+    calls = min(by_kernel.values())
     out = collections.defaultdict(float)
     for r in rows:
         out[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()] += float(r["Counter_Value"])
