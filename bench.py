@@ -694,8 +694,10 @@ def main():
             ref_rate = full * blocks_all / t / 1e12
             va = {"fp32_arith_ops_per_block": arith, "fp32_arith_cmp_cvt_ops_per_block": full,
                   "reference_T_ops_s": round(ref_rate, 2), "peak_T_flops_s": VALU_PEAK_FMA_TFLOPS * world,
-                  "frac_of_fma_peak": round(ref_rate / (VALU_PEAK_FMA_TFLOPS * world), 4),
-                  "note": "NOT a roofline of this implementation: the reference algorithm's scalar fp32 operations per block (mul/add/"
+                  "reference_equivalent_over_fma_peak": round(ref_rate / (VALU_PEAK_FMA_TFLOPS * world), 4),
+                  "note": "NOT a roofline of this implementation, and NOT bounded by 1: since round 4's bounded BC7 mode order the kernels "
+                          "leave out, exactly, the parts of the reference's work that cannot change the block (DESIGN.md 3.2), so the "
+                          "reference-EQUIVALENT rate can exceed the chip's peak.  It is the reference algorithm's scalar fp32 operations per block (mul/add/"
                           "div/sqrt + compares + conversions, counted by single-stepping the CPU oracle, profiles/op_counts.json) x blocks "
                           "/ measured step time, against the chip's fp32 vector peak WITH FMA / packed credit (157.3 TFLOP/s per GPU: "
                           "one lane-op = up to 2 flops).  The kernels retire several reference ops per executed lane-op (a v_dot4 "

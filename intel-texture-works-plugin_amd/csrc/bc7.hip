@@ -1338,7 +1338,7 @@ __device__ __forceinline__ void unpack_win(Win& w, uint32_t v)
 // the refinement that merges the shares.  parts x listed blocks <= nblocks: the shares' winners fit the mode's winner row, [part][slot].
 __device__ __forceinline__ int32_t list_scan_parts(int32_t count, int32_t nblocks)
 {
-    const int32_t chunks = (count + TPB - 1) / TPB;
+    const int32_t chunks = ((count + TPB - 1) / TPB + 7) & ~7;        // in eights: a chunk's shares stay on one XCD (below)
     if (chunks <= 0) return 1;
     const int32_t p = nblocks / (chunks * TPB);
     return p < 1 ? 1 : (p > LIST_SCAN_MAX_PARTS ? LIST_SCAN_MAX_PARTS : p);
@@ -1377,7 +1377,9 @@ bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, 
         // into `parts` strided shares (list_scan_parts) so that a short list still fills the chip; winners go to [part][slot] of the modes' rows
         const int32_t count = *rgb_count;
         const int32_t parts = list_scan_parts(count, nblocks);
-        const int32_t chunk = (int32_t)(blockIdx.x / (uint32_t)parts), part = (int32_t)(blockIdx.x % (uint32_t)parts);
+        // workgroup w runs on XCD w % 8: the shares of a chunk are 8 workgroups apart, so they read its texels through the same L2
+        const uint32_t wg = blockIdx.x;
+        const int32_t chunk = (int32_t)((wg / (8u * (uint32_t)parts)) * 8u + (wg & 7u)), part = (int32_t)((wg >> 3) % (uint32_t)parts);
         if (chunk * TPB >= count) return;                                // whole workgroup: no barrier is pending
         Lane ln;
         ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
