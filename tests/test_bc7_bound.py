@@ -158,3 +158,38 @@ def test_bound_never_exceeds_brute_force_palettes_from_arbitrary_endpoints():
                     assert lb[shape] <= total, (b, shape, bits, trial, lb[shape], total)
                     worst = min(worst, total - lb[shape])
     assert worst >= 0
+
+
+def test_list_scan_share_mapping_covers_every_chunk_and_share_exactly_once():
+    """The bounded order's list scans (csrc/bc7.hip: list_scan_parts and the split branch of bc7_scan_all) cut each listed block's 64
+    shapes into `parts` strided shares and map workgroup w to (chunk, share) so that a chunk's shares sit on one XCD (w % 8).  Restated
+    here: for every list length the workgroups of the launch (grid >= ceil(nblocks / 256) rounded up to 8) cover every (chunk, share)
+    exactly once, every share's winners fit the mode's winner row (parts x listed <= nblocks), and the shares partition the 64 shapes."""
+    TPB, MAXP = 256, 8
+
+    def parts_of(count, nblocks):
+        chunks = ((count + TPB - 1) // TPB + 7) & ~7
+        if chunks <= 0:
+            return 1
+        return max(1, min(MAXP, nblocks // (chunks * TPB)))
+
+    for nblocks in (1, 9, 255, 256, 257, 4096, 65536, 262145, 1 << 20):
+        nchunks = (nblocks + TPB - 1) // TPB
+        grid = (nchunks + 7) // 8 * 8
+        counts = sorted({0, 1, 2, 255, 256, 257, nblocks // 7, nblocks // 3, nblocks // 2, nblocks - 1, nblocks} & set(range(nblocks + 1)))
+        for count in counts:
+            parts = parts_of(count, nblocks)
+            assert parts * count <= nblocks or parts == 1
+            seen = {}
+            for w in range(grid):
+                chunk, part = (w // (8 * parts)) * 8 + (w & 7), (w >> 3) % parts
+                if chunk * TPB >= count:
+                    continue
+                assert (chunk, part) not in seen
+                seen[(chunk, part)] = w
+            need = {(c, p) for c in range((count + TPB - 1) // TPB) for p in range(parts)}
+            assert set(seen) == need, (nblocks, count, parts)
+            for (c, p), w in seen.items():
+                assert w % 8 == seen[(c, 0)] % 8                     # a chunk's shares: the same XCD
+            shapes = sorted(s for p in range(parts) for s in range(p, 64, parts))
+            assert shapes == list(range(64))
