@@ -1,5 +1,5 @@
 """GPU box: prune rates from gpurun_variants/lib_pruneprobe.so (tools/variants/make_bc7_prune_probe.py).  The variant library is
-loaded INSTEAD of the product (copy it over intel-texture-works-plugin_amd/lib/libispc_texcomp.so first: tools/gpu_r04c.sh)."""
+loaded INSTEAD of the product (copy it over intel-texture-works-plugin_amd/lib/libispc_texcomp.so first: tools/round4/gpu_r04c.sh)."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "intel-texture-works-plugin_amd"))
