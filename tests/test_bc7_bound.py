@@ -193,3 +193,72 @@ def test_list_scan_share_mapping_covers_every_chunk_and_share_exactly_once():
                 assert w % 8 == seen[(c, 0)] % 8                     # a chunk's shares: the same XCD
             shapes = sorted(s for p in range(parts) for s in range(p, 64, parts))
             assert shapes == list(range(64))
+
+
+def test_bound_on_twenty_thousand_random_blocks_of_five_kinds():
+    """seeded random blocks (uniform bytes, two colours + noise, planar gradients + noise, low-amplitude noise around a colour, one-channel
+    noise): bound <= part_fast error of every shape for modes 1 and 3"""
+    rng = np.random.default_rng(4242)
+    n = 4000
+    kinds = []
+    kinds.append(rng.integers(0, 256, (n, 16, 3)))
+    a, b = rng.integers(0, 256, (n, 1, 3)), rng.integers(0, 256, (n, 1, 3))
+    pick = rng.integers(0, 2, (n, 16, 1))
+    kinds.append(np.where(pick == 1, a, b) + rng.integers(-3, 4, (n, 16, 3)))
+    gx, gy = np.meshgrid(np.arange(4), np.arange(4))
+    g = (gx.reshape(1, 16, 1) * rng.integers(-40, 41, (n, 1, 3)) + gy.reshape(1, 16, 1) * rng.integers(-40, 41, (n, 1, 3)))
+    kinds.append(rng.integers(40, 216, (n, 1, 3)) + g + rng.integers(-2, 3, (n, 16, 3)))
+    kinds.append(rng.integers(0, 256, (n, 1, 3)) + rng.integers(-12, 13, (n, 16, 3)))
+    one = rng.integers(0, 256, (n, 1, 3)) + np.zeros((n, 16, 3), np.int64)
+    one[:, :, 1] += rng.integers(-60, 61, (n, 16))
+    kinds.append(one)
+    L = lib()
+    err = np.zeros(64, np.float32)
+    key = np.zeros(64, np.int32)
+    checked = 0
+    for tex in kinds:
+        tex = np.clip(tex, 0, 255).astype(np.float32)
+        blocks = np.zeros((n, 64), np.float32)
+        blocks[:, :48] = tex.transpose(0, 2, 1).reshape(n, 48)
+        blocks[:, 48:] = 255
+        for b in range(n):
+            lb = bounds_of(L, blocks[b])
+            for mode in (1, 3):
+                L.oracle_bc7_part_fast_errors(blocks[b].ctypes.data, mode, err.ctypes.data, key.ctypes.data)
+                assert (lb <= err.astype(np.float64)).all(), (b, mode, int(np.argmax(lb - err)), float((lb - err).max()))
+            checked += 1
+    assert checked == 5 * n
+
+
+def test_float_restatement_never_exceeds_the_bound_in_exact_arithmetic():
+    """the fp32 evaluation (scaled matrix, ||M^2||_F^(1/2) for the eigenvalue, margins) against the same bound in float64 with the exact
+    largest eigenvalue: the fp32 number is the smaller one for every block and shape -- roundings never push it above the mathematics"""
+    import re
+    rng = np.random.default_rng(99)
+    t = open(os.path.join(ROOT, "oracle", "bc7_tables.h")).read()
+    m = re.search(r"BCN_SUBSET_MASKS\[128\]\s*=\s*\{([^}]*)\}", t)
+    masks = [int(x, 16) & 0xffff for x in re.findall(r"0x([0-9a-fA-F]+)u", m.group(1))][:64]
+    n = 1500
+    tex = np.concatenate([rng.integers(0, 256, (n, 16, 3)),
+                          np.clip(rng.integers(0, 256, (n, 1, 3)) + rng.integers(-20, 21, (n, 16, 3)), 0, 255),
+                          np.where(rng.integers(0, 2, (n, 16, 1)) == 1, rng.integers(0, 256, (n, 1, 3)), rng.integers(0, 256, (n, 1, 3)))]).astype(np.float64)
+    nb = tex.shape[0]
+    exact = np.zeros((nb, 64))
+    for p in range(64):
+        in0 = np.array([(masks[p] >> k) & 1 for k in range(16)], bool)
+        for sel in (in0, ~in0):
+            x = tex[:, sel, :]
+            x = x - x.mean(axis=1, keepdims=True)
+            c = np.einsum("bki,bkj->bij", x, x)
+            r = np.maximum(np.trace(c, axis1=1, axis2=2) - np.linalg.eigvalsh(c)[:, -1], 0)
+            exact[:, p] += np.maximum(np.sqrt(r) - np.sqrt(3) / 2 * np.sqrt(sel.sum()), 0) ** 2
+    L = lib()
+    blocks = np.zeros((nb, 64), np.float32)
+    blocks[:, :48] = tex.transpose(0, 2, 1).reshape(nb, 48)
+    blocks[:, 48:] = 255
+    worst = 0.0
+    for b in range(nb):
+        lb = bounds_of(L, blocks[b])
+        assert (lb <= exact[b] + 1e-9).all(), (b, int(np.argmax(lb - exact[b])), float((lb - exact[b]).max()))
+        worst = max(worst, float((exact[b] - lb).max()))
+    assert worst > 0
