@@ -13,6 +13,16 @@ profiles = sys.argv[1].split(",") if len(sys.argv) > 1 else ["slow", "basic", "a
 fmt = sys.argv[2] if len(sys.argv) > 2 else "bc7"
 if fmt == "bc6h":
     base = surfaces.hdr_smooth(4096, 4096)
+# optional third argument: content of the LDR surface -- I3 (default: smooth fields + noise, alpha field as generated), I3opaque, baboon (the
+# reference's sample tiled, opaque): the bounded BC7 order (csrc/bc7.hip) makes the deep shape's time content dependent
+content = sys.argv[3] if len(sys.argv) > 3 else "I3"
+if fmt == "bc7" and content == "I3opaque":
+    base = base.copy(); base[..., 3] = 255
+if fmt == "bc7" and content == "baboon":
+    z = np.load(os.path.join(ROOT, "tests", "golden", "inputs.npz"))
+    base = np.ascontiguousarray(np.tile(z["baboon"], (16, 16, 1)))
+    # rows of the probe cut through whole tiles: every call size sees the same mix of blocks
+print("content:", content)
 print(f"{'profile':<12} {'rows x 4096':>12} {'blocks':>9} {'deep ms':>9} {'wide ms':>9} {'wide Mpix/s':>12} same")
 for prof in profiles:
     for rows in (8, 32, 64, 128, 256, 384, 512, 1024, 4096):
