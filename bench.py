@@ -636,6 +636,9 @@ def main():
                        "RCCL, overlapped with the next step's encode" if world > 1 else "single GPU",
                        "ranks_seen_by_rccl": (dist.get_world_size() if dist is not None else 1),
                        "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if (dist is not None and not FAKE) else None),
+                       "bc7_mode_order": ("reference order (ITW_BC7_BOUND=0)" if os.environ.get("ITW_BC7_BOUND", "")[:1] == "0" else
+                                          "bounded (slow / alpha_slow: modes 1/3/7 last, only where their exact lower bound allows; same bytes; the time is "
+                                          "content dependent: formats[*@baboon_tiled] is the natural-image end)") if fmt == "bc7" else None,
                        "device": ("CONTROL-FLOW TEST ON CPU -- not a measurement" if FAKE else itw_amd.device_info()), "lib": itw_amd.version()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
