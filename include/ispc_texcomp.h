@@ -44,6 +44,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only what the headers declare is exported */
 
 struct rgba_surface
 {
@@ -111,6 +112,7 @@ void CompressBlocksBC3 (const rgba_surface* src, uint8_t* dst);
 void CompressBlocksBC6H(const rgba_surface* src, uint8_t* dst, bc6h_enc_settings* settings);
 void CompressBlocksBC7 (const rgba_surface* src, uint8_t* dst, bc7_enc_settings* settings);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 static_assert(sizeof(rgba_surface) == 24,      "rgba_surface layout (x86-64)");

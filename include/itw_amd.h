@@ -21,6 +21,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only what the headers declare is exported */
 
 /* Stream (hipStream_t as void*) used by this host thread's device-resident
  * calls.  Default: the NULL stream.  Thread-local and sticky: the handle must stay valid for as long as it is the
@@ -58,6 +59,14 @@ const char* itwDeviceInfo(void);
 enum { ITW_BC7_PATH_AUTO = 0, ITW_BC7_PATH_DEEP = 1, ITW_BC7_PATH_WIDE = 2 };
 void itwSetBc7Path(int path);
 
+/* Tuning / test knob of the BC7 `slow` profile's mode order on whole surfaces (csrc/bc7.hip): the library runs modes 1/3 last and only
+ * for the blocks an exact lower bound cannot exclude ("bounded order"), which pays on content where few blocks need them and costs 4-6 %
+ * where nearly all do.  A pilot -- 1/16 of the surface, spread over it, encoded first on a second stream -- decides per call, on the
+ * device: `percent` = the share of the pilot's blocks that may still need modes 1/3 for the rest of the surface to take the bounded
+ * order (default 75; env ITW_BC7_PILOT_THR presets it); 0 = the rest always takes the reference's order, 100 = always the bounded
+ * order, -1 = no pilot (the whole call in the bounded order).  The emitted bytes are the same whatever the value. */
+void itwSetBc7Pilot(int percent);
+
 /* Library build identification: arithmetic model and arch, e.g.
  * "itw-amd 0.1 gfx950 arith=x86-lut-nr contract=off". */
 const char* itwVersion(void);
@@ -75,16 +84,7 @@ int64_t itwBandForPart(int32_t width, int32_t height, int32_t bytes_per_block,
 int64_t itwBandForPartEx(int32_t width, int32_t height, int32_t bytes_per_block, int32_t part, int32_t parts,
                          int32_t keep_partial_blocks, int32_t* first_row, int32_t* row_count);
 
-/* Device-side self test hooks (used by tests/ to prove the pinned arithmetic on
- * the GPU): evaluate rcp / rsqrt / float->int of `n` floats resident in HBM. */
-void itwTestRcp  (const float* d_in, float* d_out, int64_t n);
-void itwTestRsqrt(const float* d_in, float* d_out, int64_t n);
-void itwTestF2I  (const float* d_in, int32_t* d_out, int64_t n);
-/* The bounded BC7 mode order's lower bound (csrc/bc7_exact.hpp two_subset_bound): for every 4x4 block of the device-resident RGBA8
- * surface, the bound of each of the 64 two-subset shapes, d_out[block * 64 + shape] (device memory, raster block order).  tests/ check it
- * against the oracle's error of every shape (it must never exceed one) and against its CPU restatement (oracle/bc7_bound.c). */
-void itwTestBc7TwoSubsetBounds(const rgba_surface* d_src, float* d_out);
-
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -25,17 +25,16 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only what the headers declare is exported */
 
 void CompressBlocksBC4(const rgba_surface* src, uint8_t* dst);
 void CompressBlocksBC5(const rgba_surface* src, uint8_t* dst);
 
-/* Test hook (tests/test_gpu_bc45_index_table.py).  The encoders evaluate FindClosestUNORM (BC4BC5.cpp:314-337) through a table
- * the current device builds once by running that search, as written, for all 65 536 endpoint pairs: per pair the 7 texel
- * codes where the chosen index changes and the 8 indices of the runs in between (csrc/bc4_bc5.hip).  Copies the table --
- * 65 536 entries x 4 words {256 - start of run 1..4, one byte each; the same for runs 5..7 with the number of runs in
- * the top byte; indices of runs 0..3, one byte each; indices of runs 4..7} -- to host memory.  Returns 0, or -1 on failure (error mode "return"). */
-int itwTestBc45IndexTable(uint32_t* host_out);
+/* The first BC4 / BC5 call on a device builds a 1 MiB index table there (csrc/bc4_bc5.hip): that one call allocates device memory and is not
+ * stream-capturable; itwWarmupBC45() does the same ahead of time (see itw_amd.h for the asynchronous contract of device-pointer calls). */
+void itwWarmupBC45(void);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

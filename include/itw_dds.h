@@ -14,6 +14,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only what the headers declare is exported */
 
 typedef struct ItwDdsDesc {
     uint32_t width, height;     /* top mip, texels */
@@ -37,6 +38,7 @@ size_t itwDdsReadHeader(const uint8_t* src, size_t size, ItwDdsDesc* desc);
  * Returns bytes written (== itwDdsFileBytes) or 0. */
 size_t itwDdsWriteFile(const ItwDdsDesc* desc, const uint8_t* const* levels, size_t nlevels, uint8_t* dst, size_t capacity);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only what the headers declare is exported */
 
 /* Decodes (width/4)*(height/4) tightly packed blocks in raster block order into a surface of `out_stride` bytes per
  * texel row: RGBA8 for BC1 / BC3 / BC7, (R,0,0,255) / (R,G,0,255) RGBA8 for BC4 / BC5 (the layout D3DXDecodeBC4U/BC5U
@@ -28,6 +29,7 @@ extern "C" {
  * Returns 0, or -1 for an unsupported format / misaligned sizes. */
 int itwDecodeBlocks(int dxgi_format, const uint8_t* blocks, int width, int height, uint8_t* out, int64_t out_stride, int32_t* modes);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

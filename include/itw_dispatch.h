@@ -19,6 +19,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only what the headers declare is exported */
 
 /* win32Threads.h:24 */
 typedef void (CompressionFunc)(const rgba_surface* input, uint8_t* output);
@@ -99,6 +100,7 @@ void itwPadToMultipleOf4Device(const rgba_surface* input, int pixel_size, uint8_
 int itwConvertToRGBA8Device(const void* src, int depth, int planes, int has_alpha, int gamma_correct, int width, int height, uint8_t* dst);
 int itwConvertToRGBA16FDevice(const void* src, int depth, int planes, int has_alpha, int width, int height, uint16_t* dst);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -30,6 +30,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only what the headers declare is exported */
 
 /* Ranks a call with ranks = 0 uses: ITW_MULTIGPU_RANKS if set, else the number of visible devices.  Rank r runs on
  * device r % device_count, so more ranks than devices is legal (how the 8-way path is exercised on a 1-GPU box). */
@@ -84,11 +85,7 @@ typedef struct itw_multigpu_stats {
 bool itwCompressImageMultiGPUEx(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks,
                                 const rgba_surface* resident_bands, itw_multigpu_stats* stats);
 
-/* Test hook (tests/test_gpu_multigpu_cpp.py): the NEXT call on this process fails inside rank `rank` at `stage`
- * (1 = while preparing, before any transfer is posted; 2 = after its first half-band was posted; 3 = the rank stalls for
- * `stall_ms` before posting anything, which is what the watchdog is for).  One-shot; nothing in the environment can set it. */
-void itwMultiGpuTestInjectFailure(int rank, int stage, int stall_ms);
-
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,9 @@
 #include <cstring>
 #include "../../include/itw_amd.h"
 #include "../../include/itw_bc45.h"
+#ifdef ITW_TEST_HOOKS
+#include "../../include/itw_test_hooks.h"
+#endif
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -104,7 +107,7 @@ struct ThreadCtx {
     void*  d_ws = nullptr;  size_t ws_cap = 0;      // BC7 inter-family workspace
     hipStream_t ws_stream = nullptr; bool ws_used = false;
     hipEvent_t  ws_event = nullptr;                 // recorded after each BC7 call: orders the workspace across streams
-    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0};  // second stream + fork/join events for the parallel parts of small BC7 calls
+    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr};  // second stream + fork/join events for the parallel parts of small BC7 calls
     int    device = -1;
     char   info[256] = {0};
     ~ThreadCtx() {
@@ -120,6 +123,7 @@ struct ThreadCtx {
         if (aux.stream) (void)hipStreamDestroy(aux.stream);
         if (aux.fork) (void)hipEventDestroy(aux.fork);
         if (aux.join) (void)hipEventDestroy(aux.join);
+        if (aux.mid) (void)hipEventDestroy(aux.mid);
     }
 };
 thread_local ThreadCtx tls;
@@ -142,6 +146,7 @@ void bind_thread_to_current_device()
     if (tls.aux.stream) { (void)hipStreamDestroy(tls.aux.stream); tls.aux.stream = nullptr; }
     if (tls.aux.fork) { (void)hipEventDestroy(tls.aux.fork); tls.aux.fork = nullptr; }
     if (tls.aux.join) { (void)hipEventDestroy(tls.aux.join); tls.aux.join = nullptr; }
+    if (tls.aux.mid) { (void)hipEventDestroy(tls.aux.mid); tls.aux.mid = nullptr; }
     tls.device = dev;
 }
 
@@ -203,6 +208,13 @@ void reserve_workspace(size_t bytes, hipStream_t st)
 // shape (scans and single-subset modes side by side on two streams) fills the gaps between runs better than five dependent
 // launches: measured 8.75 -> 7.89 ms for a 4096^2 `slow` call.  Device-resident calls keep the deep shape above 262144
 // blocks (same time, a fifth of the HBM traffic and workspace).
+// ITW_STAGED_WIDE_MAX: up to how many blocks a staged run of a host-pointer BC7 call takes the wide launch shape (tuning knob)
+int64_t staged_wide_max_blocks()
+{
+    static const int64_t v = [] { const char* e = std::getenv("ITW_STAGED_WIDE_MAX"); return e ? (int64_t)std::atoll(e) : ((int64_t)1 << 20); }();
+    return v < 1 ? 1 : v;
+}
+
 void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, uint8_t* d_dst, hipStream_t st, bool staged = false)
 {
     switch (j.fmt) {
@@ -214,8 +226,9 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
             ITW_CHECK(hipStreamCreateWithFlags(&tls.aux.stream, hipStreamNonBlocking));
             ITW_CHECK(hipEventCreateWithFlags(&tls.aux.fork, hipEventDisableTiming));
             ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join, hipEventDisableTiming));
+            ITW_CHECK(hipEventCreateWithFlags(&tls.aux.mid, hipEventDisableTiming));
         }
-        tls.aux.wide_max_blocks = staged ? ((int64_t)1 << 20) : 0;
+        tls.aux.wide_max_blocks = staged ? staged_wide_max_blocks() : 0;
         itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st, tls.aux.wide_max_blocks), st, &tls.aux);
         ITW_CHECK(hipEventRecord(tls.ws_event, st));
         break;
@@ -311,7 +324,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         // Size the workspace once for the most demanding run: growing it frees it, and hipFree waits for the runs in flight.
         // "Most demanding" is not "tallest" (ADVICE r02): a staged BC7 run of up to 2^20 blocks takes the wide shape at ~440
         // B/block while a taller one takes the deep shape at 36 B/block, so the maximum is taken over every run's own need.
-        const int64_t wide_max = (!src_dev && !dst_dev) ? ((int64_t)1 << 20) : 0;
+        const int64_t wide_max = (!src_dev && !dst_dev) ? staged_wide_max_blocks() : 0;
         size_t need = 0;
         for (int c = 0; c < nch; c++) {
             const int run_rows = (cut[c + 1] - cut[c]) * 4;
@@ -557,7 +570,8 @@ void apply(const Bc6hPreset& p, bc6h_enc_settings* s)
     s->fastSkipTreshold = p.n; s->refineIterations_1p = p.r1p; s->refineIterations_2p = p.r2p;
 }
 
-// ---- device self-test kernels ------------------------------------------------
+// ---- device self-test kernels (libispc_texcomp_test.so only) ------------------
+#ifdef ITW_TEST_HOOKS
 __global__ void k_test_rcp(const float* in, float* out, int64_t n)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -583,6 +597,7 @@ __global__ void k_test_f2i(const float* in, int32_t* out, int64_t n)
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = itw::f2i_x86(in[i]);
 }
+#endif // ITW_TEST_HOOKS
 
 } // namespace
 
@@ -669,6 +684,7 @@ const char* itwDeviceInfo(void)
 }
 
 void itwSetBc7Path(int path) { itw::set_bc7_path(path); itw::set_bc6h_path(path); }
+void itwSetBc7Pilot(int percent) { itw::set_bc7_pilot(percent); }
 
 const char* itwVersion(void) { return "itw-amd 0.1 gfx950 arith=x86-lut-nr contract=off"; }
 
@@ -696,6 +712,13 @@ int64_t itwBandForPartEx(int32_t width, int32_t height, int32_t bytes_per_block,
     return r0 * bx * bytes_per_block;
 }
 
+void itwWarmupBC45(void)
+{
+    itwClearError();
+    itw::guarded([&] { bind_thread_to_current_device(); itw::warmup_bc45(); });
+}
+
+#ifdef ITW_TEST_HOOKS      // libispc_texcomp_test.so only (include/itw_test_hooks.h)
 int itwTestBc45IndexTable(uint32_t* host_out)
 {
     itwClearError();
@@ -730,5 +753,6 @@ void itwTestF2I(const float* in, int32_t* out, int64_t n)
     hipLaunchKernelGGL(k_test_f2i, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, tls.user_stream, in, out, n);
     itw::guarded([&] { ITW_CHECK(hipGetLastError()); });
 }
+#endif // ITW_TEST_HOOKS
 
 } // extern "C"

@@ -523,8 +523,10 @@ static unsigned bc13_grid(int64_t n)
     return (unsigned)(chunks < BC13_GRID ? chunks : BC13_GRID);
 }
 
-// SMALL: positive stride and every texel row below 2 GiB from the base (16384^2 RGBA8 is 1 GiB): 32-bit offsets
-static bool bc13_small(int64_t stride, int height) { return stride > 0 && (int64_t)height * stride < ((int64_t)1 << 31); }
+// SMALL: positive stride and every texel row below 2 GiB from the base (16384^2 RGBA8 is 1 GiB): 32-bit offsets.  The output offset is
+// 32-bit on that path too: with rows that overlap (a positive stride below 4 * width, which the ABI tolerates) the block stream can
+// outgrow the texels, so it is bounded separately.
+static bool bc13_small(int64_t stride, int height, int64_t nblocks) { return stride > 0 && (int64_t)height * stride < ((int64_t)1 << 31) && nblocks * 16 < ((int64_t)1 << 32); }
 
 // VEC16 requires: src base and stride multiples of 16, dst multiple of 16 (BC3) / 8 (BC1).
 void launch_bc1(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st)
@@ -534,7 +536,7 @@ void launch_bc1(const uint8_t* src, int64_t stride, int width, int height, uint8
     if (n <= 0) return;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7) == 0;
     const dim3 grid(bc13_grid(n)), blk(256);
-    if (bc13_small(stride, height)) {
+    if (bc13_small(stride, height, n)) {
         if (vec) hipLaunchKernelGGL((bc13_kernel<false, true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
         else     hipLaunchKernelGGL((bc13_kernel<false, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
     } else {
@@ -550,7 +552,7 @@ void launch_bc3(const uint8_t* src, int64_t stride, int width, int height, uint8
     if (n <= 0) return;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const dim3 grid(bc13_grid(n)), blk(256);
-    if (bc13_small(stride, height)) {
+    if (bc13_small(stride, height, n)) {
         if (vec) hipLaunchKernelGGL((bc13_kernel<true, true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
         else     hipLaunchKernelGGL((bc13_kernel<true, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst);
     } else {

@@ -95,7 +95,11 @@ __global__ void __launch_bounds__(256) bc45_build_index_table(uint4* __restrict_
 struct TableSlot { std::once_flag once; uint4* table = nullptr; };
 TableSlot g_tables[64];
 
-const uint4* index_table(hipStream_t st)
+// Built once per device on a stream of the library's own (not on the caller's -- the first call used to synchronise the user's
+// stream): the first BC4 / BC5 call on a device, or itwWarmupBC45(), blocks its HOST thread until the table exists; the caller's stream is
+// never synchronised and later calls are plain asynchronous launches.  That one call allocates device memory, so it cannot run inside a
+// stream capture: warm up first (include/itw_bc45.h).
+const uint4* index_table()
 {
     int dev = 0;
     ITW_CHECK(hipGetDevice(&dev));
@@ -103,11 +107,15 @@ const uint4* index_table(hipStream_t st)
     TableSlot& s = g_tables[dev];
     std::call_once(s.once, [&] {                                  // an exception leaves the flag unset: the next call retries
         uint4* t = nullptr;
-        ITW_CHECK(hipMalloc(&t, 65536 * sizeof(uint4)));
-        hipLaunchKernelGGL(bc45_build_index_table, dim3(256), dim3(256), 0, st, t);
+        hipStream_t own = nullptr;
+        ITW_CHECK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+        hipError_t e = hipMalloc(&t, 65536 * sizeof(uint4));
+        if (e != hipSuccess) { (void)hipStreamDestroy(own); fail_hip("hipMalloc (BC4/BC5 index table)", e, __FILE__, __LINE__); }
+        hipLaunchKernelGGL(bc45_build_index_table, dim3(256), dim3(256), 0, own, t);
         std::vector<uint4> h(65536);
-        hipError_t e = hipMemcpyAsync(h.data(), t, 65536 * sizeof(uint4), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);        // later calls use the table from any stream
+        e = hipMemcpyAsync(h.data(), t, 65536 * sizeof(uint4), hipMemcpyDeviceToHost, own);
+        if (e == hipSuccess) e = hipStreamSynchronize(own);       // complete before any later launch, on whatever stream
+        (void)hipStreamDestroy(own);
         if (e != hipSuccess) { (void)hipFree(t); fail_hip("bc45_build_index_table", e, __FILE__, __LINE__); }
         for (const uint4& v : h)
             if ((v.y >> 24) < 1u || (v.y >> 24) > 8u) { (void)hipFree(t); fail_msg("BC4/BC5 index table: an endpoint pair has %u runs (at most 8 expected)", v.y >> 24); }
@@ -387,7 +395,7 @@ void launch_bc45(const uint8_t* src, int64_t stride, int width, int height, uint
     const int bx = (width + 3) / 4, by = (height + 3) / 4;       // DirectXTex keeps partial blocks
     const int64_t n = (int64_t)bx * by * NCH;
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride) & 15) == 0;
-    const uint4* runs = index_table(st);
+    const uint4* runs = index_table();
     const int64_t chunks = (n + 255) / 256;
     const dim3 grid((unsigned)(chunks < BC45_GRID ? chunks : BC45_GRID)), blk(256);
     // WHOLE: no partial blocks and every texel offset fits 31 bits (a non-negative stride; 16384^2 RGBA8 is 1 GiB)
@@ -406,12 +414,16 @@ void launch_bc45(const uint8_t* src, int64_t stride, int width, int height, uint
 void launch_bc4(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st) { launch_bc45<1>(src, stride, width, height, dst, st); }
 void launch_bc5(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st) { launch_bc45<2>(src, stride, width, height, dst, st); }
 
-// test hook (include/itw_bc45.h): the run table of the current device, 65 536 entries x 4 words, to host memory
+void warmup_bc45() { (void)index_table(); }
+
+#ifdef ITW_TEST_HOOKS
+// test hook (include/itw_test_hooks.h): the run table of the current device, 65 536 entries x 4 words, to host memory
 void copy_bc45_index_table(uint32_t* host_out, hipStream_t st)
 {
-    const uint4* t = index_table(st);
+    const uint4* t = index_table();
     ITW_CHECK(hipMemcpyAsync(host_out, t, 65536 * sizeof(uint4), hipMemcpyDeviceToHost, st));
     ITW_CHECK(hipStreamSynchronize(st));
 }
+#endif
 
 } // namespace itw

@@ -1141,6 +1141,17 @@ __device__ __forceinline__ void load_block(Tex& tx, const uint8_t* __restrict__ 
     tx.make_planar();
 }
 
+// Round 5: the blocks a finish phase lists for a later scan also leave their 64 B of texels in a compact buffer, in list order, so the
+// list scans (up to 8 shares per block) and their refinement read contiguous lines instead of gathering 64 B out of every 128 B line
+template <bool = true>
+__device__ __forceinline__ void load_block_compact(Tex& tx, const uint4* __restrict__ compact, int32_t slot)
+{
+    const uint4* p = compact + (int64_t)slot * 4;
+#pragma unroll
+    for (int y = 0; y < 4; y++) { const uint4 v = p[y]; tx.w[y * 4 + 0] = v.x; tx.w[y * 4 + 1] = v.y; tx.w[y * 4 + 2] = v.z; tx.w[y * 4 + 3] = v.w; }
+    tx.make_planar();
+}
+
 // winners of a family's two modes: [slot][block] x {err, shape}  (8 B; the workspace keeps its 16 B slots)
 __device__ __forceinline__ void store_win(uint4* __restrict__ wins, int32_t nblocks, int slot, int32_t b, const Win& w)
 {
@@ -1360,6 +1371,31 @@ __device__ __forceinline__ void merge_packed_parts(Win& w, Lane& ln, const uint3
 
 struct ScanTasks { int n; int kind[3]; };      // WK_SCAN02 / WK_SCAN13 / WK_SCAN7 in launch order
 
+// Round 5, the PILOT of the bounded order (launch_bc7): which chunks (runs of TPB blocks) of the surface a launch of bc7_scan_all /
+// bc7_finish_all walks, and whether it runs at all.
+//   kind 0  every chunk: workgroup i -> chunk i
+//   kind 1  the SAMPLE: one chunk out of every full group of `period` chunks, at an offset that moves from group to group (5 g mod period:
+//           a fixed offset would sample one column of a surface whose rows hold a multiple of `period` chunks)
+//   kind 2  the REST: every other chunk (and the chunks behind the last full group)
+// `gate` (optional): a device word written by bc7_pilot_decide before this launch starts; the launch returns at once unless it holds
+// `want` -- both mode orders are enqueued behind the pilot and the device picks one, without a host round trip.
+struct ChunkSel { int32_t kind, period, groups; const int32_t* gate; int32_t want; };
+__device__ __forceinline__ int32_t sel_chunk(const ChunkSel& s, int32_t i)
+{
+    if (s.kind == 0) return i;
+    if (s.kind == 1) return i * s.period + (int32_t)(((uint32_t)i * 5u) % (uint32_t)s.period);
+    const int32_t per = s.period - 1, full = s.groups * per;
+    if (i >= full) return s.groups * s.period + (i - full);
+    const int32_t g = i / per, k = i - g * per, off = (int32_t)(((uint32_t)g * 5u) % (uint32_t)s.period);
+    return g * s.period + k + (k >= off ? 1 : 0);
+}
+// the pilot's verdict: 1 = bounded order for the rest of the surface (few enough of the sample's blocks still need modes 1/3), 0 = the
+// reference's order.  `listed` blocks of `sampled`; threshold in 1/256.
+__global__ void bc7_pilot_decide(const int32_t* __restrict__ listed, int32_t sampled, int32_t thr256, int32_t* __restrict__ flag)
+{
+    *flag = ((int64_t)*listed * 256 <= (int64_t)thr256 * sampled) ? 1 : 0;
+}
+
 // FAM7 = false: the three-channel families {0,2} and {1,3} (4 waves per SIMD; ranked lists 3); FAM7 = true: the mode 7 scan
 // alone (four-channel fits need the registers of 3 waves per SIMD; sharing a kernel with the others made those spill).
 __host__ __device__ constexpr int scan_all_waves(bool ranked, bool fam7) { return fam7 ? (ranked ? SWR27 : SW7) : (ranked ? SWR2 : SWALL); }
@@ -1367,11 +1403,13 @@ template <bool VEC16, bool RANKED_LISTS, bool FAM7>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(scan_all_waves(RANKED_LISTS, FAM7), scan_all_waves(RANKED_LISTS, FAM7))))
 bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint32_t* __restrict__ wins4,
              const bc7_enc_settings S, const ScanTasks tasks, const int ranked13, const int ranked7, const int32_t nchunks, const int32_t grain,
-             const int32_t* __restrict__ rgb_list, const int32_t* __restrict__ rgb_count, const int32_t split)
+             const int32_t* __restrict__ rgb_list, const int32_t* __restrict__ rgb_count, const int32_t split, const ChunkSel sel,
+             const uint4* __restrict__ compact)
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
     __shared__ uint2 s_pal[((RANKED_LISTS && ITW_BC7_LANE_PAL) ? 16 : 12) * TPB];   // ranked lists: 2 subsets x 8 levels (3 waves per SIMD: 3 x 44 KiB)
+    if (sel.gate && *sel.gate != sel.want) return;                  // the pilot chose the other order (whole grid: no barrier is pending)
     if (!RANKED_LISTS && split) {
         // bounded order: modes 1/3 (or mode 7: FAM7) over the list bc7_finish_all<.., 3 | 5 | 6> left, each listed block's 64 shapes cut
         // into `parts` strided shares (list_scan_parts) so that a short list still fills the chip; winners go to [part][slot] of the modes' rows
@@ -1389,7 +1427,7 @@ bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, 
         const int32_t slot = live ? gid : count - 1;
         ln.keys = nullptr;
         ln.pal = s_pal + threadIdx.x;
-        load_block<VEC16>(ln.tx, src, stride, blocks_x, rgb_list[slot]);
+        if (compact) load_block_compact(ln.tx, compact, slot); else load_block<VEC16>(ln.tx, src, stride, blocks_x, rgb_list[slot]);
         Win wa, wb;
         if (FAM7) {
             search_two_subset<true, 4, 0>(ln, S, wa, wb, part, parts);             // RGBA profiles only (launch_bc7)
@@ -1407,8 +1445,9 @@ bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, 
     // families run on the same XCD: workgroup w -> XCD w % 8)
     const uint32_t w = blockIdx.x, per = (uint32_t)grain * (uint32_t)tasks.n, group = w / per, r = w % per;
     const int t = (int)(r / (uint32_t)grain);
-    const int32_t chunk = (int32_t)(group * (uint32_t)grain + r % (uint32_t)grain);
-    if (chunk >= nchunks) return;                                    // whole workgroup: no barrier is pending
+    const int32_t chunk_i = (int32_t)(group * (uint32_t)grain + r % (uint32_t)grain);
+    if (chunk_i >= nchunks) return;                                  // whole workgroup: no barrier is pending
+    const int32_t chunk = sel_chunk(sel, chunk_i);                   // nchunks counts the chunks `sel` selects
     // RGBA profile, alpha-capable modes already encoded (bc7_finish_all<.., 1>): an RGB-only mode's error includes
     // sum (alpha - 255)^2 (kernel.ispc:1267-1277, 1356), so where that term alone exceeds the alpha modes' best error no
     // three-channel mode can win or tie.  Round 3: finish<1> COMPACTS the blocks where an RGB mode can still win or tie into
@@ -1443,16 +1482,19 @@ bc7_scan_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, 
 }
 
 // appends block `b` of the lanes with `need` to a list: one atomic per wave, ranks within the wave by ballot (any order: blocks are independent)
-__device__ __forceinline__ void append_to_list(int32_t* __restrict__ list, int32_t* __restrict__ count, bool need, int32_t b)
+// returns the block's position in the list (-1: not appended)
+__device__ __forceinline__ int32_t append_to_list(int32_t* __restrict__ list, int32_t* __restrict__ count, bool need, int32_t b)
 {
     const unsigned long long m = __ballot(need);
+    int32_t pos = -1;
     if (m) {
         const int lane = (int)(threadIdx.x & 63u);
         int32_t base = 0;
         if (lane == 0) base = atomicAdd(count, (int32_t)__popcll(m));
         base = __shfl(base, 0);
-        if (need) list[base + (int32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
+        if (need) { pos = base + (int32_t)__popcll(m & ((1ull << lane) - 1ull)); list[pos] = b; }
     }
+    return pos;
 }
 
 // PHASE 0: every mode, reference order (RGB profiles).  RGBA profiles run in two phases so that the three-channel modes can be
@@ -1478,6 +1520,23 @@ __device__ __forceinline__ void append_to_list(int32_t* __restrict__ list, int32
 // The final block is the reference's first strict minimum over 0,2,1,3,7,4,5,6 either way: a mode's result enters only through
 // `err < best_err`, the groups keep their internal order, and a skipped block's modes 1/3 cannot reach inc whatever shape their scan would
 // have picked (every encoding of every shape is bounded).
+// Round 5: mode 6 under an RGB profile (kernel.ispc:1657-1689, channels == 3) decodes every texel to a ROUNDED point of ONE segment in RGB,
+// so its error is >= (sqrt(R) - sqrt(3)/2 sqrt(16))_+^2 with R the block's residual about its best line (subset_residual_bound: the same
+// number the two-subset bound is built from, for the whole block), and it replaces the block only on a strict `<`.  Where that bound has
+// already been reached by the modes before it for all 64 blocks of the wave, mode 6 is not run (per-lane skipping saves nothing on a SIMT
+// machine).  profiles/r05_bc7_bound456_study.txt: 100 % of the bench surface's blocks (noise in every block: three subsets beat one line),
+// 56-64 % of a photograph's; modes 4/5 cannot be bounded out this way (15 % / 1 %: their scalar channel absorbs the noise).
+__device__ __forceinline__ bool mode6_cannot_win(Lane& ln)
+{
+    if (__all(ln.best_err == 0)) return true;
+    IStats<3> full;
+    stats_int<3>(full, ln.tx.pl, whole_block());
+    const float d = __builtin_amdgcn_sqrtf(subset_residual_bound(full) * rcp_of_count(16)) * 0.999999f - BOUND_SLACK3[16];
+    const float e = fmaxf(d, 0.0f);
+    const float lb = e * e * 0.999999f;
+    return __all(lb >= (float)ln.best_err);                        // errors are integers below 2^24: exact as floats
+}
+
 #ifndef FINISH_ALL_WAVES
 #define FINISH_ALL_WAVES 2
 #endif
@@ -1492,7 +1551,8 @@ __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(FINISH
 bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint8_t* __restrict__ dst,
                const uint32_t* __restrict__ wins4, const bc7_enc_settings S, int32_t* __restrict__ inc_err,
                const int32_t* __restrict__ in_list, const int32_t* __restrict__ in_count, int32_t* __restrict__ out_list, int32_t* __restrict__ out_count,
-               int32_t* __restrict__ out_list7, int32_t* __restrict__ out_count7)
+               int32_t* __restrict__ out_list7, int32_t* __restrict__ out_count7, const ChunkSel sel,
+               const uint4* __restrict__ in_compact, uint4* __restrict__ out_compact)
 {
     constexpr bool LISTED = PHASE == 2 || PHASE == 4 || PHASE == 5 || PHASE == 7;   // walks a compacted list of an earlier phase
     constexpr bool DO02 = PHASE == 0 || PHASE == 2 || PHASE == 3 || PHASE == 5;
@@ -1502,18 +1562,19 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
     __shared__ uint2 s_pal[(ITW_BC7_LANE_PAL ? LANE_PAL_LEVELS : 8) * TPB];   // refinement: a palette per subset of the lane's winner
+    if (sel.gate && *sel.gate != sel.want) return;                   // the pilot chose the other order (whole grid: no barrier is pending)
     const int32_t nact = LISTED ? *in_count : nblocks;
     if (LISTED && (int32_t)(blockIdx.x * TPB) >= nact) return;       // whole workgroup, before any barrier
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
-    const int32_t gid = blockIdx.x * TPB + threadIdx.x;
+    const int32_t gid = (LISTED ? (int32_t)blockIdx.x : sel_chunk(sel, (int32_t)blockIdx.x)) * TPB + threadIdx.x;
     const bool live = gid < nact;
     const int32_t slot = live ? gid : nact - 1;
     const int32_t b = LISTED ? in_list[slot] : slot;
     ln.keys = nullptr;
     ln.pal = s_pal + threadIdx.x;
-    load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
+    if (LISTED && in_compact) load_block_compact(ln.tx, in_compact, slot); else load_block<VEC16>(ln.tx, src, stride, blocks_x, b);
     ln.best_err = ERR_MAX;
     ln.best[0] = ln.best[1] = ln.best[2] = ln.best[3] = 0u;
     ln.improved = false;
@@ -1554,7 +1615,10 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
     if (DO456) {
         ln.tx.fence();
         if (S.mode_selection[2]) modes_45(ln, S);
-        if (S.mode_selection[3]) { if (S.channels == 4) mode_6<4>(ln, S); else mode_6<3>(ln, S); }
+        if (S.mode_selection[3]) {
+            if (S.channels == 4) mode_6<4>(ln, S);
+            else if (!mode6_cannot_win(ln)) mode_6<3>(ln, S);
+        }
     }
     if (PHASE == 1) {
         if (live) inc_err[b] = ln.best_err;
@@ -1591,7 +1655,12 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
             need = need || !(lb >= lim);
             need7 = need7 || !(lb >= lim7);
         }
-        append_to_list(out_list, out_count, live && need, b);
+        const int32_t pos = append_to_list(out_list, out_count, live && need, b);
+        if (out_compact && pos >= 0) {                              // the listed block's texels, in list order (load_block_compact)
+            uint4* c = out_compact + (int64_t)pos * 4;
+#pragma unroll
+            for (int y = 0; y < 4; y++) c[y] = make_uint4(ln.tx.w[y * 4 + 0], ln.tx.w[y * 4 + 1], ln.tx.w[y * 4 + 2], ln.tx.w[y * 4 + 3]);
+        }
         if (with7) append_to_list(out_list7, out_count7, live && need7, b);
     }
     bool store = live;
@@ -1824,7 +1893,8 @@ static void launch_finish(Bc7Launch& L)
 
 // 0 = by size, 1 = deep always, 2 = wide whenever it supports the settings (itwSetBc7Path / ITW_BC7_PATH=deep|wide:
 // tests and probes)
-// test hook (itwTestBc7TwoSubsetBounds): two_subset_bound of every two-subset shape of every block, out[block * 64 + shape]
+#ifdef ITW_TEST_HOOKS
+// test hook (itwTestBc7TwoSubsetBounds, libispc_texcomp_test.so only): two_subset_bound of every two-subset shape of every block, out[block * 64 + shape]
 template <bool VEC16>
 __global__ void __launch_bounds__(TPB) bc7_test_bounds(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, float* __restrict__ out)
 {
@@ -1850,6 +1920,7 @@ void launch_bc7_test_bounds(const uint8_t* src, int64_t stride, int width, int h
     if (vec) hipLaunchKernelGGL((bc7_test_bounds<true>),  grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, out);
     else     hipLaunchKernelGGL((bc7_test_bounds<false>), grid, dim3(TPB), 0, st, src, stride, bx, (int32_t)n, out);
 }
+#endif // ITW_TEST_HOOKS
 
 static std::atomic<int> g_bc7_path{-1};
 static int bc7_path_override()
@@ -1870,6 +1941,31 @@ void set_bc7_path(int v) { g_bc7_path.store(v == 1 || v == 2 ? v : 0, std::memor
 static bool bc7_bounded_order()
 {
     static const bool on = [] { const char* e = std::getenv("ITW_BC7_BOUND"); return !(e && e[0] == '0'); }();
+    return on;
+}
+// Round 5.  ITW_BC7_PILOT_THR: the pilot's threshold in percent of the sample's blocks that still need modes 1/3 -- at or below it the rest of
+// the surface takes the bounded order, above it the reference's; -1 = no pilot (always bounded), 0 = pilot, always the reference's order for the
+// rest, 100 = pilot, always bounded (tools/round5/gpu_pilot.sh measures both ends).  Returned in 1/256.
+#ifndef ITW_BC7_PILOT_THR_DEFAULT
+#define ITW_BC7_PILOT_THR_DEFAULT 75
+#endif
+static std::atomic<int> g_bc7_pilot{-2};           // percent; -2 = not read yet
+static int bc7_pilot_threshold()
+{
+    int pct = g_bc7_pilot.load(std::memory_order_relaxed);
+    if (pct == -2) {
+        const char* e = std::getenv("ITW_BC7_PILOT_THR");
+        pct = e ? std::atoi(e) : ITW_BC7_PILOT_THR_DEFAULT;
+        pct = pct < 0 ? -1 : (pct > 100 ? 100 : pct);
+        g_bc7_pilot.store(pct, std::memory_order_relaxed);
+    }
+    return pct < 0 ? -1 : pct * 256 / 100;
+}
+void set_bc7_pilot(int percent) { g_bc7_pilot.store(percent < 0 ? -1 : (percent > 100 ? 100 : percent), std::memory_order_relaxed); }
+// ITW_BC7_COMPACT=0: the list scans gather their blocks from the surface (round 4) instead of reading the compact copy
+static bool bc7_compact_lists()
+{
+    static const bool on = [] { const char* e = std::getenv("ITW_BC7_COMPACT"); return !(e && e[0] == '0'); }();
     return on;
 }
 static bool bc7_alpha_first(const bc7_enc_settings& S)
@@ -1913,16 +2009,37 @@ static size_t wide_workspace_bytes(size_t n)
 {
     return (size_t)5 * wide_win_entries(n) * sizeof(uint4) + (((size_t)WIDE_SLOTS * n * sizeof(int32_t) + 15) & ~(size_t)15) + (size_t)WIDE_SLOTS * n * sizeof(uint4);
 }
+// fused shape, in 4-byte words from the start of the workspace (every region starts on a 16-byte boundary)
+constexpr int PILOT_PERIOD = 16;          // the pilot samples one chunk in 16 (launch_bc7)
+struct FusedLayout { size_t inc, list0, list1, list2, counts, listS, winsS, compactS, compact, words; };
+static FusedLayout fused_layout(size_t n)
+{
+    auto up4 = [](size_t w) { return (w + 3) & ~(size_t)3; };
+    const size_t nS = (n / TPB / PILOT_PERIOD + 1) * TPB;          // blocks of the pilot's sample, at most
+    FusedLayout W;
+    size_t o = up4(5 * n);                                         // 5 winner rows
+    W.inc = o;      o = up4(o + n);                                // a phase's error / incumbent
+    W.list0 = o;    o = up4(o + n);                                // three block lists
+    W.list1 = o;    o = up4(o + n);
+    W.list2 = o;    o = up4(o + n);
+    W.counts = o;   o += 16;                                       // list lengths, the pilot's list length and verdict
+    W.listS = o;    o = up4(o + nS);
+    W.winsS = o;    o = up4(o + 5 * nS);
+    W.compactS = o; o += 16 * nS;                                  // 64 B of texels per listed block
+    W.compact = o;  o += 16 * n;
+    W.words = o;
+    return W;
+}
 size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks)
 {
     const size_t n = (size_t)(width / 4) * (size_t)(height / 4);
     size_t deep = ((n * sizeof(int32_t) + 15) & ~(size_t)15) + 2 * n * sizeof(uint4);
-    const size_t fused = (size_t)9 * n * sizeof(int32_t) + 4 * sizeof(int32_t);     // 5 winner rows, incumbents, three block lists + their lengths
+    const size_t fused = fused_layout(n).words * sizeof(uint32_t);
     if (fused > deep) deep = fused;
     const size_t limit = bc7_path_override() == 2 ? ((size_t)1 << 20) : (wide_max_blocks > 0 ? (size_t)wide_max_blocks : (size_t)ITW_BC7_WIDE_MAX_BLOCKS);
     const bool may_wide = bc7_path_override() != 1 && n <= limit && n <= ((size_t)1 << 20);
     const size_t wide = may_wide ? wide_workspace_bytes(n) : 0;
-    return deep > wide ? deep : wide;
+    return (deep > wide ? deep : wide) + ((size_t)1 << 18);         // + room for the rounding of up to 8 bands' slices (ITW_BC7_DEEP_SPLIT)
 }
 
 static void launch_bc7_wide(const uint8_t* src, int64_t stride, int bx, int64_t n, uint8_t* dst, const bc7_enc_settings& S, float* workspace,
@@ -2018,8 +2135,25 @@ static void launch_bc7_wide(const uint8_t* src, int64_t stride, int bx, int64_t 
 }
 
 // Families run in the reference's order (kernel.ispc:1970-1977): {0,2} -> {1,3} -> {7} -> {4,5} -> {6}.
+static void launch_bc7_impl(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
+                            const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux, bool force_deep);
+
 void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                 const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux)
+{
+    launch_bc7_impl(src, stride, width, height, dst, s, workspace, st, aux, false);
+}
+
+// ITW_BC7_DEEP_SPLIT=K (probe, round 5): a deep call is cut into K bands of block rows, issued alternately on the caller's stream and the
+// second one, so that one band's launch tails overlap the other's work (each band is a complete call with its own slice of the workspace)
+static int bc7_deep_split()
+{
+    static const int k = [] { const char* e = std::getenv("ITW_BC7_DEEP_SPLIT"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+    return k;
+}
+
+static void launch_bc7_impl(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
+                            const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux, bool force_deep)
 {
     const int bx = width / 4, by = height / 4;
     const int64_t n = (int64_t)bx * by;
@@ -2027,7 +2161,22 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
     Bc7Launch L;
     L.S = s;
     L.S.channels = (s.channels == 4) ? 4 : 3;
-    if (bc7_use_wide(n, L.S, aux ? aux->wide_max_blocks : 0)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st, aux); return; }
+    if (!force_deep && bc7_use_wide(n, L.S, aux ? aux->wide_max_blocks : 0)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st, aux); return; }
+    if (!force_deep && bc7_deep_split() > 1 && aux && aux->stream && by >= 8 * bc7_deep_split()) {
+        const int K = bc7_deep_split();
+        ITW_CHECK(hipEventRecord(aux->fork, st));
+        ITW_CHECK(hipStreamWaitEvent(aux->stream, aux->fork, 0));
+        size_t off = 0;
+        for (int k = 0; k < K; k++) {
+            const int r0 = (int)((int64_t)by * k / K), r1 = (int)((int64_t)by * (k + 1) / K);
+            float* ws = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + off);
+            off += (bc7_workspace_bytes(width, (r1 - r0) * 4, 1) + 255) & ~(size_t)255;
+            launch_bc7_impl(src + (int64_t)r0 * 4 * stride, stride, width, (r1 - r0) * 4, dst + (int64_t)r0 * bx * 16, s, ws, (k & 1) ? aux->stream : st, nullptr, true);
+        }
+        ITW_CHECK(hipEventRecord(aux->join, aux->stream));
+        ITW_CHECK(hipStreamWaitEvent(st, aux->join, 0));
+        return;
+    }
     L.err = reinterpret_cast<int32_t*>(workspace);
     L.wins = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(workspace) + (((size_t)n * sizeof(int32_t) + 15) & ~(size_t)15));
     L.vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
@@ -2054,58 +2203,78 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             // Interleave grain, measured at 4096^2 `slow` (scan time / scan FETCH_SIZE): 8 chunks 6.01 ms / 76 MB (two code paths
             // alternate on every CU: instruction cache), 256 chunks 5.36 ms / 76 MB, 1024 chunks 5.38 ms / 166 MB (L2 no longer
             // holds the first family's texels), family-major 5.39 ms / 154 MB; two separate launches 5.45 ms.
-            const int32_t chunks8 = ((nchunks + 7) / 8) * 8;
-            int32_t grain = 256;
-            if (grain > chunks8) grain = chunks8;
-            const int32_t groups = (chunks8 + grain - 1) / grain;
             const int a13 = r13 ? 1 : 0, a7 = r7 ? 1 : 0;
-            int32_t* alpha_err = reinterpret_cast<int32_t*>(wins4 + (size_t)5 * n);            // [n] x 4 B behind the winner rows: a phase's error / incumbent
-            int32_t* rgb_list = alpha_err + n;                                                 // [n] block ids (RGBA profiles: where an RGB mode can win; RGB: where modes 1/3 can)
-            int32_t* list13 = rgb_list + n;                                                    // [n] block ids (RGBA profiles, bounded order)
-            int32_t* list7 = list13 + n;                                                       // [n] block ids (RGBA profiles, bounded order incl. mode 7)
-            int32_t* rgb_count = list7 + n;                                                    // the three lists' lengths
+            const FusedLayout W = fused_layout((size_t)n);
+            int32_t* alpha_err = reinterpret_cast<int32_t*>(wins4 + W.inc);                    // [n] x 4 B behind the winner rows: a phase's error / incumbent
+            int32_t* rgb_list = reinterpret_cast<int32_t*>(wins4 + W.list0);                   // [n] block ids (RGBA profiles: where an RGB mode can win; RGB: where modes 1/3 can)
+            int32_t* list13 = reinterpret_cast<int32_t*>(wins4 + W.list1);                     // [n] block ids (RGBA profiles, bounded order)
+            int32_t* list7 = reinterpret_cast<int32_t*>(wins4 + W.list2);                      // [n] block ids (RGBA profiles, bounded order incl. mode 7)
+            int32_t* rgb_count = reinterpret_cast<int32_t*>(wins4 + W.counts);                 // the lists' lengths, the pilot's list length and verdict
             int32_t* count13 = rgb_count + 1;
             int32_t* count7 = rgb_count + 2;
+            int32_t* countS = rgb_count + 3;
+            int32_t* pilot_flag = rgb_count + 4;
+            int32_t* listS = reinterpret_cast<int32_t*>(wins4 + W.listS);                      // the pilot sample's list for modes 1/3
+            uint32_t* winsS = wins4 + W.winsS;                                                 // ... and its list scan's winners: [5][nS]
+            uint4* compact13 = bc7_compact_lists() ? reinterpret_cast<uint4*>(wins4 + W.compact) : nullptr;   // texels of list13's blocks, in list order
+            uint4* compactS = bc7_compact_lists() ? reinterpret_cast<uint4*>(wins4 + W.compactS) : nullptr;
             const dim3 blk(TPB);
-            auto scan_rgb = [&](const int32_t* list, const int32_t* count, bool do13, bool do02, int32_t split = 0) {
+            const ChunkSel ALL{0, 1, 0, nullptr, 0};
+            // `sel`: which chunks (ChunkSel); `cnt`: how many chunks that is; `rows`: length of a winner row (n; the pilot sample's list scan has its own rows)
+            auto scan_rgb = [&](const int32_t* list, const int32_t* count, bool do13, bool do02, int32_t split = 0, ChunkSel sel = ChunkSel{0, 1, 0, nullptr, 0},
+                                int32_t cnt = -1, hipStream_t s = nullptr, uint32_t* wins = nullptr, int32_t rows = 0, const uint4* compact = nullptr) {
                 ScanTasks T;
                 T.n = 0;
                 if (on13 && do13) T.kind[T.n++] = WK_SCAN13;                   // longest first
                 if (on02 && do02) T.kind[T.n++] = WK_SCAN02;
                 if (T.n == 0) return;
+                if (cnt < 0) cnt = nchunks;
+                if (!s) s = st;
+                if (!wins) { wins = wins4; rows = (int32_t)n; }
+                const int32_t c8 = ((cnt + 7) / 8) * 8;
+                int32_t grain = 256;
+                if (grain > c8) grain = c8;
+                const int32_t groups = (c8 + grain - 1) / grain;
                 const dim3 grid((unsigned)(groups * grain * T.n));
                 if (r13) {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count, split);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count, split);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, false>),  grid, blk, 0, s, src, stride, bx, rows, wins, S, T, a13, a7, cnt, grain, list, count, split, sel, compact);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, false>), grid, blk, 0, s, src, stride, bx, rows, wins, S, T, a13, a7, cnt, grain, list, count, split, sel, compact);
                 } else {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, false>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count, split);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T, a13, a7, nchunks, grain, list, count, split);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, false>),  grid, blk, 0, s, src, stride, bx, rows, wins, S, T, a13, a7, cnt, grain, list, count, split, sel, compact);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, false>), grid, blk, 0, s, src, stride, bx, rows, wins, S, T, a13, a7, cnt, grain, list, count, split, sel, compact);
                 }
             };
             auto scan_7 = [&](const int32_t* list = nullptr, const int32_t* count = nullptr, int32_t split = 0) {
                 if (!on7) return;
                 ScanTasks T7;
                 T7.n = 1; T7.kind[0] = WK_SCAN7;
+                const int32_t chunks8 = ((nchunks + 7) / 8) * 8;
                 const dim3 grid((unsigned)chunks8);
                 if (r7) {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split, ALL, (const uint4*)nullptr);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split, ALL, (const uint4*)nullptr);
                 } else {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split, ALL, (const uint4*)nullptr);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split, ALL, (const uint4*)nullptr);
                 }
             };
+            // a finish phase: list phases launch one workgroup per possible list chunk (they return at once behind the list's end)
             auto finish = [&](auto phase, const int32_t* in_list, const int32_t* in_count, int32_t* out_list, int32_t* out_count,
-                              int32_t* out_list7 = nullptr, int32_t* out_count7 = nullptr) {
+                              int32_t* out_list7 = nullptr, int32_t* out_count7 = nullptr, ChunkSel sel = ChunkSel{0, 1, 0, nullptr, 0}, int32_t cnt = -1,
+                              hipStream_t s = nullptr, const uint32_t* wins = nullptr, int32_t rows = 0, const uint4* in_compact = nullptr, uint4* out_compact = nullptr) {
                 constexpr int PH = decltype(phase)::value;
-                if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true, PH>),  L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, in_list, in_count, out_list, out_count, out_list7, out_count7);
-                else       hipLaunchKernelGGL((bc7_finish_all<false, PH>), L.grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, wins4, S, alpha_err, in_list, in_count, out_list, out_count, out_list7, out_count7);
+                if (cnt < 0) cnt = nchunks;
+                if (!s) s = st;
+                if (!wins) { wins = wins4; rows = (int32_t)n; }
+                const dim3 grid((unsigned)cnt);
+                if (L.vec) hipLaunchKernelGGL((bc7_finish_all<true, PH>),  grid, blk, 0, s, src, stride, bx, rows, dst, wins, S, alpha_err, in_list, in_count, out_list, out_count, out_list7, out_count7, sel, in_compact, out_compact);
+                else       hipLaunchKernelGGL((bc7_finish_all<false, PH>), grid, blk, 0, s, src, stride, bx, rows, dst, wins, S, alpha_err, in_list, in_count, out_list, out_count, out_list7, out_count7, sel, in_compact, out_compact);
             };
             // the bounded order (bc7_finish_all's header): profiles whose modes 1/3 scan every shape -- a ranked list already spends
             // a bound's worth of arithmetic per shape on its keys and then fits a few shapes only
             const bool bounded = bc7_bounded_order() && on02 && on13 && !r13;
             if (bc7_alpha_first(S)) {
-                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 3 * sizeof(int32_t), st));  // the finish phases append to the lists through them
+                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 8 * sizeof(int32_t), st));  // the finish phases append to the lists through them
                 if (bounded && on7 && !r7 && (S.mode_selection[2] || S.mode_selection[3])) {
                     // mode 7 bounded too: modes 4,5,6 | 0,2 first, then 1,3 and 7 each over its own list
                     finish(std::integral_constant<int, 6>{}, nullptr, nullptr, rgb_list, rgb_count, list7, count7);
@@ -2129,11 +2298,44 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                     }
                 }
             } else if (bounded && !on7) {
-                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 3 * sizeof(int32_t), st));
-                scan_rgb(nullptr, nullptr, false, true);
-                finish(std::integral_constant<int, 3>{}, nullptr, nullptr, list13, count13);
-                scan_rgb(list13, count13, true, false, 1);
-                finish(std::integral_constant<int, 4>{}, list13, count13, nullptr, nullptr);
+                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 8 * sizeof(int32_t), st));
+                const int period = PILOT_PERIOD;
+                const int32_t gS = nchunks / period;                        // the pilot's sample: one chunk of every full group of `period`
+                if (bc7_pilot_threshold() >= 0 && aux && aux->stream && aux->mid && gS >= 1) {
+                    // PILOT (round 5).  The bounded order pays where modes 1/3 can be ruled out for many blocks and costs 4-6 % where they cannot
+                    // (photographs: 94 % of the blocks still visit them, and the order's split launches are then pure overhead).  Which it is
+                    // shows in a sample: 1/16 of the chunks, spread over the surface, run the bounded order on the second stream while the {0,2}
+                    // scan of the rest -- common to both orders -- runs on the first; bc7_pilot_decide turns the sample's list length into a
+                    // device word, and both continuations of the rest are enqueued behind it, each gated on that word (ChunkSel.gate): the
+                    // one the pilot did not choose returns at once.  No host round trip; the sample's blocks are finished by the bounded
+                    // order whatever the verdict (same bytes either way).
+                    const ChunkSel SAMPLE{1, period, gS, nullptr, 0}, REST{2, period, gS, nullptr, 0};
+                    const ChunkSel REST_BOUNDED{2, period, gS, pilot_flag, 1}, REST_PLAIN{2, period, gS, pilot_flag, 0};
+                    const int32_t nS = gS * TPB, cR = nchunks - gS;
+                    hipStream_t s2 = aux->stream;
+                    ITW_CHECK(hipEventRecord(aux->fork, st));                  // whatever feeds `src` on st (an upload), and the memset above
+                    ITW_CHECK(hipStreamWaitEvent(s2, aux->fork, 0));
+                    scan_rgb(nullptr, nullptr, false, true, 0, SAMPLE, gS, s2);
+                    finish(std::integral_constant<int, 3>{}, nullptr, nullptr, listS, countS, nullptr, nullptr, SAMPLE, gS, s2, nullptr, 0, nullptr, compactS);
+                    hipLaunchKernelGGL(bc7_pilot_decide, dim3(1), dim3(1), 0, s2, countS, nS, bc7_pilot_threshold(), pilot_flag);
+                    ITW_CHECK(hipEventRecord(aux->mid, s2));
+                    scan_rgb(listS, countS, true, false, 1, ALL, gS, s2, winsS, nS, compactS);
+                    finish(std::integral_constant<int, 4>{}, listS, countS, nullptr, nullptr, nullptr, nullptr, ALL, gS, s2, winsS, nS, compactS);
+                    ITW_CHECK(hipEventRecord(aux->join, s2));
+                    scan_rgb(nullptr, nullptr, false, true, 0, REST, cR);
+                    ITW_CHECK(hipStreamWaitEvent(st, aux->mid, 0));
+                    finish(std::integral_constant<int, 3>{}, nullptr, nullptr, list13, count13, nullptr, nullptr, REST_BOUNDED, cR, nullptr, nullptr, 0, nullptr, compact13);
+                    scan_rgb(list13, count13, true, false, 1, ALL, -1, nullptr, nullptr, 0, compact13);     // an empty list under the plain order: returns at once
+                    finish(std::integral_constant<int, 4>{}, list13, count13, nullptr, nullptr, nullptr, nullptr, ALL, -1, nullptr, nullptr, 0, compact13);
+                    scan_rgb(nullptr, nullptr, true, false, 0, REST_PLAIN, cR);
+                    finish(std::integral_constant<int, 0>{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, REST_PLAIN, cR);
+                    ITW_CHECK(hipStreamWaitEvent(st, aux->join, 0));
+                } else {
+                    scan_rgb(nullptr, nullptr, false, true);
+                    finish(std::integral_constant<int, 3>{}, nullptr, nullptr, list13, count13, nullptr, nullptr, ALL, -1, nullptr, nullptr, 0, nullptr, compact13);
+                    scan_rgb(list13, count13, true, false, 1, ALL, -1, nullptr, nullptr, 0, compact13);
+                    finish(std::integral_constant<int, 4>{}, list13, count13, nullptr, nullptr, nullptr, nullptr, ALL, -1, nullptr, nullptr, 0, compact13);
+                }
             } else {
                 scan_rgb(nullptr, nullptr, true, true);
                 scan_7();

@@ -14,6 +14,7 @@ void launch_bc3 (const uint8_t* src, int64_t stride, int width, int height, uint
 // width/height >= 1: ceil(width/4) x ceil(height/4) blocks, partial blocks replicated by DirectXTex's rule.
 void launch_bc4 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
 void launch_bc5 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst, hipStream_t st);
+void warmup_bc45();                                               // builds the current device's FindClosestUNORM run table now (else: first call)
 void copy_bc45_index_table(uint32_t* host_out, hipStream_t st);   // test hook: the FindClosestUNORM run table of the current device
 // BC7 runs as up to seven kernels (search + finish per multi-subset mode family, one for modes 4/5/6) that hand
 // "best error so far" and the search winners to each other through
@@ -22,9 +23,13 @@ size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks = 0); 
 // BC7 launch shape: 0 = by call size (default), 1 = deep (one lane per block, a launch pair per mode family: fills the
 // chip on whole surfaces), 2 = wide (split scans + ordered argmin: small calls).  Same blocks either way.
 void set_bc7_path(int path);
+// The pilot of the bounded BC7 mode order (bc7.hip, launch_bc7): percent of the sample's blocks that may still need modes 1/3 for the rest of
+// the surface to take the bounded order; -1 = no pilot, the whole call in the bounded order.  Same blocks whatever the value.
+void set_bc7_pilot(int percent);
 // `aux` (optional): a second stream of the same device plus two events the launcher may use to run independent parts of a
 // small call side by side; everything is joined back into `st` before the launcher returns.
-struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; };   // wide_max_blocks: 0 = the library default
+// `mid` (may be null: no pilot): a third event, for the pilot of the bounded mode order (bc7.hip).
+struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; hipEvent_t mid; };   // wide_max_blocks: 0 = the library default
 void launch_bc7 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                  const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux = nullptr);
 // test hook: bc7_exact.hpp's two_subset_bound of all 64 two-subset shapes of every block, out[block * 64 + shape] (device memory)

@@ -39,6 +39,9 @@
 #include <vector>
 #include "../../include/itw_multigpu.h"
 #include "../../include/itw_amd.h"
+#ifdef ITW_TEST_HOOKS
+#include "../../include/itw_test_hooks.h"
+#endif
 #include "host_rt.hpp"
 
 namespace {
@@ -100,7 +103,7 @@ struct RankCtx {
     bool peers_enabled = false;
     bool pending = false, failed = false;
     std::atomic<int> stage{0};                             // 0 idle / running, 1 prepared, 2 everything posted, 3 done
-    double posted_ms = 0.0;
+    std::atomic<double> posted_ms{0.0};             // written by the rank thread, read by the submitting thread (stats)
     itw_multigpu_rank_stats st{};
     char msg[384] = {0};
 };
@@ -311,7 +314,7 @@ void run_rank(RankCtx& c, const Call& k)
     c.stage.store(1);
     if (k.fail_rank == c.rank && k.fail_stage == 3)      // a rank that neither fails nor proceeds: the watchdog's case
         for (int waited = 0; waited < k.stall_ms && !g.abort.load(); waited += 20) std::this_thread::sleep_for(std::chrono::milliseconds(20));
-    if (idle) { c.posted_ms = ms_since(g.t0); c.stage.store(2); return; }
+    if (idle) { c.posted_ms.store(ms_since(g.t0)); c.stage.store(2); return; }
 
     // ---- TRANSFER + ENCODE ----
     // Posting order: upload 0, encode 0 | upload 1 on the transfer stream (runs under encode 0), encode 1 | gather 0, gather 1 on
@@ -376,8 +379,14 @@ void run_rank(RankCtx& c, const Call& k)
             for (int s = 0; s < 2; s++) {
                 mark(c, T_RECV, s, 0, c.xfer);
                 with_comm(c.rank, [&](ncclComm_t comm) {
+                    // an abort that could not take this communicator's mutex within its two seconds frees the handle
+                    // under us; looking at the flag and the handle again before every RCCL call keeps the exposure to the ONE call that
+                    // is in flight at that moment (which is the call the abort exists to release)
+                    auto still_ours = [&] { if (g.abort.load() || g.comms[c.rank].load() != comm) itw::fail_msg("stopped: another rank failed"); };
+                    still_ours();
                     ITW_NCCL(g.rccl.GroupStart());
                     for (int p = 0; p < k.ranks; p++) {
+                        still_ours();
                         if (p == c.rank) continue;
                         int p0, p1, pc[3];
                         band_rows(by, p, k.ranks, p0, p1);
@@ -386,12 +395,13 @@ void run_rank(RankCtx& c, const Call& k)
                         if (pc[s + 1] <= pc[s]) continue;
                         ITW_NCCL(g.rccl.Recv(k.output + (size_t)pc[s] * bx * k.bpb, (size_t)(pc[s + 1] - pc[s]) * bx * k.bpb, ncclUint8, p, comm, c.xfer));
                     }
+                    still_ours();
                     ITW_NCCL(g.rccl.GroupEnd());
                 });
                 mark(c, T_RECV, s, 1, c.xfer);
             }
         }
-        c.posted_ms = ms_since(g.t0);
+        c.posted_ms.store(ms_since(g.t0));
         c.stage.store(2);
         ITW_CHECK(hipStreamSynchronize(c.enc));
         ITW_CHECK(hipStreamSynchronize(c.xfer));
@@ -562,7 +572,7 @@ bool compress_multi(const rgba_surface* input, uint8_t* output, CompressionFunc*
             g.call = k;
             g.t0 = Clock::now();
             g.ready = 0; g.prepare_failed = false; g.abort.store(false);
-            for (int i = 0; i < n; i++) { RankCtx* c = g.ranks[(size_t)i]; c->pending = true; c->failed = false; c->stage.store(0); c->posted_ms = 0.0; }
+            for (int i = 0; i < n; i++) { RankCtx* c = g.ranks[(size_t)i]; c->pending = true; c->failed = false; c->stage.store(0); c->posted_ms.store(0.0); }
             g.outstanding = n;
         }
         g.work.notify_all();
@@ -601,7 +611,7 @@ bool compress_multi(const rgba_surface* input, uint8_t* output, CompressionFunc*
                 const RankCtx* c = g.ranks[(size_t)i];
                 if (c->stage.load() == 3) stats->rank[i] = c->st;
                 else { stats->rank[i] = itw_multigpu_rank_stats{}; stats->rank[i].rank = i; stats->rank[i].device = c->device; }
-                if (c->posted_ms > posted) posted = c->posted_ms;
+                if (c->stage.load() >= 2 && c->posted_ms.load() > posted) posted = c->posted_ms.load();
             }
             stats->posted_ms = (float)posted;
             if (k.use_rccl) {
@@ -648,10 +658,12 @@ const char* itwMultiGpuTransport(void) { return g.transport; }
 
 int itwMultiGpuPeerLinks(void) { return g.peer_links.load(); }
 
+#ifdef ITW_TEST_HOOKS      // libispc_texcomp_test.so only (include/itw_test_hooks.h); in the product nothing ever arms the injection
 void itwMultiGpuTestInjectFailure(int rank, int stage, int stall_ms)
 {
     g.inject_stage.store(stage); g.inject_stall.store(stall_ms); g.inject_rank.store(rank);
 }
+#endif
 
 bool itwCompressImageMultiGPU(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks)
 {

@@ -4,6 +4,7 @@ import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.normpath(os.path.join(_PKG, "..", "lib", "libispc_texcomp.so"))
+_TEST_LIB = os.path.normpath(os.path.join(_PKG, "..", "lib", "libispc_texcomp_test.so"))
 
 BYTES_PER_BLOCK = {"bc1": 8, "bc3": 16, "bc7": 16, "bc6h": 16, "bc4": 8, "bc5": 16}
 KEEPS_PARTIAL_BLOCKS = ("bc4", "bc5")     # DirectXTex formats: ceil(w/4) x ceil(h/4) blocks (include/itw_bc45.h)
@@ -15,9 +16,8 @@ BC6H_PROFILES = ("veryfast", "fast", "basic", "slow", "veryslow")
 EXPORTED_SYMBOLS = tuple(
     ["CompressBlocksBC1", "CompressBlocksBC3", "CompressBlocksBC6H", "CompressBlocksBC7"]
     + ["GetProfile_" + p for p in BC7_PROFILES] + ["GetProfile_bc6h_" + p for p in BC6H_PROFILES]
-    + ["itwSetStream", "itwGetStream", "itwAvailable", "itwSetErrorMode", "itwLastError", "itwClearError", "itwSetBc7Path",
-       "itwDeviceInfo", "itwVersion", "itwBandForPart", "itwBandForPartEx",
-       "itwTestRcp", "itwTestRsqrt", "itwTestF2I", "itwTestBc7TwoSubsetBounds"]
+    + ["itwSetStream", "itwGetStream", "itwAvailable", "itwSetErrorMode", "itwLastError", "itwClearError", "itwSetBc7Path", "itwSetBc7Pilot",
+       "itwDeviceInfo", "itwVersion", "itwBandForPart", "itwBandForPartEx"]
     # include/itw_dispatch.h: the reference's dispatch layer (win32Threads.h), slice loop, pad pre-pass
     + ["GetProcessorCount", "InitWin32Threads", "DestroyThreads", "GetBytesPerBlock", "CompressImageMT", "CompressImageST",
        "CompressImageBC1", "CompressImageBC3", "CompressImageBC4", "CompressImageBC5"]
@@ -25,14 +25,15 @@ EXPORTED_SYMBOLS = tuple(
     + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
        "itwConvertToRGBA8Device", "itwConvertToRGBA16FDevice"]
     # include/itw_multigpu.h: one surface over all GPUs, one process
-    + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU", "itwCompressImageMultiGPUEx",
-       "itwMultiGpuTestInjectFailure"]
+    + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU", "itwCompressImageMultiGPUEx"]
     # include/itw_bc45.h: the DirectXTex formats of the plugin
-    + ["CompressBlocksBC4", "CompressBlocksBC5", "itwTestBc45IndexTable"]
+    + ["CompressBlocksBC4", "CompressBlocksBC5", "itwWarmupBC45"]
     # include/itw_decode.h: device decoders
     + ["itwDecodeBlocks"]
     # include/itw_dds.h: DDS container
     + ["itwDdsLevelBytes", "itwDdsHeaderBytes", "itwDdsFileBytes", "itwDdsWriteHeader", "itwDdsReadHeader", "itwDdsWriteFile"])
+# include/itw_test_hooks.h: exported by libispc_texcomp_test.so only (the same sources built with -DITW_TEST_HOOKS), never by the product
+TEST_HOOK_SYMBOLS = ("itwTestRcp", "itwTestRsqrt", "itwTestF2I", "itwTestBc7TwoSubsetBounds", "itwTestBc45IndexTable", "itwMultiGpuTestInjectFailure")
 
 
 
@@ -95,6 +96,7 @@ COMPRESSION_FUNC = C.CFUNCTYPE(None, C.POINTER(RgbaSurface), C.c_void_p)
 PROGRESS_FUNC = C.CFUNCTYPE(C.c_bool, C.c_int, C.c_int, C.c_void_p)
 
 _lib = None
+_test_lib = None
 
 
 def lib_path():
@@ -102,20 +104,34 @@ def lib_path():
 
 
 def lib():
-    """Load libispc_texcomp.so; raises (never falls back) when it has not been built."""
+    """Load libispc_texcomp.so (the product); raises (never falls back) when it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB):
+        _lib = _load(_LIB, hooks=False)
+    return _lib
+
+
+def test_lib():
+    """Load libispc_texcomp_test.so: the product's sources built with -DITW_TEST_HOOKS, which adds the entry points of
+    include/itw_test_hooks.h.  A second, independent instance of the library in the process; tests/ use it for the hook calls only."""
+    global _test_lib
+    if _test_lib is None:
+        _test_lib = _load(_TEST_LIB, hooks=True)
+    return _test_lib
+
+
+def _load(path, hooks):
+    if True:
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{_LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C intel-texture-works-plugin_amd/csrc`.  There is no CPU fallback.")
-        L = C.CDLL(_LIB, mode=C.RTLD_GLOBAL)
+        L = C.CDLL(path, mode=C.RTLD_LOCAL if hooks else C.RTLD_GLOBAL)
         L.CompressBlocksBC1.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
         L.CompressBlocksBC4.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
         L.CompressBlocksBC5.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
         L.CompressBlocksBC4.restype = None
-        L.itwTestBc45IndexTable.argtypes = [C.c_void_p]
-        L.itwTestBc45IndexTable.restype = C.c_int
+        L.itwWarmupBC45.restype = None
         L.CompressBlocksBC5.restype = None
         L.CompressBlocksBC3.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
         L.CompressBlocksBC7.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.POINTER(Bc7Settings)]
@@ -133,16 +149,23 @@ def lib():
         L.itwClearError.restype = None
         L.itwSetBc7Path.argtypes = [C.c_int]
         L.itwSetBc7Path.restype = None
+        L.itwSetBc7Pilot.argtypes = [C.c_int]
+        L.itwSetBc7Pilot.restype = None
         L.itwVersion.restype = C.c_char_p
         L.itwBandForPart.argtypes = [C.c_int32] * 5 + [C.POINTER(C.c_int32)] * 2
         L.itwBandForPart.restype = C.c_int64
         L.itwBandForPartEx.argtypes = [C.c_int32] * 6 + [C.POINTER(C.c_int32)] * 2
         L.itwBandForPartEx.restype = C.c_int64
-        for n in ("itwTestRcp", "itwTestRsqrt", "itwTestF2I"):
-            getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
-            getattr(L, n).restype = None
-        L.itwTestBc7TwoSubsetBounds.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
-        L.itwTestBc7TwoSubsetBounds.restype = None
+        if hooks:
+            for n in ("itwTestRcp", "itwTestRsqrt", "itwTestF2I"):
+                getattr(L, n).argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+                getattr(L, n).restype = None
+            L.itwTestBc7TwoSubsetBounds.argtypes = [C.POINTER(RgbaSurface), C.c_void_p]
+            L.itwTestBc7TwoSubsetBounds.restype = None
+            L.itwTestBc45IndexTable.argtypes = [C.c_void_p]
+            L.itwTestBc45IndexTable.restype = C.c_int
+            L.itwMultiGpuTestInjectFailure.argtypes = [C.c_int, C.c_int, C.c_int]
+            L.itwMultiGpuTestInjectFailure.restype = None
         # dispatch layer (itw_dispatch.h)
         L.GetProcessorCount.restype = C.c_int
         L.GetBytesPerBlock.argtypes = [C.c_int]
@@ -165,8 +188,6 @@ def lib():
         L.itwCompressImageMultiGPUEx.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(RgbaSurface),
                                                  C.POINTER(MultiGpuStats)]
         L.itwCompressImageMultiGPUEx.restype = C.c_bool
-        L.itwMultiGpuTestInjectFailure.argtypes = [C.c_int, C.c_int, C.c_int]
-        L.itwMultiGpuTestInjectFailure.restype = None
         L.itwPadToMultipleOf4.argtypes = [C.POINTER(RgbaSurface), C.c_int]
         L.itwPadToMultipleOf4.restype = RgbaSurface
         L.itwFreeSurface.argtypes = [C.POINTER(RgbaSurface)]
@@ -191,8 +212,7 @@ def lib():
         L.itwDdsReadHeader.restype = C.c_size_t
         L.itwDdsWriteFile.argtypes = [C.POINTER(DdsDesc), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_size_t]
         L.itwDdsWriteFile.restype = C.c_size_t
-        _lib = L
-    return _lib
+    return L
 
 
 def version():
@@ -215,6 +235,12 @@ def source_sha256():
 
 ON_ERROR_ABORT, ON_ERROR_RETURN = 0, 1
 BC7_PATH = {"auto": 0, "deep": 1, "wide": 2}
+
+
+def set_bc7_pilot(percent):
+    """itwSetBc7Pilot: threshold of the bounded mode order's pilot in percent (0 = reference order for the rest of the surface, 100 = bounded,
+    -1 = no pilot, None = the library default); same bytes whatever the value."""
+    lib().itwSetBc7Pilot(75 if percent is None else int(percent))
 
 
 def set_bc7_path(name):
@@ -337,21 +363,22 @@ def bc7_two_subset_bounds(img):
     assert img.stride(2) == 1 and img.stride(1) == 4
     h, w = img.shape[:2]
     out = torch.empty(((h // 4) * (w // 4), 64), dtype=torch.float32, device=img.device)
-    L = lib()
+    L = test_lib()
     with torch.cuda.device(img.device):
         L.itwSetStream(torch.cuda.current_stream(img.device).cuda_stream)
         surf = RgbaSurface(img.data_ptr(), w, h, img.stride(0))
         L.itwTestBc7TwoSubsetBounds(C.byref(surf), out.data_ptr())
-    if last_error():
-        raise RuntimeError(last_error())
+    e = L.itwLastError()
+    if e:
+        raise RuntimeError(e.decode())
     return out
 
 
-def image_func(fmt, profile=None):
-    """Address of the CompressImage* trampoline (win32Threads.h:58-80) for a format / profile, as a void*."""
+def image_func(fmt, profile=None, L=None):
+    """Address of the CompressImage* trampoline (win32Threads.h:58-80) for a format / profile, as a void* (L: the library instance, default the product)."""
     name = {"bc1": "CompressImageBC1", "bc3": "CompressImageBC3", "bc4": "CompressImageBC4", "bc5": "CompressImageBC5"}.get(fmt) or \
         ("CompressImageBC7_" if fmt == "bc7" else "CompressImageBC6H_") + (profile or "slow")
-    return C.cast(getattr(lib(), name), C.c_void_p)
+    return C.cast(getattr(L or lib(), name), C.c_void_p)
 
 
 def compress_image(fmt, img, profile=None, multithreaded=True, slice_pixels=0, progress=None):
@@ -367,12 +394,14 @@ def compress_image(fmt, img, profile=None, multithreaded=True, slice_pixels=0, p
     return bool(ok), out
 
 
-def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None, bands=None, stats=None):
+def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None, bands=None, stats=None, L=None):
     """itwCompressImageMultiGPU[Ex]: img is a host numpy array or a CUDA torch tensor (H, W, 4); the block stream comes back in
     the same kind of container (or in `out`, which may be the other kind).  Synchronous.
     bands: optional list of CUDA tensors, band r of the image resident on device r % device_count (no scatter; `img` may then be
-    a (height, width) tuple).  stats: an optional MultiGpuStats to fill (stats.as_dict())."""
+    a (height, width) tuple).  stats: an optional MultiGpuStats to fill (stats.as_dict()).  L: the library instance (default: the product;
+    the failure-injection tests pass test_lib(), whose hook arms that instance)."""
     import numpy as np
+    L = L or lib()
     if bands is not None:
         import torch
         h, w = (img if isinstance(img, tuple) else img.shape[:2])
@@ -402,12 +431,13 @@ def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None, bands=Non
         torch.cuda.synchronize(img.device)            # the rank threads read the texels on their own streams
     surf = RgbaSurface(src_ptr, w, h, stride)
     if bands is None and stats is None:
-        ok = lib().itwCompressImageMultiGPU(C.byref(surf), dst_ptr, image_func(fmt, profile), DXGI_FORMAT[fmt], ranks)
+        ok = L.itwCompressImageMultiGPU(C.byref(surf), dst_ptr, image_func(fmt, profile, L), DXGI_FORMAT[fmt], ranks)
     else:
-        ok = lib().itwCompressImageMultiGPUEx(C.byref(surf), dst_ptr, image_func(fmt, profile), DXGI_FORMAT[fmt], ranks, arr,
-                                              C.byref(stats) if stats is not None else None)
+        ok = L.itwCompressImageMultiGPUEx(C.byref(surf), dst_ptr, image_func(fmt, profile, L), DXGI_FORMAT[fmt], ranks, arr,
+                                          C.byref(stats) if stats is not None else None)
     if not ok:
-        raise RuntimeError(last_error() or "itwCompressImageMultiGPU failed")
+        e = L.itwLastError()
+        raise RuntimeError((e.decode() if e else None) or "itwCompressImageMultiGPU failed")
     return out
 
 

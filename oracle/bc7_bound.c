@@ -54,3 +54,22 @@ float oracle_bc7_two_subset_bound(const float block[64], int shape)
     }
     return total * 0.999999f;
 }
+
+/* Round 5: the same bound for ONE segment through the whole block (csrc/bc7.hip mode6_cannot_win).  Under an RGB profile (channels == 3) a
+ * mode 6 encoding decodes every texel to floor(L + 1/2) per colour channel with L on the segment between its two endpoints
+ * (kernel.ispc:1657-1689 through block_quant, :1133-1193): rounded points of one line in RGB, so its error is at least
+ * (sqrt(R) - sqrt(3)/2 sqrt(16))_+^2 with R the residual of the 16 texels about their best line.  Mode 6 replaces the block only on a strict
+ * `<` (:1684), so where this number has been reached by the modes before it, mode 6 need not run. */
+float oracle_bc7_one_line_bound(const float block[64])
+{
+    int32_t m[6] = {0}, s[3] = {0};
+    for (int k = 0; k < 16; k++) {
+        const int32_t r = (int32_t)block[k], g = (int32_t)block[16 + k], b = (int32_t)block[32 + k];
+        m[0] += r * r; m[1] += r * g; m[2] += r * b; m[3] += g * g; m[4] += g * b; m[5] += b * b;
+        s[0] += r; s[1] += g; s[2] += b;
+    }
+    const float slack = (float)(0.8660254037844386 * 4.0 * (1.0 + 1e-6));
+    const float d = sqrtf(residual_bound_n(m, s, 16) * (1.0f / 16.0f) * 0.9999999f) * 0.999999f - slack;
+    const float e = fmaxf(d, 0.0f);
+    return e * e * 0.999999f;
+}

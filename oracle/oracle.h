@@ -63,6 +63,7 @@ void oracle_bc1_block(const float block[48], uint32_t data[2]);
 void oracle_bc3_alpha_block(const float alpha[16], uint32_t data[2]);
 void oracle_bc7_block(const float block[64], const oracle_bc7_settings* s, uint32_t data[4], float* best_err);
 float oracle_bc7_two_subset_bound(const float block[64], int shape);   /* bc7_bound.c: restatement of the product's bounded-order bound */
+float oracle_bc7_one_line_bound(const float block[64]);                /* bc7_bound.c: ... and of the bound that lets mode 6 be skipped (RGB profiles) */
 void oracle_bc7_part_fast_errors(const float block[64], int mode, float err[64], int32_t key[64]);   /* study / test hook */
 void oracle_bc6h_block(const float block[64], const oracle_bc6h_settings* s, uint32_t data[4], float* best_err);
 

@@ -262,3 +262,84 @@ def test_float_restatement_never_exceeds_the_bound_in_exact_arithmetic():
         assert (lb <= exact[b] + 1e-9).all(), (b, int(np.argmax(lb - exact[b])), float((lb - exact[b]).max()))
         worst = max(worst, float((exact[b] - lb).max()))
     assert worst > 0
+
+
+# ---- round 5: the one-line bound that lets mode 6 be skipped under an RGB profile (csrc/bc7.hip mode6_cannot_win) -------------------------
+
+def _one_line(L):
+    L.oracle_bc7_one_line_bound.argtypes = [C.c_void_p]
+    L.oracle_bc7_one_line_bound.restype = C.c_float
+    return L.oracle_bc7_one_line_bound
+
+
+def _mode6_only():
+    s = pyoracle.bc7_profile("slow")
+    s.mode_selection[0] = 0; s.mode_selection[1] = 0; s.mode_selection[2] = 0; s.mode_selection[3] = 1
+    return s
+
+
+@pytest.mark.parametrize("name,img", list(sample_images()), ids=[n for n, _ in sample_images()])
+def test_one_line_bound_never_exceeds_the_oracles_mode_6_error(name, img):
+    """mode 6 alone (RGB profile, every refinement count from 0 to the slow profile's 4): its error is never below the bound"""
+    L = lib()
+    f = _one_line(L)
+    blocks = planar_blocks(img)
+    data = (C.c_uint32 * 4)()
+    e = C.c_float()
+    L.oracle_bc7_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_bc7_block.restype = None
+    s = _mode6_only()
+    tight = 0
+    for it in (0, 1, 4):
+        s.refineIterations[6] = it
+        for b in range(blocks.shape[0]):
+            lb = f(blocks[b].ctypes.data)
+            L.oracle_bc7_block(blocks[b].ctypes.data, C.byref(s), data, C.byref(e))
+            assert 0.0 <= lb <= e.value, (name, it, b, lb, e.value)
+            tight += lb > 0.5 * e.value
+    if name == "ldr_smooth":
+        assert tight > 0.5 * 3 * blocks.shape[0]
+
+
+def test_one_line_bound_on_random_blocks_and_against_exact_arithmetic():
+    """20 000 seeded random blocks of five kinds: bound <= the oracle's mode 6 error, and the fp32 number never exceeds the same bound in
+    float64 with the exact largest eigenvalue; brute-force 4-bit palettes from arbitrary integer endpoints stay above it too"""
+    rng = np.random.default_rng(606)
+    n = 4000
+    kinds = [rng.integers(0, 256, (n, 16, 3))]
+    a, b = rng.integers(0, 256, (n, 1, 3)), rng.integers(0, 256, (n, 1, 3))
+    kinds.append(np.where(rng.integers(0, 2, (n, 16, 1)) == 1, a, b) + rng.integers(-3, 4, (n, 16, 3)))
+    gx, gy = np.meshgrid(np.arange(4), np.arange(4))
+    g = (gx.reshape(1, 16, 1) * rng.integers(-40, 41, (n, 1, 3)) + gy.reshape(1, 16, 1) * rng.integers(-40, 41, (n, 1, 3)))
+    kinds.append(rng.integers(40, 216, (n, 1, 3)) + g + rng.integers(-2, 3, (n, 16, 3)))
+    kinds.append(rng.integers(0, 256, (n, 1, 3)) + rng.integers(-12, 13, (n, 16, 3)))
+    t = np.arange(16).reshape(1, 16, 1) * rng.integers(-17, 18, (n, 1, 3)) + rng.integers(0, 256, (n, 1, 3))      # exactly collinear (before clipping)
+    kinds.append(t)
+    L = lib()
+    f = _one_line(L)
+    data = (C.c_uint32 * 4)()
+    e = C.c_float()
+    L.oracle_bc7_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_bc7_block.restype = None
+    s = _mode6_only()
+    w4 = np.array([0, 4, 9, 13, 17, 21, 26, 30, 34, 38, 43, 47, 51, 55, 60, 64])
+    for tex in kinds:
+        tex = np.clip(tex, 0, 255).astype(np.float64)
+        x = tex - tex.mean(axis=1, keepdims=True)
+        c = np.einsum("bki,bkj->bij", x, x)
+        r = np.maximum(np.trace(c, axis1=1, axis2=2) - np.linalg.eigvalsh(c)[:, -1], 0)
+        exact = np.maximum(np.sqrt(r) - np.sqrt(3) / 2 * 4, 0) ** 2
+        blocks = np.zeros((n, 64), np.float32)
+        blocks[:, :48] = tex.transpose(0, 2, 1).reshape(n, 48)
+        blocks[:, 48:] = 255
+        for b in range(n):
+            lb = f(blocks[b].ctypes.data)
+            assert lb <= exact[b] + 1e-9, (b, lb, exact[b])
+            if b % 4 == 0:
+                L.oracle_bc7_block(blocks[b].ctypes.data, C.byref(s), data, C.byref(e))
+                assert lb <= e.value, (b, lb, e.value)
+            if b % 16 == 0:          # arbitrary endpoints, best level per texel (rounded as block_quant decodes them)
+                e0, e1 = rng.integers(0, 256, 3), rng.integers(0, 256, 3)
+                pal = ((64 - w4)[:, None] * e0[None, :] + w4[:, None] * e1[None, :] + 32) // 64
+                err = ((tex[b][:, None, :] - pal[None, :, :]) ** 2).sum(axis=2).min(axis=1).sum()
+                assert lb <= err, (b, lb, err)

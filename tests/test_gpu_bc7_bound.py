@@ -88,3 +88,84 @@ def test_bounded_order_on_noisy_and_natural_content(itw, gpu, oracle, deep, gold
         want = oracle.encode_mt("bc7", img, prof)
         got = _encode(itw, gpu, img, prof)
         assert first_mismatch(got, want, 16) is None, first_mismatch(got, want, 16)
+
+
+# ---- round 5: the pilot that picks the mode order per call, the compact texel buffer of the list scans, mode 6 skipped by its bound -------
+
+def _mixed_content(golden_inputs, h, w):
+    """noise over smooth fields (few blocks need modes 1/3), a photograph (nearly all do), few-level content (ties between the modes) and
+    flat / two-colour blocks, side by side in bands so that the pilot's sample (one 256-block chunk in 16) sees all of them"""
+    from itw_amd import surfaces
+    rng = np.random.default_rng(5)
+    bab = golden_inputs["baboon"]
+    img = surfaces.ldr_smooth(h, w, seed=surfaces.SEED + 77).copy()
+    q = h // 4
+    nat = np.tile(bab, (-(-q // bab.shape[0]), -(-w // bab.shape[1]), 1))[:q, :w]
+    img[q:2 * q] = nat
+    img[2 * q:3 * q] = (img[2 * q:3 * q] // 64 * 64)
+    for y in range(3 * q, h - 3, 4):
+        for x in range(0, w - 3, 4):
+            a, b = rng.integers(0, 256, 4), rng.integers(0, 256, 4)
+            m = rng.integers(0, 2, (4, 4)).astype(bool) if (x // 4) % 3 else np.zeros((4, 4), bool)
+            img[y:y + 4, x:x + 4] = np.where(m[..., None], a[None, None, :], b[None, None, :])
+    img[..., 3] = 255
+    return np.ascontiguousarray(img)
+
+
+@pytest.mark.parametrize("pilot", [-1, 0, 100, None])
+def test_pilot_verdicts_and_compact_lists_emit_the_oracles_bytes(itw, gpu, oracle, deep, golden_inputs, pilot):
+    """`slow` through the fused shape with the pilot forced either way (0: the rest of the surface takes the reference's order, 100: the
+    bounded order), off (-1: round 4's whole-call bounded order) and at its default threshold: the same bytes as the oracle.  The surface
+    has a chunk count that is not a multiple of the pilot's period and a partial last chunk (604 x 516: 151 x 129 blocks = 76.1 chunks)."""
+    img = _mixed_content(golden_inputs, 516, 604)
+    want = oracle.encode_mt("bc7", img, "slow")
+    itw.set_bc7_pilot(pilot)
+    try:
+        got = _encode(itw, gpu, img, "slow")
+    finally:
+        itw.set_bc7_pilot(None)
+    assert first_mismatch(got, want, 16) is None, (pilot, first_mismatch(got, want, 16))
+
+
+def test_pilot_on_a_strided_surface_and_repeated_calls(itw, gpu, oracle, deep, golden_inputs):
+    """rows of the device surface further apart than their texels, both verdicts back to back on one stream (the workspace, the lists'
+    counters and the pilot's word are reused from call to call)"""
+    import torch
+    img = _mixed_content(golden_inputs, 260, 1028)
+    want = oracle.encode_mt("bc7", img, "slow")
+    wide = torch.zeros((260, 1100, 4), dtype=torch.uint8, device=gpu)
+    wide[:, :1028] = torch.from_numpy(img).to(gpu)
+    view = wide[:, :1028]
+    try:
+        for pilot in (0, 100, 0, None, -1):
+            itw.set_bc7_pilot(pilot)
+            out = itw.compress("bc7", view, "slow")
+            torch.cuda.synchronize()
+            assert first_mismatch(out.cpu().numpy(), want, 16) is None, pilot
+    finally:
+        itw.set_bc7_pilot(None)
+
+
+def test_mode_6_skipped_by_its_bound_changes_nothing(itw, gpu, oracle, deep):
+    """content where mode 6 wins most blocks (smooth one-line gradients), content where its bound rules it out everywhere (noise) and flat
+    blocks (error 0 everywhere): `slow` and a custom struct with modes 0/2 + 6 only"""
+    from itw_amd import surfaces
+    rng = np.random.default_rng(9)
+    g = np.linspace(0, 255, 256)
+    grad = np.stack([np.tile(g, (64, 1)), np.tile(g[::-1], (64, 1)), np.tile(g * 0.5 + 20, (64, 1)), np.full((64, 256), 255.0)], axis=2)
+    noise = rng.integers(0, 256, (64, 256, 4))
+    flat = np.tile(rng.integers(0, 256, (1, 64, 1, 4)).repeat(4, axis=1).reshape(1, 256, 4), (64, 1, 1))
+    img = np.concatenate([grad, noise, flat, surfaces.ldr_smooth(64, 256)], axis=0).astype(np.uint8)
+    img[..., 3] = 255
+    img = np.ascontiguousarray(img)
+    for prof in ("slow", None):
+        if prof is None:
+            s = itw.bc7_profile("slow")
+            s.mode_selection[1] = 0; s.mode_selection[2] = 0
+            o = oracle.bc7_profile("slow")
+            o.mode_selection[1] = 0; o.mode_selection[2] = 0
+        else:
+            s, o = prof, prof
+        want = oracle.encode("bc7", img, o)
+        got = _encode(itw, gpu, img, s)
+        assert first_mismatch(got, want, 16) is None, (prof, first_mismatch(got, want, 16))

@@ -87,15 +87,16 @@ def test_a_failing_rank_fails_the_call_and_never_hangs(itw, gpu, oracle, spec, d
     img = _img("bc7", 128, 64)
     want = oracle.encode("bc7", img, "veryfast").reshape(-1)
     out = torch.empty(want.size, dtype=torch.uint8, device=gpu) if device_out else None
-    itw.set_error_mode(itw.ON_ERROR_RETURN)
+    T = itw.test_lib()            # the build with the hooks (include/itw_test_hooks.h): its own instance of the library
+    T.itwSetErrorMode(itw.ON_ERROR_RETURN)
     r, st = (int(v) for v in spec.split(":"))
-    itw.lib().itwMultiGpuTestInjectFailure(r, st, 0)
+    T.itwMultiGpuTestInjectFailure(r, st, 0)
     try:
         with pytest.raises(RuntimeError, match="injected failure"):
-            itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, out=out)
+            itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, out=out, L=T)
     finally:
-        itw.set_error_mode(itw.ON_ERROR_ABORT)
-    got = itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, out=out)
+        T.itwSetErrorMode(itw.ON_ERROR_ABORT)
+    got = itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, out=out, L=T)
     if device_out:
         torch.cuda.synchronize()
         got = got.cpu().numpy()
@@ -139,14 +140,15 @@ def test_real_devices_failure_aborts_the_rccl_gather(itw, gpu, oracle):
     img = _img("bc7", 64 * n, 128)
     want = oracle.encode("bc7", img, "veryfast").reshape(-1)
     d = torch.from_numpy(img).to(gpu)
-    itw.set_error_mode(itw.ON_ERROR_RETURN)
-    itw.lib().itwMultiGpuTestInjectFailure(1, 2, 0)
+    T = itw.test_lib()            # the build with the hooks (include/itw_test_hooks.h): its own instance of the library
+    T.itwSetErrorMode(itw.ON_ERROR_RETURN)
+    T.itwMultiGpuTestInjectFailure(1, 2, 0)
     try:
         with pytest.raises(RuntimeError, match="injected failure"):
-            itw.compress_image_multigpu("bc7", d, "veryfast", ranks=n)
+            itw.compress_image_multigpu("bc7", d, "veryfast", ranks=n, L=T)
     finally:
-        itw.set_error_mode(itw.ON_ERROR_ABORT)
-    out = itw.compress_image_multigpu("bc7", d, "veryfast", ranks=n)
+        T.itwSetErrorMode(itw.ON_ERROR_ABORT)
+    out = itw.compress_image_multigpu("bc7", d, "veryfast", ranks=n, L=T)
     torch.cuda.synchronize()
     assert first_mismatch(out.cpu().numpy(), want, 16) is None
     assert itw.lib().itwMultiGpuTransport() == b"rccl"
@@ -224,18 +226,19 @@ def test_the_watchdog_ends_a_call_whose_rank_never_posts(itw, gpu, oracle, devic
     want = oracle.encode("bc7", img, "veryfast").reshape(-1)
     out = torch.empty(want.size, dtype=torch.uint8, device=gpu) if device_out else None
     monkeypatch.setenv("ITW_MULTIGPU_POST_TIMEOUT_S", "1")
-    itw.set_error_mode(itw.ON_ERROR_RETURN)
-    itw.lib().itwMultiGpuTestInjectFailure(2, 3, 15000)
+    T = itw.test_lib()            # the build with the hooks (include/itw_test_hooks.h): its own instance of the library
+    T.itwSetErrorMode(itw.ON_ERROR_RETURN)
+    T.itwMultiGpuTestInjectFailure(2, 3, 15000)
     st = itw.MultiGpuStats()
     t0 = time.perf_counter()
     try:
         with pytest.raises(RuntimeError, match="watchdog"):
-            itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, out=out, stats=st)
+            itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, out=out, stats=st, L=T)
     finally:
-        itw.set_error_mode(itw.ON_ERROR_ABORT)
+        T.itwSetErrorMode(itw.ON_ERROR_ABORT)
     assert time.perf_counter() - t0 < 8.0 and st.as_dict()["watchdog_fired"]
     monkeypatch.delenv("ITW_MULTIGPU_POST_TIMEOUT_S")
-    got = itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, out=out)
+    got = itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, out=out, L=T)
     if device_out:
         torch.cuda.synchronize()
         got = got.cpu().numpy()

@@ -126,7 +126,7 @@ def test_device_run_table_equals_the_table_of_the_search_as_written(itw, gpu, or
     from _bc45_runs import runs_table
     want, max_runs = runs_table(oracle.bc4_find_closest_table())
     got = np.zeros((65536, 4), dtype=np.uint32)
-    assert itw.lib().itwTestBc45IndexTable(got.ctypes.data) == 0
+    assert itw.test_lib().itwTestBc45IndexTable(got.ctypes.data) == 0     # hooks build (same sources, include/itw_test_hooks.h)
     assert max_runs == 8 and np.array_equal(got, want), np.flatnonzero((got != want).any(axis=1))[:8]
 
 
