@@ -1371,17 +1371,19 @@ __device__ __forceinline__ void merge_packed_parts(Win& w, Lane& ln, const uint3
 
 struct ScanTasks { int n; int kind[3]; };      // WK_SCAN02 / WK_SCAN13 / WK_SCAN7 in launch order
 
-// Round 5, the PILOT of the bounded order (launch_bc7): which chunks (runs of TPB blocks) of the surface a launch of bc7_scan_all /
-// bc7_finish_all walks, and whether it runs at all.
-//   kind 0  every chunk: workgroup i -> chunk i
+// Round 5, the PILOT and the BANDS of the bounded order (launch_bc7): which chunks (runs of TPB blocks) of the surface a launch of
+// bc7_scan_all / bc7_finish_all walks, and whether it runs at all.
+//   kind 0  every chunk: workgroup i -> chunk first + i
 //   kind 1  the SAMPLE: one chunk out of every full group of `period` chunks, at an offset that moves from group to group (5 g mod period:
 //           a fixed offset would sample one column of a surface whose rows hold a multiple of `period` chunks)
-//   kind 2  the REST: every other chunk (and the chunks behind the last full group)
+//   kind 2  the REST: every other chunk (and the chunks behind the last full group), enumerated in surface order; workgroup i takes the
+//           (first + i)-th of them, so that a band of the rest is a range [first, first + count) of that enumeration
 // `gate` (optional): a device word written by bc7_pilot_decide before this launch starts; the launch returns at once unless it holds
 // `want` -- both mode orders are enqueued behind the pilot and the device picks one, without a host round trip.
-struct ChunkSel { int32_t kind, period, groups; const int32_t* gate; int32_t want; };
+struct ChunkSel { int32_t kind, period, groups, first; const int32_t* gate; int32_t want; };
 __device__ __forceinline__ int32_t sel_chunk(const ChunkSel& s, int32_t i)
 {
+    i += s.first;
     if (s.kind == 0) return i;
     if (s.kind == 1) return i * s.period + (int32_t)(((uint32_t)i * 5u) % (uint32_t)s.period);
     const int32_t per = s.period - 1, full = s.groups * per;
@@ -1962,6 +1964,12 @@ static int bc7_pilot_threshold()
     return pct < 0 ? -1 : pct * 256 / 100;
 }
 void set_bc7_pilot(int percent) { g_bc7_pilot.store(percent < 0 ? -1 : (percent > 100 ? 100 : percent), std::memory_order_relaxed); }
+// ITW_BC7_BANDS=1: one band on the caller's stream, no pilot (round 4's launch order); default 2
+static int bc7_bands()
+{
+    static const int k = [] { const char* e = std::getenv("ITW_BC7_BANDS"); const int v = e ? std::atoi(e) : 2; return v < 2 ? 1 : 2; }();
+    return k;
+}
 // ITW_BC7_COMPACT=0: the list scans gather their blocks from the surface (round 4) instead of reading the compact copy
 static bool bc7_compact_lists()
 {
@@ -2011,22 +2019,36 @@ static size_t wide_workspace_bytes(size_t n)
 }
 // fused shape, in 4-byte words from the start of the workspace (every region starts on a 16-byte boundary)
 constexpr int PILOT_PERIOD = 16;          // the pilot samples one chunk in 16 (launch_bc7)
-struct FusedLayout { size_t inc, list0, list1, list2, counts, listS, winsS, compactS, compact, words; };
+// a list of blocks for modes 1/3 with what its split scan and refinement need: block ids [cap], winners of the scan's shares [5 rows][cap]
+// (rows 2, 3 used: list_scan_parts x listed <= cap), the listed blocks' texels [cap] x 64 B in list order
+struct ListRegion { size_t list, wins, compact, cap; };
+struct FusedLayout { size_t inc, list0, list1, list2, counts, words; ListRegion sample, band[2]; };
 static FusedLayout fused_layout(size_t n)
 {
     auto up4 = [](size_t w) { return (w + 3) & ~(size_t)3; };
-    const size_t nS = (n / TPB / PILOT_PERIOD + 1) * TPB;          // blocks of the pilot's sample, at most
+    const size_t nchunks = (n + TPB - 1) / TPB;
     FusedLayout W;
     size_t o = up4(5 * n);                                         // 5 winner rows
     W.inc = o;      o = up4(o + n);                                // a phase's error / incumbent
-    W.list0 = o;    o = up4(o + n);                                // three block lists
+    W.list0 = o;    o = up4(o + n);                                // three block lists (RGBA profiles)
     W.list1 = o;    o = up4(o + n);
     W.list2 = o;    o = up4(o + n);
-    W.counts = o;   o += 16;                                       // list lengths, the pilot's list length and verdict
-    W.listS = o;    o = up4(o + nS);
-    W.winsS = o;    o = up4(o + 5 * nS);
-    W.compactS = o; o += 16 * nS;                                  // 64 B of texels per listed block
-    W.compact = o;  o += 16 * n;
+    W.counts = o;   o += 16;                                       // list lengths, the pilot's verdict
+    auto region = [&](ListRegion& r, size_t chunks) {
+        r.cap = chunks * TPB;
+        r.list = o;    o = up4(o + r.cap);
+        r.wins = o;    o = up4(o + 5 * r.cap);
+        r.compact = o; o += 16 * r.cap;
+    };
+    region(W.sample, nchunks / PILOT_PERIOD + 1);                  // the pilot's sample
+    for (int k = 0; k < 2; k++) {                                  // the two bands of the rest: lists and share winners ...
+        ListRegion& r = W.band[k];
+        r.cap = (nchunks / 2 + 1) * TPB;
+        r.list = o;    o = up4(o + r.cap);
+        r.wins = o;    o = up4(o + 5 * r.cap);
+    }
+    W.band[0].compact = o; o += 16 * W.band[0].cap;                // ... and their texels, contiguous: a call without bands uses both as one
+    W.band[1].compact = o; o += 16 * W.band[1].cap;
     W.words = o;
     return W;
 }
@@ -2039,7 +2061,7 @@ size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks)
     const size_t limit = bc7_path_override() == 2 ? ((size_t)1 << 20) : (wide_max_blocks > 0 ? (size_t)wide_max_blocks : (size_t)ITW_BC7_WIDE_MAX_BLOCKS);
     const bool may_wide = bc7_path_override() != 1 && n <= limit && n <= ((size_t)1 << 20);
     const size_t wide = may_wide ? wide_workspace_bytes(n) : 0;
-    return (deep > wide ? deep : wide) + ((size_t)1 << 18);         // + room for the rounding of up to 8 bands' slices (ITW_BC7_DEEP_SPLIT)
+    return deep > wide ? deep : wide;
 }
 
 static void launch_bc7_wide(const uint8_t* src, int64_t stride, int bx, int64_t n, uint8_t* dst, const bc7_enc_settings& S, float* workspace,
@@ -2135,25 +2157,8 @@ static void launch_bc7_wide(const uint8_t* src, int64_t stride, int bx, int64_t 
 }
 
 // Families run in the reference's order (kernel.ispc:1970-1977): {0,2} -> {1,3} -> {7} -> {4,5} -> {6}.
-static void launch_bc7_impl(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
-                            const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux, bool force_deep);
-
 void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                 const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux)
-{
-    launch_bc7_impl(src, stride, width, height, dst, s, workspace, st, aux, false);
-}
-
-// ITW_BC7_DEEP_SPLIT=K (probe, round 5): a deep call is cut into K bands of block rows, issued alternately on the caller's stream and the
-// second one, so that one band's launch tails overlap the other's work (each band is a complete call with its own slice of the workspace)
-static int bc7_deep_split()
-{
-    static const int k = [] { const char* e = std::getenv("ITW_BC7_DEEP_SPLIT"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
-    return k;
-}
-
-static void launch_bc7_impl(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
-                            const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux, bool force_deep)
 {
     const int bx = width / 4, by = height / 4;
     const int64_t n = (int64_t)bx * by;
@@ -2161,22 +2166,7 @@ static void launch_bc7_impl(const uint8_t* src, int64_t stride, int width, int h
     Bc7Launch L;
     L.S = s;
     L.S.channels = (s.channels == 4) ? 4 : 3;
-    if (!force_deep && bc7_use_wide(n, L.S, aux ? aux->wide_max_blocks : 0)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st, aux); return; }
-    if (!force_deep && bc7_deep_split() > 1 && aux && aux->stream && by >= 8 * bc7_deep_split()) {
-        const int K = bc7_deep_split();
-        ITW_CHECK(hipEventRecord(aux->fork, st));
-        ITW_CHECK(hipStreamWaitEvent(aux->stream, aux->fork, 0));
-        size_t off = 0;
-        for (int k = 0; k < K; k++) {
-            const int r0 = (int)((int64_t)by * k / K), r1 = (int)((int64_t)by * (k + 1) / K);
-            float* ws = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(workspace) + off);
-            off += (bc7_workspace_bytes(width, (r1 - r0) * 4, 1) + 255) & ~(size_t)255;
-            launch_bc7_impl(src + (int64_t)r0 * 4 * stride, stride, width, (r1 - r0) * 4, dst + (int64_t)r0 * bx * 16, s, ws, (k & 1) ? aux->stream : st, nullptr, true);
-        }
-        ITW_CHECK(hipEventRecord(aux->join, aux->stream));
-        ITW_CHECK(hipStreamWaitEvent(st, aux->join, 0));
-        return;
-    }
+    if (bc7_use_wide(n, L.S, aux ? aux->wide_max_blocks : 0)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st, aux); return; }
     L.err = reinterpret_cast<int32_t*>(workspace);
     L.wins = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(workspace) + (((size_t)n * sizeof(int32_t) + 15) & ~(size_t)15));
     L.vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
@@ -2212,16 +2202,14 @@ static void launch_bc7_impl(const uint8_t* src, int64_t stride, int width, int h
             int32_t* rgb_count = reinterpret_cast<int32_t*>(wins4 + W.counts);                 // the lists' lengths, the pilot's list length and verdict
             int32_t* count13 = rgb_count + 1;
             int32_t* count7 = rgb_count + 2;
-            int32_t* countS = rgb_count + 3;
-            int32_t* pilot_flag = rgb_count + 4;
-            int32_t* listS = reinterpret_cast<int32_t*>(wins4 + W.listS);                      // the pilot sample's list for modes 1/3
-            uint32_t* winsS = wins4 + W.winsS;                                                 // ... and its list scan's winners: [5][nS]
-            uint4* compact13 = bc7_compact_lists() ? reinterpret_cast<uint4*>(wins4 + W.compact) : nullptr;   // texels of list13's blocks, in list order
-            uint4* compactS = bc7_compact_lists() ? reinterpret_cast<uint4*>(wins4 + W.compactS) : nullptr;
+            int32_t* band_count = rgb_count + 3;                                               // [2]: the bands' lists for modes 1/3
+            int32_t* countS = rgb_count + 5;                                                   // the pilot sample's
+            int32_t* pilot_flag = rgb_count + 6;
+            const bool compact_on = bc7_compact_lists();
             const dim3 blk(TPB);
-            const ChunkSel ALL{0, 1, 0, nullptr, 0};
+            const ChunkSel ALL{0, 1, 0, 0, nullptr, 0};
             // `sel`: which chunks (ChunkSel); `cnt`: how many chunks that is; `rows`: length of a winner row (n; the pilot sample's list scan has its own rows)
-            auto scan_rgb = [&](const int32_t* list, const int32_t* count, bool do13, bool do02, int32_t split = 0, ChunkSel sel = ChunkSel{0, 1, 0, nullptr, 0},
+            auto scan_rgb = [&](const int32_t* list, const int32_t* count, bool do13, bool do02, int32_t split = 0, ChunkSel sel = ChunkSel{0, 1, 0, 0, nullptr, 0},
                                 int32_t cnt = -1, hipStream_t s = nullptr, uint32_t* wins = nullptr, int32_t rows = 0, const uint4* compact = nullptr) {
                 ScanTasks T;
                 T.n = 0;
@@ -2260,7 +2248,7 @@ static void launch_bc7_impl(const uint8_t* src, int64_t stride, int width, int h
             };
             // a finish phase: list phases launch one workgroup per possible list chunk (they return at once behind the list's end)
             auto finish = [&](auto phase, const int32_t* in_list, const int32_t* in_count, int32_t* out_list, int32_t* out_count,
-                              int32_t* out_list7 = nullptr, int32_t* out_count7 = nullptr, ChunkSel sel = ChunkSel{0, 1, 0, nullptr, 0}, int32_t cnt = -1,
+                              int32_t* out_list7 = nullptr, int32_t* out_count7 = nullptr, ChunkSel sel = ChunkSel{0, 1, 0, 0, nullptr, 0}, int32_t cnt = -1,
                               hipStream_t s = nullptr, const uint32_t* wins = nullptr, int32_t rows = 0, const uint4* in_compact = nullptr, uint4* out_compact = nullptr) {
                 constexpr int PH = decltype(phase)::value;
                 if (cnt < 0) cnt = nchunks;
@@ -2298,43 +2286,72 @@ static void launch_bc7_impl(const uint8_t* src, int64_t stride, int width, int h
                     }
                 }
             } else if (bounded && !on7) {
+                // RGB profiles whose modes 1/3 scan every shape (`slow`).  Round 4: scan {0,2} -> finish<3> (modes 0,2,4,5,6; lists the blocks
+                // whose modes 1/3 an exact bound cannot exclude) -> scan {1,3} over the list -> finish<4>.  Round 5, with a second stream:
+                //  * PILOT.  The order pays where few blocks are listed and costs 4-6 % where nearly all are (photographs: 94 %; the split
+                //    launches are then pure overhead).  Which it is shows in a sample: one chunk in 16, spread over the surface, runs the
+                //    bounded order first; bc7_pilot_decide turns the sample's list length into a device word, and BOTH continuations of the
+                //    rest are enqueued behind it, each gated on that word (ChunkSel.gate): the one the pilot did not choose returns at once.
+                //    No host round trip; the sample's blocks are finished by the bounded order whatever the verdict (same bytes either way).
+                //  * BANDS.  The rest is cut into two bands, one per stream: a band's four dependent launches leave the chip partly empty at
+                //    every boundary (a scan wave runs 0.6 ms), and the other band's work fills those tails (measured: 5.23 -> 4.97 ms on the
+                //    bench surface, 7.30 -> 6.99 on a photograph; four bands are slower again).  Stream 1 = sample, then band A; stream 2 =
+                //    band B, whose {0,2} scan (common to both orders) hides the pilot; band B's continuations wait for the verdict's event.
                 ITW_CHECK(hipMemsetAsync(rgb_count, 0, 8 * sizeof(int32_t), st));
                 const int period = PILOT_PERIOD;
-                const int32_t gS = nchunks / period;                        // the pilot's sample: one chunk of every full group of `period`
-                if (bc7_pilot_threshold() >= 0 && aux && aux->stream && aux->mid && gS >= 1) {
-                    // PILOT (round 5).  The bounded order pays where modes 1/3 can be ruled out for many blocks and costs 4-6 % where they cannot
-                    // (photographs: 94 % of the blocks still visit them, and the order's split launches are then pure overhead).  Which it is
-                    // shows in a sample: 1/16 of the chunks, spread over the surface, run the bounded order on the second stream while the {0,2}
-                    // scan of the rest -- common to both orders -- runs on the first; bc7_pilot_decide turns the sample's list length into a
-                    // device word, and both continuations of the rest are enqueued behind it, each gated on that word (ChunkSel.gate): the
-                    // one the pilot did not choose returns at once.  No host round trip; the sample's blocks are finished by the bounded
-                    // order whatever the verdict (same bytes either way).
-                    const ChunkSel SAMPLE{1, period, gS, nullptr, 0}, REST{2, period, gS, nullptr, 0};
-                    const ChunkSel REST_BOUNDED{2, period, gS, pilot_flag, 1}, REST_PLAIN{2, period, gS, pilot_flag, 0};
-                    const int32_t nS = gS * TPB, cR = nchunks - gS;
-                    hipStream_t s2 = aux->stream;
-                    ITW_CHECK(hipEventRecord(aux->fork, st));                  // whatever feeds `src` on st (an upload), and the memset above
-                    ITW_CHECK(hipStreamWaitEvent(s2, aux->fork, 0));
-                    scan_rgb(nullptr, nullptr, false, true, 0, SAMPLE, gS, s2);
-                    finish(std::integral_constant<int, 3>{}, nullptr, nullptr, listS, countS, nullptr, nullptr, SAMPLE, gS, s2, nullptr, 0, nullptr, compactS);
-                    hipLaunchKernelGGL(bc7_pilot_decide, dim3(1), dim3(1), 0, s2, countS, nS, bc7_pilot_threshold(), pilot_flag);
-                    ITW_CHECK(hipEventRecord(aux->mid, s2));
-                    scan_rgb(listS, countS, true, false, 1, ALL, gS, s2, winsS, nS, compactS);
-                    finish(std::integral_constant<int, 4>{}, listS, countS, nullptr, nullptr, nullptr, nullptr, ALL, gS, s2, winsS, nS, compactS);
-                    ITW_CHECK(hipEventRecord(aux->join, s2));
-                    scan_rgb(nullptr, nullptr, false, true, 0, REST, cR);
-                    ITW_CHECK(hipStreamWaitEvent(st, aux->mid, 0));
-                    finish(std::integral_constant<int, 3>{}, nullptr, nullptr, list13, count13, nullptr, nullptr, REST_BOUNDED, cR, nullptr, nullptr, 0, nullptr, compact13);
-                    scan_rgb(list13, count13, true, false, 1, ALL, -1, nullptr, nullptr, 0, compact13);     // an empty list under the plain order: returns at once
-                    finish(std::integral_constant<int, 4>{}, list13, count13, nullptr, nullptr, nullptr, nullptr, ALL, -1, nullptr, nullptr, 0, compact13);
-                    scan_rgb(nullptr, nullptr, true, false, 0, REST_PLAIN, cR);
-                    finish(std::integral_constant<int, 0>{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, REST_PLAIN, cR);
-                    ITW_CHECK(hipStreamWaitEvent(st, aux->join, 0));
+                const bool two = bc7_bands() > 1 && aux && aux->stream && aux->mid && nchunks >= 32;
+                const bool pilot = two && bc7_pilot_threshold() >= 0;
+                const int32_t gS = pilot ? nchunks / period : 0;             // the pilot's sample: one chunk of every full group of `period`
+                const int32_t cR = nchunks - gS;                             // chunks of the rest
+                auto rest = [&](int32_t first, const int32_t* gate, int32_t want) { return ChunkSel{2, period, gS, first, gate, want}; };
+                struct Band { int32_t first, cnt; hipStream_t s; int32_t* list; int32_t* count; uint32_t* wins; int32_t rows; uint4* compact; };
+                auto region = [&](const ListRegion& r, int32_t* count) {
+                    return Band{0, 0, nullptr, reinterpret_cast<int32_t*>(wins4 + r.list), count, wins4 + r.wins, (int32_t)r.cap,
+                                compact_on ? reinterpret_cast<uint4*>(wins4 + r.compact) : nullptr};
+                };
+                // one band's chain; `gated`: both continuations behind the pilot's word, else the bounded order alone
+                auto chain = [&](const Band& B, bool gated, bool wait_mid) {
+                    scan_rgb(nullptr, nullptr, false, true, 0, rest(B.first, nullptr, 0), B.cnt, B.s);
+                    if (wait_mid) ITW_CHECK(hipStreamWaitEvent(B.s, aux->mid, 0));
+                    finish(std::integral_constant<int, 3>{}, nullptr, nullptr, B.list, B.count, nullptr, nullptr, rest(B.first, gated ? pilot_flag : nullptr, 1), B.cnt, B.s,
+                           nullptr, 0, nullptr, B.compact);
+                    scan_rgb(B.list, B.count, true, false, 1, ALL, B.cnt, B.s, B.wins, B.rows, B.compact);    // an empty list (the other order): returns at once
+                    finish(std::integral_constant<int, 4>{}, B.list, B.count, nullptr, nullptr, nullptr, nullptr, ALL, B.cnt, B.s, B.wins, B.rows, B.compact);
+                    if (gated) {
+                        scan_rgb(nullptr, nullptr, true, false, 0, rest(B.first, pilot_flag, 0), B.cnt, B.s);
+                        finish(std::integral_constant<int, 0>{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rest(B.first, pilot_flag, 0), B.cnt, B.s);
+                    }
+                };
+                if (!two) {
+                    Band B = region(W.band[0], band_count);                  // the whole surface: global winner rows, both bands' texel regions as one
+                    B.first = 0; B.cnt = nchunks; B.s = st; B.list = list13; B.wins = wins4; B.rows = (int32_t)n;
+                    chain(B, false, false);
                 } else {
-                    scan_rgb(nullptr, nullptr, false, true);
-                    finish(std::integral_constant<int, 3>{}, nullptr, nullptr, list13, count13, nullptr, nullptr, ALL, -1, nullptr, nullptr, 0, nullptr, compact13);
-                    scan_rgb(list13, count13, true, false, 1, ALL, -1, nullptr, nullptr, 0, compact13);
-                    finish(std::integral_constant<int, 4>{}, list13, count13, nullptr, nullptr, nullptr, nullptr, ALL, -1, nullptr, nullptr, 0, compact13);
+                    hipStream_t s2 = aux->stream;
+                    ITW_CHECK(hipEventRecord(aux->fork, st));                // whatever feeds `src` on st (an upload), and the memset above
+                    ITW_CHECK(hipStreamWaitEvent(s2, aux->fork, 0));
+                    Band A = region(W.band[0], band_count), Bb = region(W.band[1], band_count + 1);
+                    A.cnt = (cR - gS) / 2; if (A.cnt < 1) A.cnt = 1;         // stream 1 also carries the sample
+                    A.first = 0; A.s = st;
+                    Bb.first = A.cnt; Bb.cnt = cR - A.cnt; Bb.s = s2;
+                    A.rows = A.cnt * TPB; Bb.rows = Bb.cnt * TPB;            // shares x listed blocks <= rows: the list scan's grid covers them (list_scan_parts)
+                    Band S = region(W.sample, countS);
+                    S.rows = gS * TPB;
+                    if (pilot) {
+                        const ChunkSel SAMPLE{1, period, gS, 0, nullptr, 0};
+                        scan_rgb(nullptr, nullptr, false, true, 0, SAMPLE, gS, st);
+                        finish(std::integral_constant<int, 3>{}, nullptr, nullptr, S.list, S.count, nullptr, nullptr, SAMPLE, gS, st, nullptr, 0, nullptr, S.compact);
+                        hipLaunchKernelGGL(bc7_pilot_decide, dim3(1), dim3(1), 0, st, countS, gS * TPB, bc7_pilot_threshold(), pilot_flag);
+                        ITW_CHECK(hipEventRecord(aux->mid, st));               // recorded before band B's wait for it is enqueued
+                    }
+                    chain(Bb, pilot, pilot);                                 // (its wait for the verdict sits behind its {0,2} scan)
+                    if (pilot) {
+                        scan_rgb(S.list, S.count, true, false, 1, ALL, gS, st, S.wins, S.rows, S.compact);
+                        finish(std::integral_constant<int, 4>{}, S.list, S.count, nullptr, nullptr, nullptr, nullptr, ALL, gS, st, S.wins, S.rows, S.compact);
+                    }
+                    chain(A, pilot, false);
+                    ITW_CHECK(hipEventRecord(aux->join, s2));
+                    ITW_CHECK(hipStreamWaitEvent(st, aux->join, 0));
                 }
             } else {
                 scan_rgb(nullptr, nullptr, true, true);
