@@ -107,7 +107,7 @@ struct ThreadCtx {
     void*  d_ws = nullptr;  size_t ws_cap = 0;      // BC7 inter-family workspace
     hipStream_t ws_stream = nullptr; bool ws_used = false;
     hipEvent_t  ws_event = nullptr;                 // recorded after each BC7 call: orders the workspace across streams
-    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr};  // second stream + fork/join events for the parallel parts of small BC7 calls
+    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, false};  // second stream + fork/join events for the parallel parts of small BC7 calls
     int    device = -1;
     char   info[256] = {0};
     ~ThreadCtx() {
@@ -124,6 +124,8 @@ struct ThreadCtx {
         if (aux.fork) (void)hipEventDestroy(aux.fork);
         if (aux.join) (void)hipEventDestroy(aux.join);
         if (aux.mid) (void)hipEventDestroy(aux.mid);
+        if (aux.pilot_stream) (void)hipStreamDestroy(aux.pilot_stream);
+        if (aux.join3) (void)hipEventDestroy(aux.join3);
     }
 };
 thread_local ThreadCtx tls;
@@ -147,6 +149,8 @@ void bind_thread_to_current_device()
     if (tls.aux.fork) { (void)hipEventDestroy(tls.aux.fork); tls.aux.fork = nullptr; }
     if (tls.aux.join) { (void)hipEventDestroy(tls.aux.join); tls.aux.join = nullptr; }
     if (tls.aux.mid) { (void)hipEventDestroy(tls.aux.mid); tls.aux.mid = nullptr; }
+    if (tls.aux.pilot_stream) { (void)hipStreamDestroy(tls.aux.pilot_stream); tls.aux.pilot_stream = nullptr; }
+    if (tls.aux.join3) { (void)hipEventDestroy(tls.aux.join3); tls.aux.join3 = nullptr; }
     tls.device = dev;
 }
 
@@ -215,22 +219,43 @@ int64_t staged_wide_max_blocks()
     return v < 1 ? 1 : v;
 }
 
-void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, uint8_t* d_dst, hipStream_t st, bool staged = false)
+void ensure_bc7_aux()
+{
+    if (tls.aux.stream) return;
+    bind_thread_to_current_device();
+    ITW_CHECK(hipStreamCreateWithFlags(&tls.aux.stream, hipStreamNonBlocking));
+    ITW_CHECK(hipEventCreateWithFlags(&tls.aux.fork, hipEventDisableTiming));
+    ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join, hipEventDisableTiming));
+    ITW_CHECK(hipEventCreateWithFlags(&tls.aux.mid, hipEventDisableTiming));
+    ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join3, hipEventDisableTiming));
+    // the pilot of the bounded BC7 order is a chain of small launches that must not queue behind the bands' scans: highest priority
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
+    if (hipStreamCreateWithPriority(&tls.aux.pilot_stream, hipStreamNonBlocking, hi) != hipSuccess) {
+        (void)hipGetLastError();
+        ITW_CHECK(hipStreamCreateWithFlags(&tls.aux.pilot_stream, hipStreamNonBlocking));
+    }
+}
+
+// `band` >= 0: a staged run of a host-pointer BC7 call that compress() overlaps with its neighbours on two streams; it runs in the deep
+// shape on `st` alone, in its own slice of the per-thread workspace (`ws_off`), which compress() has reserved and ordered.
+void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, uint8_t* d_dst, hipStream_t st, bool staged = false, int band = -1,
+            size_t ws_off = 0)
 {
     switch (j.fmt) {
     case Fmt::BC1:  itw::launch_bc1(d_src, stride, w, h, d_dst, st); break;
     case Fmt::BC3:  itw::launch_bc3(d_src, stride, w, h, d_dst, st); break;
     case Fmt::BC7:
-        if (!tls.aux.stream) {
-            bind_thread_to_current_device();
-            ITW_CHECK(hipStreamCreateWithFlags(&tls.aux.stream, hipStreamNonBlocking));
-            ITW_CHECK(hipEventCreateWithFlags(&tls.aux.fork, hipEventDisableTiming));
-            ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join, hipEventDisableTiming));
-            ITW_CHECK(hipEventCreateWithFlags(&tls.aux.mid, hipEventDisableTiming));
-        }
+        ensure_bc7_aux();
         tls.aux.wide_max_blocks = staged ? staged_wide_max_blocks() : 0;
-        itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st, tls.aux.wide_max_blocks), st, &tls.aux);
-        ITW_CHECK(hipEventRecord(tls.ws_event, st));
+        tls.aux.single = band >= 0;
+        if (band >= 0) {
+            itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(static_cast<uint8_t*>(tls.d_ws) + ws_off), st, &tls.aux);
+        } else {
+            itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st, tls.aux.wide_max_blocks), st, &tls.aux);
+            ITW_CHECK(hipEventRecord(tls.ws_event, st));
+        }
+        tls.aux.single = false;
         break;
     case Fmt::BC6H: {
         // the wide shape's workspace shares the per-thread BC7 workspace buffer (same ordering rules)
@@ -320,6 +345,26 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
             for (int c = 0; c < n; c++) { int r = (int)(by * f[c]); cut[c + 1] = r < cut[c] + 1 ? cut[c] + 1 : (r > by - (n - c) ? by - (n - c) : r); }
         }
     }
+    // Round 5: the runs of a BC7 call are BANDS -- run c's kernels go to stream c % 2, each run in the deep shape with its own slice of the
+    // workspace, so that one run's launch tails are filled by its neighbour's work as soon as that neighbour's texels have arrived (the
+    // device-resident path does the same with the two halves of a surface, bc7.hip).  ITW_STAGED_BANDS=0: round 4's runs, one after the
+    // other in the wide shape.
+    const bool bands = j.fmt == Fmt::BC7 && nch > 1 && !src_dev && itw::bc7_staged_bands_ok();
+    size_t ws_off[9] = {0};
+    hipStream_t run_stream[2] = {st, st};
+    if (bands) {
+        ensure_bc7_aux();
+        size_t total = 0;
+        for (int c = 0; c < nch; c++) {
+            ws_off[c] = total;
+            const int run_rows = (cut[c + 1] - cut[c]) * 4;
+            if (run_rows > 0) total += (itw::bc7_workspace_bytes(w, run_rows, 1) + 255) & ~(size_t)255;
+        }
+        reserve_workspace(total, st);
+        run_stream[1] = tls.aux.stream;
+        ITW_CHECK(hipEventRecord(tls.aux.fork, st));          // the second stream starts behind whatever ordered the workspace on the first
+        ITW_CHECK(hipStreamWaitEvent(run_stream[1], tls.aux.fork, 0));
+    } else
     if (j.fmt == Fmt::BC7 || j.fmt == Fmt::BC6H) {
         // Size the workspace once for the most demanding run: growing it frees it, and hipFree waits for the runs in flight.
         // "Most demanding" is not "tallest" (ADVICE r02): a staged BC7 run of up to 2^20 blocks takes the wide shape at ~440
@@ -352,12 +397,13 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
             }
             if (nch > 1) {
                 ITW_CHECK(hipEventRecord(tls.ev_in[c], cs));
-                ITW_CHECK(hipStreamWaitEvent(st, tls.ev_in[c], 0));
+                ITW_CHECK(hipStreamWaitEvent(run_stream[c & 1], tls.ev_in[c], 0));
             }
         }
-        launch(j, d_src + (int64_t)y0 * d_stride, d_stride, w, (int)nrows, d_dst + (size_t)row0 * bx * bpb, st, !src_dev && !dst_dev);
+        launch(j, d_src + (int64_t)y0 * d_stride, d_stride, w, (int)nrows, d_dst + (size_t)row0 * bx * bpb, run_stream[c & 1], !src_dev && !dst_dev,
+               bands ? c : -1, ws_off[c]);
         if (!dst_dev && nch > 1) {
-            ITW_CHECK(hipEventRecord(tls.ev_done[c], st));
+            ITW_CHECK(hipEventRecord(tls.ev_done[c], run_stream[c & 1]));
             if (c > 0) {                               // download the previous run while this one computes
                 const size_t off = (size_t)cut[c - 1] * bx * bpb, len = (size_t)(cut[c] - cut[c - 1]) * bx * bpb;
                 ITW_CHECK(hipStreamWaitEvent(cs, tls.ev_done[c - 1], 0));
@@ -374,6 +420,11 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         } else {
             ITW_CHECK(hipMemcpyAsync(dst, d_dst, out_bytes, hipMemcpyDeviceToHost, st));
         }
+    }
+    if (bands) {                                              // everything back into st; the workspace's event behind all of it
+        ITW_CHECK(hipEventRecord(tls.aux.join, run_stream[1]));
+        ITW_CHECK(hipStreamWaitEvent(st, tls.aux.join, 0));
+        ITW_CHECK(hipEventRecord(tls.ws_event, st));
     }
     ITW_CHECK(hipStreamSynchronize(st));
 }

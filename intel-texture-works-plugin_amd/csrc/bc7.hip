@@ -1936,6 +1936,11 @@ static int bc7_path_override()
     return v;
 }
 void set_bc7_path(int v) { g_bc7_path.store(v == 1 || v == 2 ? v : 0, std::memory_order_relaxed); }
+bool bc7_staged_bands_ok()
+{
+    static const bool on = [] { const char* e = std::getenv("ITW_STAGED_BANDS"); return !(e && e[0] == '0'); }();
+    return on && bc7_path_override() != 2;
+}
 
 // RGBA profile with both groups of modes: the fused shape runs the alpha-capable modes first and skips the three-channel
 // modes where they cannot win (bc7_finish_all).  ITW_BC7_ALPHA_PRUNE=0: always the reference's order.
@@ -2166,7 +2171,8 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
     Bc7Launch L;
     L.S = s;
     L.S.channels = (s.channels == 4) ? 4 : 3;
-    if (bc7_use_wide(n, L.S, aux ? aux->wide_max_blocks : 0)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st, aux); return; }
+    const bool single = aux && aux->single;
+    if (!single && bc7_use_wide(n, L.S, aux ? aux->wide_max_blocks : 0)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st, aux); return; }
     L.err = reinterpret_cast<int32_t*>(workspace);
     L.wins = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(workspace) + (((size_t)n * sizeof(int32_t) + 15) & ~(size_t)15));
     L.vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
@@ -2295,12 +2301,12 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                 //    No host round trip; the sample's blocks are finished by the bounded order whatever the verdict (same bytes either way).
                 //  * BANDS.  The rest is cut into two bands, one per stream: a band's four dependent launches leave the chip partly empty at
                 //    every boundary (a scan wave runs 0.6 ms), and the other band's work fills those tails (measured: 5.23 -> 4.97 ms on the
-                //    bench surface, 7.30 -> 6.99 on a photograph; four bands are slower again).  Stream 1 = sample, then band A; stream 2 =
-                //    band B, whose {0,2} scan (common to both orders) hides the pilot; band B's continuations wait for the verdict's event.
+                //    bench surface, 7.30 -> 6.99 on a photograph; four bands are slower again).  The bands' {0,2} scans (common to both
+                //    orders) hide the pilot, which has a third, high-priority stream; their continuations wait for the verdict's event.
                 ITW_CHECK(hipMemsetAsync(rgb_count, 0, 8 * sizeof(int32_t), st));
                 const int period = PILOT_PERIOD;
-                const bool two = bc7_bands() > 1 && aux && aux->stream && aux->mid && nchunks >= 32;
-                const bool pilot = two && bc7_pilot_threshold() >= 0;
+                const bool two = bc7_bands() > 1 && aux && !aux->single && aux->stream && nchunks >= 32;
+                const bool pilot = two && bc7_pilot_threshold() >= 0 && aux->pilot_stream && aux->mid && aux->join3;
                 const int32_t gS = pilot ? nchunks / period : 0;             // the pilot's sample: one chunk of every full group of `period`
                 const int32_t cR = nchunks - gS;                             // chunks of the rest
                 auto rest = [&](int32_t first, const int32_t* gate, int32_t want) { return ChunkSel{2, period, gS, first, gate, want}; };
@@ -2331,25 +2337,29 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                     ITW_CHECK(hipEventRecord(aux->fork, st));                // whatever feeds `src` on st (an upload), and the memset above
                     ITW_CHECK(hipStreamWaitEvent(s2, aux->fork, 0));
                     Band A = region(W.band[0], band_count), Bb = region(W.band[1], band_count + 1);
-                    A.cnt = (cR - gS) / 2; if (A.cnt < 1) A.cnt = 1;         // stream 1 also carries the sample
+                    A.cnt = cR / 2;
                     A.first = 0; A.s = st;
                     Bb.first = A.cnt; Bb.cnt = cR - A.cnt; Bb.s = s2;
                     A.rows = A.cnt * TPB; Bb.rows = Bb.cnt * TPB;            // shares x listed blocks <= rows: the list scan's grid covers them (list_scan_parts)
-                    Band S = region(W.sample, countS);
-                    S.rows = gS * TPB;
                     if (pilot) {
+                        // the sample's chain on its own high-priority stream: in front of band A it cost its full latency (five small
+                        // launches, 0.4 ms: profiles/r05b_bc7_pilot_plus_bands_timing.txt); beside both bands it only needs its share of the chip
+                        hipStream_t s3 = aux->pilot_stream;
+                        ITW_CHECK(hipStreamWaitEvent(s3, aux->fork, 0));
+                        Band S = region(W.sample, countS);
+                        S.rows = gS * TPB;
                         const ChunkSel SAMPLE{1, period, gS, 0, nullptr, 0};
-                        scan_rgb(nullptr, nullptr, false, true, 0, SAMPLE, gS, st);
-                        finish(std::integral_constant<int, 3>{}, nullptr, nullptr, S.list, S.count, nullptr, nullptr, SAMPLE, gS, st, nullptr, 0, nullptr, S.compact);
-                        hipLaunchKernelGGL(bc7_pilot_decide, dim3(1), dim3(1), 0, st, countS, gS * TPB, bc7_pilot_threshold(), pilot_flag);
-                        ITW_CHECK(hipEventRecord(aux->mid, st));               // recorded before band B's wait for it is enqueued
+                        scan_rgb(nullptr, nullptr, false, true, 0, SAMPLE, gS, s3);
+                        finish(std::integral_constant<int, 3>{}, nullptr, nullptr, S.list, S.count, nullptr, nullptr, SAMPLE, gS, s3, nullptr, 0, nullptr, S.compact);
+                        hipLaunchKernelGGL(bc7_pilot_decide, dim3(1), dim3(1), 0, s3, countS, gS * TPB, bc7_pilot_threshold(), pilot_flag);
+                        ITW_CHECK(hipEventRecord(aux->mid, s3));               // recorded before the bands' waits for it are enqueued
+                        scan_rgb(S.list, S.count, true, false, 1, ALL, gS, s3, S.wins, S.rows, S.compact);
+                        finish(std::integral_constant<int, 4>{}, S.list, S.count, nullptr, nullptr, nullptr, nullptr, ALL, gS, s3, S.wins, S.rows, S.compact);
+                        ITW_CHECK(hipEventRecord(aux->join3, s3));
                     }
-                    chain(Bb, pilot, pilot);                                 // (its wait for the verdict sits behind its {0,2} scan)
-                    if (pilot) {
-                        scan_rgb(S.list, S.count, true, false, 1, ALL, gS, st, S.wins, S.rows, S.compact);
-                        finish(std::integral_constant<int, 4>{}, S.list, S.count, nullptr, nullptr, nullptr, nullptr, ALL, gS, st, S.wins, S.rows, S.compact);
-                    }
-                    chain(A, pilot, false);
+                    chain(Bb, pilot, pilot);                                 // (a band's wait for the verdict sits behind its {0,2} scan)
+                    chain(A, pilot, pilot);
+                    if (pilot) ITW_CHECK(hipStreamWaitEvent(st, aux->join3, 0));
                     ITW_CHECK(hipEventRecord(aux->join, s2));
                     ITW_CHECK(hipStreamWaitEvent(st, aux->join, 0));
                 }

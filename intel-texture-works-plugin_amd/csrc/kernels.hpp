@@ -23,13 +23,16 @@ size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks = 0); 
 // BC7 launch shape: 0 = by call size (default), 1 = deep (one lane per block, a launch pair per mode family: fills the
 // chip on whole surfaces), 2 = wide (split scans + ordered argmin: small calls).  Same blocks either way.
 void set_bc7_path(int path);
+bool bc7_staged_bands_ok();      // the staged runs of a host-pointer call may run as overlapped deep bands (not when the wide shape is forced / ITW_STAGED_BANDS=0)
 // The pilot of the bounded BC7 mode order (bc7.hip, launch_bc7): percent of the sample's blocks that may still need modes 1/3 for the rest of
 // the surface to take the bounded order; -1 = no pilot, the whole call in the bounded order.  Same blocks whatever the value.
 void set_bc7_pilot(int percent);
 // `aux` (optional): a second stream of the same device plus two events the launcher may use to run independent parts of a
 // small call side by side; everything is joined back into `st` before the launcher returns.
-// `mid` (may be null: no pilot): a third event, for the pilot of the bounded mode order (bc7.hip).
-struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; hipEvent_t mid; };   // wide_max_blocks: 0 = the library default
+// `pilot_stream`, `mid`, `join3` (may be null: no pilot): a third, high-priority stream and two more events for the pilot of the bounded
+// mode order (bc7.hip).  `single`: the call is one band of a larger job whose bands the CALLER overlaps on two streams (the staged runs
+// of a host-pointer call, abi.hip): deep shape whatever the size, everything on `st`, no pilot, no inner bands.
+struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; hipEvent_t mid; hipStream_t pilot_stream; hipEvent_t join3; bool single; };   // wide_max_blocks: 0 = the library default
 void launch_bc7 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                  const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux = nullptr);
 // test hook: bc7_exact.hpp's two_subset_bound of all 64 two-subset shapes of every block, out[block * 64 + shape] (device memory)
