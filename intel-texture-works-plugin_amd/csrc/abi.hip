@@ -107,7 +107,8 @@ struct ThreadCtx {
     void*  d_ws = nullptr;  size_t ws_cap = 0;      // BC7 inter-family workspace
     hipStream_t ws_stream = nullptr; bool ws_used = false;
     hipEvent_t  ws_event = nullptr;                 // recorded after each BC7 call: orders the workspace across streams
-    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, false};  // second stream + fork/join events for the parallel parts of small BC7 calls
+    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, false, nullptr};
+    itw::Bc7Verdict verdict = {nullptr, nullptr, 0, false};  // second stream + fork/join events for the parallel parts of small BC7 calls
     int    device = -1;
     char   info[256] = {0};
     ~ThreadCtx() {
@@ -126,6 +127,7 @@ struct ThreadCtx {
         if (aux.mid) (void)hipEventDestroy(aux.mid);
         if (aux.pilot_stream) (void)hipStreamDestroy(aux.pilot_stream);
         if (aux.join3) (void)hipEventDestroy(aux.join3);
+        if (verdict.event) (void)hipEventDestroy(verdict.event);
     }
 };
 thread_local ThreadCtx tls;
@@ -151,6 +153,7 @@ void bind_thread_to_current_device()
     if (tls.aux.mid) { (void)hipEventDestroy(tls.aux.mid); tls.aux.mid = nullptr; }
     if (tls.aux.pilot_stream) { (void)hipStreamDestroy(tls.aux.pilot_stream); tls.aux.pilot_stream = nullptr; }
     if (tls.aux.join3) { (void)hipEventDestroy(tls.aux.join3); tls.aux.join3 = nullptr; }
+    if (tls.verdict.event) { (void)hipEventDestroy(tls.verdict.event); tls.verdict.event = nullptr; }
     tls.device = dev;
 }
 
@@ -219,6 +222,13 @@ int64_t staged_wide_max_blocks()
     return v < 1 ? 1 : v;
 }
 
+// ITW_STAGED_VERDICT_THR: percent of the first staged run's blocks that may still need modes 1/3 for the remaining runs to stay deep bands
+int staged_verdict_percent()
+{
+    static const int v = [] { const char* e = std::getenv("ITW_STAGED_VERDICT_THR"); return e ? std::atoi(e) : 65; }();
+    return v;
+}
+
 void ensure_bc7_aux()
 {
     if (tls.aux.stream) return;
@@ -228,6 +238,7 @@ void ensure_bc7_aux()
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join, hipEventDisableTiming));
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.mid, hipEventDisableTiming));
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join3, hipEventDisableTiming));
+    ITW_CHECK(hipEventCreateWithFlags(&tls.verdict.event, hipEventDisableTiming));
     // the pilot of the bounded BC7 order is a chain of small launches that must not queue behind the bands' scans: highest priority
     int lo = 0, hi = 0;
     if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
@@ -250,7 +261,10 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
         tls.aux.wide_max_blocks = staged ? staged_wide_max_blocks() : 0;
         tls.aux.single = band >= 0;
         if (band >= 0) {
+            tls.aux.verdict = band == 0 ? &tls.verdict : nullptr;   // the first run reports how many of its blocks needed modes 1/3
+            if (band == 0) tls.verdict.valid = false;
             itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(static_cast<uint8_t*>(tls.d_ws) + ws_off), st, &tls.aux);
+            tls.aux.verdict = nullptr;
         } else {
             itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st, tls.aux.wide_max_blocks), st, &tls.aux);
             ITW_CHECK(hipEventRecord(tls.ws_event, st));
@@ -360,6 +374,12 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
             const int run_rows = (cut[c + 1] - cut[c]) * 4;
             if (run_rows > 0) total += (itw::bc7_workspace_bytes(w, run_rows, 1) + 255) & ~(size_t)255;
         }
+        for (int c = 1; c < nch; c++) {                       // a later run may take the wide shape instead (the verdict below): room for that too
+            const int run_rows = (cut[c + 1] - cut[c]) * 4;
+            if (run_rows <= 0) continue;
+            const size_t b = itw::bc7_workspace_bytes(w, run_rows, staged_wide_max_blocks());
+            if (b > total) total = b;
+        }
         reserve_workspace(total, st);
         run_stream[1] = tls.aux.stream;
         ITW_CHECK(hipEventRecord(tls.aux.fork, st));          // the second stream starts behind whatever ordered the workspace on the first
@@ -380,6 +400,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         if (need) reserve_workspace(need, st);
     }
     hipStream_t copy = (nch > 1) ? cs : st;
+    bool run_as_band = bands;
     int c = 0;
     for (c = 0; c < nch; c++) {
         const int row0 = cut[c], nb = cut[c + 1] - cut[c];
@@ -395,13 +416,25 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
                 for (size_t y = 0; y < nrows; y++)
                     ITW_CHECK(hipMemcpyAsync(in + (y0 + y) * pitch, hs + (int64_t)y * src->stride, row_bytes, hipMemcpyHostToDevice, copy));
             }
+            if (bands && c == 1 && tls.verdict.valid) {
+                // The first run (the top eighth of the surface) ran the bounded order and left the number of its blocks that still needed
+                // modes 1/3.  Its texels went up first and its kernels have been running under the upload of this run, which has just
+                // returned: reading the count costs this host thread next to nothing.  Content where nearly every block is listed
+                // (photographs) gains nothing from the bounded order, and for it the wide shape overlaps staged runs better (8.1 against
+                // 7.4 ms per 4096^2 call, profiles/r05c_*): the remaining runs then go one after the other in the wide shape, as in round 4.
+                int32_t listed = 0;
+                ITW_CHECK(hipStreamWaitEvent(cs, tls.verdict.event, 0));
+                ITW_CHECK(hipMemcpyAsync(&listed, tls.verdict.listed, sizeof listed, hipMemcpyDeviceToHost, cs));
+                ITW_CHECK(hipStreamSynchronize(cs));
+                if ((int64_t)listed * 100 > (int64_t)staged_verdict_percent() * tls.verdict.blocks) { run_as_band = false; run_stream[1] = st; }
+            }
             if (nch > 1) {
                 ITW_CHECK(hipEventRecord(tls.ev_in[c], cs));
                 ITW_CHECK(hipStreamWaitEvent(run_stream[c & 1], tls.ev_in[c], 0));
             }
         }
         launch(j, d_src + (int64_t)y0 * d_stride, d_stride, w, (int)nrows, d_dst + (size_t)row0 * bx * bpb, run_stream[c & 1], !src_dev && !dst_dev,
-               bands ? c : -1, ws_off[c]);
+               run_as_band ? c : -1, ws_off[c]);
         if (!dst_dev && nch > 1) {
             ITW_CHECK(hipEventRecord(tls.ev_done[c], run_stream[c & 1]));
             if (c > 0) {                               // download the previous run while this one computes

@@ -2321,6 +2321,10 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                     if (wait_mid) ITW_CHECK(hipStreamWaitEvent(B.s, aux->mid, 0));
                     finish(std::integral_constant<int, 3>{}, nullptr, nullptr, B.list, B.count, nullptr, nullptr, rest(B.first, gated ? pilot_flag : nullptr, 1), B.cnt, B.s,
                            nullptr, 0, nullptr, B.compact);
+                    if (!two && aux && aux->verdict && aux->verdict->event) {      // a staged run reports its list length to the host (abi.hip)
+                        ITW_CHECK(hipEventRecord(aux->verdict->event, B.s));
+                        aux->verdict->listed = B.count; aux->verdict->blocks = (int32_t)n; aux->verdict->valid = true;
+                    }
                     scan_rgb(B.list, B.count, true, false, 1, ALL, B.cnt, B.s, B.wins, B.rows, B.compact);    // an empty list (the other order): returns at once
                     finish(std::integral_constant<int, 4>{}, B.list, B.count, nullptr, nullptr, nullptr, nullptr, ALL, B.cnt, B.s, B.wins, B.rows, B.compact);
                     if (gated) {
