@@ -771,3 +771,46 @@ void oracle_CompressBlocksBC6H(const oracle_surface* src, uint8_t* dst, const or
         store_data(dst, src->width, xx, yy, data, 4);
     }
 }
+
+/* TEST / STUDY HOOK (tools/round5/bc6h_bound_study.py; never called by the product): one two-region mode's scan as the reference runs it under
+ * the slow profiles (kernel.ispc:2332-2365 -> :2257-2273 -> :2195-2216): the 32 shapes in ranked order, each with its ranking key's bound part
+ * and bc6h_enc_2p_part_fast's error.  `mode` is kernel.ispc's number (0, 1, 2, 5, 6, 9); list[i] = shape at position i, bound[i] = (int)bound12,
+ * err[i] = its error; returns max_span (the S5 quirk's domain: kernel.ispc:1178 overflows where a span exceeds 26 754). */
+float oracle_bc6h_2p_scan(const float block[64], int mode, int32_t list[32], int32_t bound[32], float err[32])
+{
+    bc6h_enc_state state;
+    memset(&state, 0, sizeof state);
+    state.slow_mode = 1;
+    state.fastSkipTreshold = 32;
+    memcpy(state.block, block, sizeof state.block);
+    state.best_err = INFINITY;
+    bc6h_setup(&state);
+    bc6h_test_mode(&state, mode, 0, 0);                /* epb, mode, qbounds; no encode */
+    float full_stats[15];
+    compute_stats_masked(full_stats, state.block, -1, 3);
+    int32_t part_list[32];
+    for (int part = 0; part < 32; part++) {
+        int32_t mask = get_pattern_mask(part, 0);
+        float bound12 = block_pca_bound_split(state.block, mask, full_stats, 3);
+        part_list[part] = (int32_t)((uint32_t)part + (uint32_t)f2i_x86(bound12) * 64u);
+    }
+    partial_sort_list(part_list, 32, 32);
+    for (int i = 0; i < 32; i++) {
+        int32_t qep[24];
+        uint32_t qblock[2];
+        list[i] = part_list[i] & 31;
+        bound[i] = part_list[i] >> 6;
+        err[i] = bc6h_enc_2p_part_fast(&state, qep, qblock, list[i]);
+    }
+    return state.max_span;
+}
+
+/* the block as bc6h_setup leaves it (uf16-scaled texels), for the study's own bound */
+void oracle_bc6h_setup_block(const float block[64], float out[64])
+{
+    bc6h_enc_state state;
+    memset(&state, 0, sizeof state);
+    memcpy(state.block, block, sizeof state.block);
+    bc6h_setup(&state);
+    memcpy(out, state.block, sizeof state.block);
+}
