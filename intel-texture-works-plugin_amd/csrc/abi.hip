@@ -107,7 +107,7 @@ struct ThreadCtx {
     void*  d_ws = nullptr;  size_t ws_cap = 0;      // BC7 inter-family workspace
     hipStream_t ws_stream = nullptr; bool ws_used = false;
     hipEvent_t  ws_event = nullptr;                 // recorded after each BC7 call: orders the workspace across streams
-    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, false, nullptr};
+    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr, false, nullptr};
     itw::Bc7Verdict verdict = {nullptr, nullptr, 0, false};  // second stream + fork/join events for the parallel parts of small BC7 calls
     int    device = -1;
     char   info[256] = {0};
@@ -125,8 +125,6 @@ struct ThreadCtx {
         if (aux.fork) (void)hipEventDestroy(aux.fork);
         if (aux.join) (void)hipEventDestroy(aux.join);
         if (aux.mid) (void)hipEventDestroy(aux.mid);
-        if (aux.pilot_stream) (void)hipStreamDestroy(aux.pilot_stream);
-        if (aux.join3) (void)hipEventDestroy(aux.join3);
         if (verdict.event) (void)hipEventDestroy(verdict.event);
     }
 };
@@ -151,8 +149,6 @@ void bind_thread_to_current_device()
     if (tls.aux.fork) { (void)hipEventDestroy(tls.aux.fork); tls.aux.fork = nullptr; }
     if (tls.aux.join) { (void)hipEventDestroy(tls.aux.join); tls.aux.join = nullptr; }
     if (tls.aux.mid) { (void)hipEventDestroy(tls.aux.mid); tls.aux.mid = nullptr; }
-    if (tls.aux.pilot_stream) { (void)hipStreamDestroy(tls.aux.pilot_stream); tls.aux.pilot_stream = nullptr; }
-    if (tls.aux.join3) { (void)hipEventDestroy(tls.aux.join3); tls.aux.join3 = nullptr; }
     if (tls.verdict.event) { (void)hipEventDestroy(tls.verdict.event); tls.verdict.event = nullptr; }
     tls.device = dev;
 }
@@ -237,15 +233,7 @@ void ensure_bc7_aux()
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.fork, hipEventDisableTiming));
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join, hipEventDisableTiming));
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.mid, hipEventDisableTiming));
-    ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join3, hipEventDisableTiming));
     ITW_CHECK(hipEventCreateWithFlags(&tls.verdict.event, hipEventDisableTiming));
-    // the pilot of the bounded BC7 order is a chain of small launches that must not queue behind the bands' scans: highest priority
-    int lo = 0, hi = 0;
-    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = hi = 0; }
-    if (hipStreamCreateWithPriority(&tls.aux.pilot_stream, hipStreamNonBlocking, hi) != hipSuccess) {
-        (void)hipGetLastError();
-        ITW_CHECK(hipStreamCreateWithFlags(&tls.aux.pilot_stream, hipStreamNonBlocking));
-    }
 }
 
 // `band` >= 0: a staged run of a host-pointer BC7 call that compress() overlaps with its neighbours on two streams; it runs in the deep
@@ -266,7 +254,8 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
             itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(static_cast<uint8_t*>(tls.d_ws) + ws_off), st, &tls.aux);
             tls.aux.verdict = nullptr;
         } else {
-            itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, bc7_workspace(w, h, st, tls.aux.wide_max_blocks), st, &tls.aux);
+            float* ws = bc7_workspace(w, h, st, tls.aux.wide_max_blocks);         // (sized and ordered already when ws_off != 0)
+            itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(ws) + ws_off), st, &tls.aux);
             ITW_CHECK(hipEventRecord(tls.ws_event, st));
         }
         tls.aux.single = false;
@@ -359,13 +348,13 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
             for (int c = 0; c < n; c++) { int r = (int)(by * f[c]); cut[c + 1] = r < cut[c] + 1 ? cut[c] + 1 : (r > by - (n - c) ? by - (n - c) : r); }
         }
     }
-    // Round 5: the runs of a BC7 call are BANDS -- run c's kernels go to stream c % 2, each run in the deep shape with its own slice of the
+    // Round 5: the runs of a BC7 call are BANDS -- run c's kernels go to stream (c + 1) % 2 (the first, short run to the second stream), each run in the deep shape with its own slice of the
     // workspace, so that one run's launch tails are filled by its neighbour's work as soon as that neighbour's texels have arrived (the
     // device-resident path does the same with the two halves of a surface, bc7.hip).  ITW_STAGED_BANDS=0: round 4's runs, one after the
     // other in the wide shape.
     const bool bands = j.fmt == Fmt::BC7 && nch > 1 && !src_dev && itw::bc7_staged_bands_ok();
     size_t ws_off[9] = {0};
-    hipStream_t run_stream[2] = {st, st};
+    hipStream_t run_stream[2] = {st, st};                    // [(c + 1) & 1] is run c's stream
     if (bands) {
         ensure_bc7_aux();
         size_t total = 0;
@@ -377,7 +366,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         for (int c = 1; c < nch; c++) {                       // a later run may take the wide shape instead (the verdict below): room for that too
             const int run_rows = (cut[c + 1] - cut[c]) * 4;
             if (run_rows <= 0) continue;
-            const size_t b = itw::bc7_workspace_bytes(w, run_rows, staged_wide_max_blocks());
+            const size_t b = ws_off[1] + itw::bc7_workspace_bytes(w, run_rows, staged_wide_max_blocks());   // behind the first run's slice: that run may still be going
             if (b > total) total = b;
         }
         reserve_workspace(total, st);
@@ -426,17 +415,17 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
                 ITW_CHECK(hipStreamWaitEvent(cs, tls.verdict.event, 0));
                 ITW_CHECK(hipMemcpyAsync(&listed, tls.verdict.listed, sizeof listed, hipMemcpyDeviceToHost, cs));
                 ITW_CHECK(hipStreamSynchronize(cs));
-                if ((int64_t)listed * 100 > (int64_t)staged_verdict_percent() * tls.verdict.blocks) { run_as_band = false; run_stream[1] = st; }
+                if ((int64_t)listed * 100 > (int64_t)staged_verdict_percent() * tls.verdict.blocks) { run_as_band = false; run_stream[0] = run_stream[1] = st; }
             }
             if (nch > 1) {
                 ITW_CHECK(hipEventRecord(tls.ev_in[c], cs));
-                ITW_CHECK(hipStreamWaitEvent(run_stream[c & 1], tls.ev_in[c], 0));
+                ITW_CHECK(hipStreamWaitEvent(run_stream[(c + 1) & 1], tls.ev_in[c], 0));
             }
         }
-        launch(j, d_src + (int64_t)y0 * d_stride, d_stride, w, (int)nrows, d_dst + (size_t)row0 * bx * bpb, run_stream[c & 1], !src_dev && !dst_dev,
-               run_as_band ? c : -1, ws_off[c]);
+        launch(j, d_src + (int64_t)y0 * d_stride, d_stride, w, (int)nrows, d_dst + (size_t)row0 * bx * bpb, run_stream[(c + 1) & 1], !src_dev && !dst_dev,
+               run_as_band ? c : -1, run_as_band ? ws_off[c] : (bands ? ws_off[1] : 0));
         if (!dst_dev && nch > 1) {
-            ITW_CHECK(hipEventRecord(tls.ev_done[c], run_stream[c & 1]));
+            ITW_CHECK(hipEventRecord(tls.ev_done[c], run_stream[(c + 1) & 1]));
             if (c > 0) {                               // download the previous run while this one computes
                 const size_t off = (size_t)cut[c - 1] * bx * bpb, len = (size_t)(cut[c] - cut[c - 1]) * bx * bpb;
                 ITW_CHECK(hipStreamWaitEvent(cs, tls.ev_done[c - 1], 0));
@@ -455,7 +444,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         }
     }
     if (bands) {                                              // everything back into st; the workspace's event behind all of it
-        ITW_CHECK(hipEventRecord(tls.aux.join, run_stream[1]));
+        ITW_CHECK(hipEventRecord(tls.aux.join, tls.aux.stream));
         ITW_CHECK(hipStreamWaitEvent(st, tls.aux.join, 0));
         ITW_CHECK(hipEventRecord(tls.ws_event, st));
     }

@@ -1371,31 +1371,19 @@ __device__ __forceinline__ void merge_packed_parts(Win& w, Lane& ln, const uint3
 
 struct ScanTasks { int n; int kind[3]; };      // WK_SCAN02 / WK_SCAN13 / WK_SCAN7 in launch order
 
-// Round 5, the PILOT and the BANDS of the bounded order (launch_bc7): which chunks (runs of TPB blocks) of the surface a launch of
+// Round 5, the BANDS and the PILOT of the bounded order (launch_bc7): which chunks (runs of TPB blocks) of the surface a launch of
 // bc7_scan_all / bc7_finish_all walks, and whether it runs at all.
-//   kind 0  every chunk: workgroup i -> chunk first + i
-//   kind 1  the SAMPLE: one chunk out of every full group of `period` chunks, at an offset that moves from group to group (5 g mod period:
-//           a fixed offset would sample one column of a surface whose rows hold a multiple of `period` chunks)
-//   kind 2  the REST: every other chunk (and the chunks behind the last full group), enumerated in surface order; workgroup i takes the
-//           (first + i)-th of them, so that a band of the rest is a range [first, first + count) of that enumeration
-// `gate` (optional): a device word written by bc7_pilot_decide before this launch starts; the launch returns at once unless it holds
+//   kind 0  every chunk: workgroup i -> chunk i
+//   kind 1  a BAND: the surface is cut into stripes of `stripe` chunks, even stripes are band 0, odd stripes band 1 (two interleaved
+//           halves, so that both see all of the surface's content); workgroup i takes the i-th chunk of band `band`
+// `gate` (optional): a device word written by bc7_pilot_estimate before this launch starts; the launch returns at once unless it holds
 // `want` -- both mode orders are enqueued behind the pilot and the device picks one, without a host round trip.
-struct ChunkSel { int32_t kind, period, groups, first; const int32_t* gate; int32_t want; };
+struct ChunkSel { int32_t kind, stripe, band; const int32_t* gate; int32_t want; };
 __device__ __forceinline__ int32_t sel_chunk(const ChunkSel& s, int32_t i)
 {
-    i += s.first;
     if (s.kind == 0) return i;
-    if (s.kind == 1) return i * s.period + (int32_t)(((uint32_t)i * 5u) % (uint32_t)s.period);
-    const int32_t per = s.period - 1, full = s.groups * per;
-    if (i >= full) return s.groups * s.period + (i - full);
-    const int32_t g = i / per, k = i - g * per, off = (int32_t)(((uint32_t)g * 5u) % (uint32_t)s.period);
-    return g * s.period + k + (k >= off ? 1 : 0);
-}
-// the pilot's verdict: 1 = bounded order for the rest of the surface (few enough of the sample's blocks still need modes 1/3), 0 = the
-// reference's order.  `listed` blocks of `sampled`; threshold in 1/256.
-__global__ void bc7_pilot_decide(const int32_t* __restrict__ listed, int32_t sampled, int32_t thr256, int32_t* __restrict__ flag)
-{
-    *flag = ((int64_t)*listed * 256 <= (int64_t)thr256 * sampled) ? 1 : 0;
+    const int32_t q = i / s.stripe;
+    return (2 * q + s.band) * s.stripe + (i - q * s.stripe);
 }
 
 // FAM7 = false: the three-channel families {0,2} and {1,3} (4 waves per SIMD; ranked lists 3); FAM7 = true: the mode 7 scan
@@ -1566,11 +1554,12 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
     __shared__ uint2 s_pal[(ITW_BC7_LANE_PAL ? LANE_PAL_LEVELS : 8) * TPB];   // refinement: a palette per subset of the lane's winner
     if (sel.gate && *sel.gate != sel.want) return;                   // the pilot chose the other order (whole grid: no barrier is pending)
     const int32_t nact = LISTED ? *in_count : nblocks;
-    if (LISTED && (int32_t)(blockIdx.x * TPB) >= nact) return;       // whole workgroup, before any barrier
+    const int32_t chunk = LISTED ? (int32_t)blockIdx.x : sel_chunk(sel, (int32_t)blockIdx.x);
+    if (chunk * TPB >= nact) return;                                 // whole workgroup, before any barrier (a band's grid is whole stripes)
     Lane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB);
     __syncthreads();
-    const int32_t gid = (LISTED ? (int32_t)blockIdx.x : sel_chunk(sel, (int32_t)blockIdx.x)) * TPB + threadIdx.x;
+    const int32_t gid = chunk * TPB + threadIdx.x;
     const bool live = gid < nact;
     const int32_t slot = live ? gid : nact - 1;
     const int32_t b = LISTED ? in_list[slot] : slot;
@@ -1673,6 +1662,53 @@ bc7_finish_all(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x
         uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
         if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(ln.best[0], ln.best[1], ln.best[2], ln.best[3]);
         else { d[0] = ln.best[0]; d[1] = ln.best[1]; d[2] = ln.best[2]; d[3] = ln.best[3]; }
+    }
+}
+
+// The PILOT of the bounded order (round 5).  Runs behind band 0's {0,2} scan on every eighth chunk of that band (1/16 of the surface, spread
+// over it by the bands' stripes): with the scan's winners as the incumbent -- before refinement and before modes 4,5,6, so the true
+// incumbent is lower and the true list longer: an ESTIMATE from below -- it counts the blocks some two-subset shape's bound can still get
+// under, exactly as bc7_finish_all<3> will list them, and the workgroup that finishes last turns the two counts into the device word the
+// gated launches read: 1 = few enough blocks will need modes 1/3, the bounded order pays; 0 = nearly all will, the reference's order (one
+// scan of the family over the band, one refinement kernel) is cheaper.  Nothing it computes reaches the output.
+template <bool VEC16>
+__global__ void __launch_bounds__(TPB)
+bc7_pilot_estimate(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, const uint32_t* __restrict__ wins4,
+                   const int skip_mode2, const ChunkSel sel, int32_t* __restrict__ counters /* listed, sampled, done */, const int32_t thr256,
+                   int32_t* __restrict__ flag)
+{
+    const int32_t chunk = sel_chunk(sel, (int32_t)blockIdx.x * 8 + 3);
+    if (chunk * TPB < nblocks) {                                     // workgroup-uniform
+        const int32_t gid = chunk * TPB + threadIdx.x;
+        const bool live = gid < nblocks;
+        const int32_t b = live ? gid : nblocks - 1;
+        Tex tx;
+        load_block<VEC16>(tx, src, stride, blocks_x, b);
+        Win w0, w2;
+        unpack_win(w0, wins4[(int64_t)wide_win_slot(0) * nblocks + b]);
+        unpack_win(w2, skip_mode2 ? 0xffffffffu : wins4[(int64_t)wide_win_slot(2) * nblocks + b]);
+        const int32_t e = min(w0.err, w2.err);
+        IStats<3> full;
+        stats_int<3>(full, tx.pl, whole_block());
+        const float lim = (float)e - 0.5f;
+        bool need = !live;
+#pragma unroll 1
+        for (int shape = 0; shape < 64; shape++) {
+            if (__all(need)) break;
+            if (shape == BOUND_BAIL_AFTER && __popcll(__ballot(need)) >= BOUND_BAIL_LANES) { need = true; break; }
+            need = need || !(two_subset_bound(shape, tx.pl, full) >= lim);
+        }
+        const unsigned long long ml = __ballot(live && need), mt = __ballot(live);
+        if ((threadIdx.x & 63u) == 0u) { atomicAdd(counters + 0, (int32_t)__popcll(ml)); atomicAdd(counters + 1, (int32_t)__popcll(mt)); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(counters + 2, 1) == (int32_t)gridDim.x - 1) {  // the last workgroup: every count has arrived
+            __threadfence();
+            const int64_t listed = atomicAdd(counters + 0, 0), sampled = atomicAdd(counters + 1, 0);
+            *flag = (listed * 256 <= (int64_t)thr256 * sampled) ? 1 : 0;
+        }
     }
 }
 
@@ -1969,6 +2005,11 @@ static int bc7_pilot_threshold()
     return pct < 0 ? -1 : pct * 256 / 100;
 }
 void set_bc7_pilot(int percent) { g_bc7_pilot.store(percent < 0 ? -1 : (percent > 100 ? 100 : percent), std::memory_order_relaxed); }
+static bool bc7_pilot_debug()
+{
+    static const bool on = [] { const char* e = std::getenv("ITW_BC7_PILOT_DEBUG"); return e && e[0] == '1'; }();
+    return on;
+}
 // ITW_BC7_BANDS=1: one band on the caller's stream, no pilot (round 4's launch order); default 2
 static int bc7_bands()
 {
@@ -2023,11 +2064,10 @@ static size_t wide_workspace_bytes(size_t n)
     return (size_t)5 * wide_win_entries(n) * sizeof(uint4) + (((size_t)WIDE_SLOTS * n * sizeof(int32_t) + 15) & ~(size_t)15) + (size_t)WIDE_SLOTS * n * sizeof(uint4);
 }
 // fused shape, in 4-byte words from the start of the workspace (every region starts on a 16-byte boundary)
-constexpr int PILOT_PERIOD = 16;          // the pilot samples one chunk in 16 (launch_bc7)
 // a list of blocks for modes 1/3 with what its split scan and refinement need: block ids [cap], winners of the scan's shares [5 rows][cap]
 // (rows 2, 3 used: list_scan_parts x listed <= cap), the listed blocks' texels [cap] x 64 B in list order
 struct ListRegion { size_t list, wins, compact, cap; };
-struct FusedLayout { size_t inc, list0, list1, list2, counts, words; ListRegion sample, band[2]; };
+struct FusedLayout { size_t inc, list0, list1, list2, counts, words; ListRegion band[2]; };
 static FusedLayout fused_layout(size_t n)
 {
     auto up4 = [](size_t w) { return (w + 3) & ~(size_t)3; };
@@ -2039,16 +2079,9 @@ static FusedLayout fused_layout(size_t n)
     W.list1 = o;    o = up4(o + n);
     W.list2 = o;    o = up4(o + n);
     W.counts = o;   o += 16;                                       // list lengths, the pilot's verdict
-    auto region = [&](ListRegion& r, size_t chunks) {
-        r.cap = chunks * TPB;
-        r.list = o;    o = up4(o + r.cap);
-        r.wins = o;    o = up4(o + 5 * r.cap);
-        r.compact = o; o += 16 * r.cap;
-    };
-    region(W.sample, nchunks / PILOT_PERIOD + 1);                  // the pilot's sample
-    for (int k = 0; k < 2; k++) {                                  // the two bands of the rest: lists and share winners ...
+    for (int k = 0; k < 2; k++) {                                  // the two bands: lists and share winners ...
         ListRegion& r = W.band[k];
-        r.cap = (nchunks / 2 + 1) * TPB;
+        r.cap = (nchunks / 2 + 65) * TPB;                          // (a band is whole stripes of up to 64 chunks)
         r.list = o;    o = up4(o + r.cap);
         r.wins = o;    o = up4(o + 5 * r.cap);
     }
@@ -2209,13 +2242,13 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             int32_t* count13 = rgb_count + 1;
             int32_t* count7 = rgb_count + 2;
             int32_t* band_count = rgb_count + 3;                                               // [2]: the bands' lists for modes 1/3
-            int32_t* countS = rgb_count + 5;                                                   // the pilot sample's
-            int32_t* pilot_flag = rgb_count + 6;
+            int32_t* pilot_flag = rgb_count + 6;                                               // the pilot's verdict
+            int32_t* pilot_ctr = rgb_count + 8;                                                // [3]: its counts (listed, sampled, workgroups done)
             const bool compact_on = bc7_compact_lists();
             const dim3 blk(TPB);
-            const ChunkSel ALL{0, 1, 0, 0, nullptr, 0};
+            const ChunkSel ALL{0, 1, 0, nullptr, 0};
             // `sel`: which chunks (ChunkSel); `cnt`: how many chunks that is; `rows`: length of a winner row (n; the pilot sample's list scan has its own rows)
-            auto scan_rgb = [&](const int32_t* list, const int32_t* count, bool do13, bool do02, int32_t split = 0, ChunkSel sel = ChunkSel{0, 1, 0, 0, nullptr, 0},
+            auto scan_rgb = [&](const int32_t* list, const int32_t* count, bool do13, bool do02, int32_t split = 0, ChunkSel sel = ChunkSel{0, 1, 0, nullptr, 0},
                                 int32_t cnt = -1, hipStream_t s = nullptr, uint32_t* wins = nullptr, int32_t rows = 0, const uint4* compact = nullptr) {
                 ScanTasks T;
                 T.n = 0;
@@ -2254,7 +2287,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             };
             // a finish phase: list phases launch one workgroup per possible list chunk (they return at once behind the list's end)
             auto finish = [&](auto phase, const int32_t* in_list, const int32_t* in_count, int32_t* out_list, int32_t* out_count,
-                              int32_t* out_list7 = nullptr, int32_t* out_count7 = nullptr, ChunkSel sel = ChunkSel{0, 1, 0, 0, nullptr, 0}, int32_t cnt = -1,
+                              int32_t* out_list7 = nullptr, int32_t* out_count7 = nullptr, ChunkSel sel = ChunkSel{0, 1, 0, nullptr, 0}, int32_t cnt = -1,
                               hipStream_t s = nullptr, const uint32_t* wins = nullptr, int32_t rows = 0, const uint4* in_compact = nullptr, uint4* out_compact = nullptr) {
                 constexpr int PH = decltype(phase)::value;
                 if (cnt < 0) cnt = nchunks;
@@ -2268,7 +2301,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             // a bound's worth of arithmetic per shape on its keys and then fits a few shapes only
             const bool bounded = bc7_bounded_order() && on02 && on13 && !r13;
             if (bc7_alpha_first(S)) {
-                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 8 * sizeof(int32_t), st));  // the finish phases append to the lists through them
+                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 16 * sizeof(int32_t), st));  // the finish phases append to the lists through them
                 if (bounded && on7 && !r7 && (S.mode_selection[2] || S.mode_selection[3])) {
                     // mode 7 bounded too: modes 4,5,6 | 0,2 first, then 1,3 and 7 each over its own list
                     finish(std::integral_constant<int, 6>{}, nullptr, nullptr, rgb_list, rgb_count, list7, count7);
@@ -2294,78 +2327,71 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             } else if (bounded && !on7) {
                 // RGB profiles whose modes 1/3 scan every shape (`slow`).  Round 4: scan {0,2} -> finish<3> (modes 0,2,4,5,6; lists the blocks
                 // whose modes 1/3 an exact bound cannot exclude) -> scan {1,3} over the list -> finish<4>.  Round 5, with a second stream:
-                //  * PILOT.  The order pays where few blocks are listed and costs 4-6 % where nearly all are (photographs: 94 %; the split
-                //    launches are then pure overhead).  Which it is shows in a sample: one chunk in 16, spread over the surface, runs the
-                //    bounded order first; bc7_pilot_decide turns the sample's list length into a device word, and BOTH continuations of the
-                //    rest are enqueued behind it, each gated on that word (ChunkSel.gate): the one the pilot did not choose returns at once.
-                //    No host round trip; the sample's blocks are finished by the bounded order whatever the verdict (same bytes either way).
-                //  * BANDS.  The rest is cut into two bands, one per stream: a band's four dependent launches leave the chip partly empty at
-                //    every boundary (a scan wave runs 0.6 ms), and the other band's work fills those tails (measured: 5.23 -> 4.97 ms on the
-                //    bench surface, 7.30 -> 6.99 on a photograph; four bands are slower again).  The bands' {0,2} scans (common to both
-                //    orders) hide the pilot, which has a third, high-priority stream; their continuations wait for the verdict's event.
-                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 8 * sizeof(int32_t), st));
-                const int period = PILOT_PERIOD;
+                //  * BANDS.  The surface is cut into two interleaved bands (stripes of chunks), one per stream: a band's four dependent
+                //    launches leave the chip partly empty at every boundary (a scan wave runs 0.6 ms), and the other band's work fills those
+                //    tails (5.23 -> 4.98 ms on the bench surface, 7.30 -> 7.00 on a photograph; four bands are slower again).
+                //  * PILOT.  The order pays where few blocks are listed and still costs a little where nearly all are (photographs: 94 %).
+                //    Behind band 0's {0,2} scan -- common to both orders -- bc7_pilot_estimate looks at 1/16 of the surface and leaves a
+                //    device word; BOTH continuations of each band are enqueued behind it, each gated on that word (ChunkSel.gate): the one
+                //    the pilot did not choose returns at once.  No host round trip, no block treated differently from its neighbours.
+                //    (A sample encoded ahead on a third stream was measured first: its chain of small launches could not get its share of a
+                //    chip the bands' scans fill, and the verdict arrived late: profiles/r05d_bc7_pilot_timeline.txt.)
+                ITW_CHECK(hipMemsetAsync(rgb_count, 0, 16 * sizeof(int32_t), st));
                 const bool two = bc7_bands() > 1 && aux && !aux->single && aux->stream && nchunks >= 32;
-                const bool pilot = two && bc7_pilot_threshold() >= 0 && aux->pilot_stream && aux->mid && aux->join3;
-                const int32_t gS = pilot ? nchunks / period : 0;             // the pilot's sample: one chunk of every full group of `period`
-                const int32_t cR = nchunks - gS;                             // chunks of the rest
-                auto rest = [&](int32_t first, const int32_t* gate, int32_t want) { return ChunkSel{2, period, gS, first, gate, want}; };
-                struct Band { int32_t first, cnt; hipStream_t s; int32_t* list; int32_t* count; uint32_t* wins; int32_t rows; uint4* compact; };
-                auto region = [&](const ListRegion& r, int32_t* count) {
-                    return Band{0, 0, nullptr, reinterpret_cast<int32_t*>(wins4 + r.list), count, wins4 + r.wins, (int32_t)r.cap,
-                                compact_on ? reinterpret_cast<uint4*>(wins4 + r.compact) : nullptr};
+                const bool pilot = two && bc7_pilot_threshold() >= 0 && aux->mid;
+                int32_t stripe = nchunks / 16;                               // stripes of 64 chunks (16 block rows of a 4096-wide surface), fewer on small surfaces
+                stripe = stripe < 1 ? 1 : (stripe > 64 ? 64 : stripe);
+                const int32_t stripes = (nchunks + stripe - 1) / stripe;
+                struct Band { ChunkSel sel; int32_t cnt; hipStream_t s; int32_t* list; int32_t* count; uint32_t* wins; int32_t rows; uint4* compact; };
+                auto band = [&](int k, hipStream_t s) {
+                    const ListRegion& r = W.band[k];
+                    Band B{ChunkSel{two ? 1 : 0, stripe, k, nullptr, 0}, two ? ((stripes + 1 - k) / 2) * stripe : nchunks, s,
+                           reinterpret_cast<int32_t*>(wins4 + r.list), band_count + k, wins4 + r.wins, 0, compact_on ? reinterpret_cast<uint4*>(wins4 + r.compact) : nullptr};
+                    B.rows = B.cnt * TPB;                                    // shares x listed blocks <= rows: the list scan's grid covers them (list_scan_parts)
+                    if (!two) { B.list = list13; B.wins = wins4; B.rows = (int32_t)n; }     // one band: the global winner rows, both texel regions as one
+                    return B;
                 };
-                // one band's chain; `gated`: both continuations behind the pilot's word, else the bounded order alone
-                auto chain = [&](const Band& B, bool gated, bool wait_mid) {
-                    scan_rgb(nullptr, nullptr, false, true, 0, rest(B.first, nullptr, 0), B.cnt, B.s);
-                    if (wait_mid) ITW_CHECK(hipStreamWaitEvent(B.s, aux->mid, 0));
-                    finish(std::integral_constant<int, 3>{}, nullptr, nullptr, B.list, B.count, nullptr, nullptr, rest(B.first, gated ? pilot_flag : nullptr, 1), B.cnt, B.s,
-                           nullptr, 0, nullptr, B.compact);
+                auto gated = [&](const Band& B, int32_t want) { ChunkSel g = B.sel; if (pilot) { g.gate = pilot_flag; g.want = want; } return g; };
+                auto head = [&](const Band& B) { scan_rgb(nullptr, nullptr, false, true, 0, B.sel, B.cnt, B.s); };
+                auto tail = [&](const Band& B) {
+                    finish(std::integral_constant<int, 3>{}, nullptr, nullptr, B.list, B.count, nullptr, nullptr, gated(B, 1), B.cnt, B.s, nullptr, 0, nullptr, B.compact);
                     if (!two && aux && aux->verdict && aux->verdict->event) {      // a staged run reports its list length to the host (abi.hip)
                         ITW_CHECK(hipEventRecord(aux->verdict->event, B.s));
                         aux->verdict->listed = B.count; aux->verdict->blocks = (int32_t)n; aux->verdict->valid = true;
                     }
                     scan_rgb(B.list, B.count, true, false, 1, ALL, B.cnt, B.s, B.wins, B.rows, B.compact);    // an empty list (the other order): returns at once
                     finish(std::integral_constant<int, 4>{}, B.list, B.count, nullptr, nullptr, nullptr, nullptr, ALL, B.cnt, B.s, B.wins, B.rows, B.compact);
-                    if (gated) {
-                        scan_rgb(nullptr, nullptr, true, false, 0, rest(B.first, pilot_flag, 0), B.cnt, B.s);
-                        finish(std::integral_constant<int, 0>{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rest(B.first, pilot_flag, 0), B.cnt, B.s);
+                    if (pilot) {
+                        scan_rgb(nullptr, nullptr, true, false, 0, gated(B, 0), B.cnt, B.s);
+                        finish(std::integral_constant<int, 0>{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, gated(B, 0), B.cnt, B.s);
                     }
                 };
                 if (!two) {
-                    Band B = region(W.band[0], band_count);                  // the whole surface: global winner rows, both bands' texel regions as one
-                    B.first = 0; B.cnt = nchunks; B.s = st; B.list = list13; B.wins = wins4; B.rows = (int32_t)n;
-                    chain(B, false, false);
+                    const Band B = band(0, st);
+                    head(B); tail(B);
                 } else {
                     hipStream_t s2 = aux->stream;
                     ITW_CHECK(hipEventRecord(aux->fork, st));                // whatever feeds `src` on st (an upload), and the memset above
                     ITW_CHECK(hipStreamWaitEvent(s2, aux->fork, 0));
-                    Band A = region(W.band[0], band_count), Bb = region(W.band[1], band_count + 1);
-                    A.cnt = cR / 2;
-                    A.first = 0; A.s = st;
-                    Bb.first = A.cnt; Bb.cnt = cR - A.cnt; Bb.s = s2;
-                    A.rows = A.cnt * TPB; Bb.rows = Bb.cnt * TPB;            // shares x listed blocks <= rows: the list scan's grid covers them (list_scan_parts)
+                    const Band A = band(0, st), Bb = band(1, s2);
+                    head(Bb); head(A);
                     if (pilot) {
-                        // the sample's chain on its own high-priority stream: in front of band A it cost its full latency (five small
-                        // launches, 0.4 ms: profiles/r05b_bc7_pilot_plus_bands_timing.txt); beside both bands it only needs its share of the chip
-                        hipStream_t s3 = aux->pilot_stream;
-                        ITW_CHECK(hipStreamWaitEvent(s3, aux->fork, 0));
-                        Band S = region(W.sample, countS);
-                        S.rows = gS * TPB;
-                        const ChunkSel SAMPLE{1, period, gS, 0, nullptr, 0};
-                        scan_rgb(nullptr, nullptr, false, true, 0, SAMPLE, gS, s3);
-                        finish(std::integral_constant<int, 3>{}, nullptr, nullptr, S.list, S.count, nullptr, nullptr, SAMPLE, gS, s3, nullptr, 0, nullptr, S.compact);
-                        hipLaunchKernelGGL(bc7_pilot_decide, dim3(1), dim3(1), 0, s3, countS, gS * TPB, bc7_pilot_threshold(), pilot_flag);
-                        ITW_CHECK(hipEventRecord(aux->mid, s3));               // recorded before the bands' waits for it are enqueued
-                        scan_rgb(S.list, S.count, true, false, 1, ALL, gS, s3, S.wins, S.rows, S.compact);
-                        finish(std::integral_constant<int, 4>{}, S.list, S.count, nullptr, nullptr, nullptr, nullptr, ALL, gS, s3, S.wins, S.rows, S.compact);
-                        ITW_CHECK(hipEventRecord(aux->join3, s3));
+                        const dim3 grid((unsigned)((A.cnt + 7) / 8));
+                        if (L.vec) hipLaunchKernelGGL((bc7_pilot_estimate<true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S.skip_mode2 ? 1 : 0, A.sel, pilot_ctr, bc7_pilot_threshold(), pilot_flag);
+                        else       hipLaunchKernelGGL((bc7_pilot_estimate<false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S.skip_mode2 ? 1 : 0, A.sel, pilot_ctr, bc7_pilot_threshold(), pilot_flag);
+                        ITW_CHECK(hipEventRecord(aux->mid, st));
+                        ITW_CHECK(hipStreamWaitEvent(s2, aux->mid, 0));        // band 1's continuations start behind the verdict
                     }
-                    chain(Bb, pilot, pilot);                                 // (a band's wait for the verdict sits behind its {0,2} scan)
-                    chain(A, pilot, pilot);
-                    if (pilot) ITW_CHECK(hipStreamWaitEvent(st, aux->join3, 0));
+                    tail(Bb); tail(A);
                     ITW_CHECK(hipEventRecord(aux->join, s2));
                     ITW_CHECK(hipStreamWaitEvent(st, aux->join, 0));
+                    if (bc7_pilot_debug()) {
+                        int32_t h[16];
+                        ITW_CHECK(hipStreamSynchronize(st));
+                        ITW_CHECK(hipMemcpy(h, rgb_count, sizeof h, hipMemcpyDeviceToHost));
+                        std::fprintf(stderr, "bc7 pilot: estimate %d of %d sampled blocks listed -> %s; lists %d + %d of %lld blocks\n", h[8], h[9], h[6] ? "bounded" : "reference order",
+                                     h[3], h[4], (long long)n);
+                    }
                 }
             } else {
                 scan_rgb(nullptr, nullptr, true, true);

@@ -29,15 +29,14 @@ bool bc7_staged_bands_ok();      // the staged runs of a host-pointer call may r
 void set_bc7_pilot(int percent);
 // `aux` (optional): a second stream of the same device plus two events the launcher may use to run independent parts of a
 // small call side by side; everything is joined back into `st` before the launcher returns.
-// `pilot_stream`, `mid`, `join3` (may be null: no pilot): a third, high-priority stream and two more events for the pilot of the bounded
-// mode order (bc7.hip).  `single`: the call is one band of a larger job whose bands the CALLER overlaps on two streams (the staged runs
-// of a host-pointer call, abi.hip): deep shape whatever the size, everything on `st`, no pilot, no inner bands.
+// `mid` (may be null: no pilot): a third event, for the pilot of the bounded mode order (bc7.hip).  `single`: the call is one band of a
+// larger job whose bands the CALLER overlaps on two streams (the staged runs of a host-pointer call, abi.hip): deep shape whatever the
+// size, everything on `st`, no pilot, no inner bands.
 // `verdict` (optional, `single` calls): where a call that ran the bounded order reports how many of its blocks still needed modes 1/3 --
 // `event` is recorded behind the kernel that leaves the count; the caller of the first staged run reads it on the HOST (under the upload
 // of the next run) and picks the launch shape of the remaining runs (abi.hip).
 struct Bc7Verdict { hipEvent_t event; const int32_t* listed; int32_t blocks; bool valid; };
-struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; hipEvent_t mid; hipStream_t pilot_stream; hipEvent_t join3; bool single;
-                Bc7Verdict* verdict; };   // wide_max_blocks: 0 = the library default
+struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; hipEvent_t mid; bool single; Bc7Verdict* verdict; };   // wide_max_blocks: 0 = the library default
 void launch_bc7 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                  const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux = nullptr);
 // test hook: bc7_exact.hpp's two_subset_bound of all 64 two-subset shapes of every block, out[block * 64 + shape] (device memory)
