@@ -108,7 +108,8 @@ struct ThreadCtx {
     hipStream_t ws_stream = nullptr; bool ws_used = false;
     hipEvent_t  ws_event = nullptr;                 // recorded after each BC7 call: orders the workspace across streams
     itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr, false, nullptr};
-    itw::Bc7Verdict verdict = {nullptr, nullptr, 0, false};  // second stream + fork/join events for the parallel parts of small BC7 calls
+    itw::Bc7Verdict verdict = {nullptr, nullptr, false};
+    bool staged_wide = false;                       // what the last staged BC7 call's estimate said (used when this call's is not in yet)  // second stream + fork/join events for the parallel parts of small BC7 calls
     int    device = -1;
     char   info[256] = {0};
     ~ThreadCtx() {
@@ -218,10 +219,10 @@ int64_t staged_wide_max_blocks()
     return v < 1 ? 1 : v;
 }
 
-// ITW_STAGED_VERDICT_THR: percent of the first staged run's blocks that may still need modes 1/3 for the remaining runs to stay deep bands
+// ITW_STAGED_VERDICT_THR: percent of the first staged run's sampled blocks the pilot's estimate may list for the remaining runs to stay deep bands
 int staged_verdict_percent()
 {
-    static const int v = [] { const char* e = std::getenv("ITW_STAGED_VERDICT_THR"); return e ? std::atoi(e) : 65; }();
+    static const int v = [] { const char* e = std::getenv("ITW_STAGED_VERDICT_THR"); return e ? std::atoi(e) : 75; }();
     return v;
 }
 
@@ -405,17 +406,20 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
                 for (size_t y = 0; y < nrows; y++)
                     ITW_CHECK(hipMemcpyAsync(in + (y0 + y) * pitch, hs + (int64_t)y * src->stride, row_bytes, hipMemcpyHostToDevice, copy));
             }
-            if (bands && c == 1 && tls.verdict.valid) {
-                // The first run (the top eighth of the surface) ran the bounded order and left the number of its blocks that still needed
-                // modes 1/3.  Its texels went up first and its kernels have been running under the upload of this run, which has just
-                // returned: reading the count costs this host thread next to nothing.  Content where nearly every block is listed
-                // (photographs) gains nothing from the bounded order, and for it the wide shape overlaps staged runs better (8.1 against
-                // 7.4 ms per 4096^2 call, profiles/r05c_*): the remaining runs then go one after the other in the wide shape, as in round 4.
-                int32_t listed = 0;
-                ITW_CHECK(hipStreamWaitEvent(cs, tls.verdict.event, 0));
-                ITW_CHECK(hipMemcpyAsync(&listed, tls.verdict.listed, sizeof listed, hipMemcpyDeviceToHost, cs));
-                ITW_CHECK(hipStreamSynchronize(cs));
-                if ((int64_t)listed * 100 > (int64_t)staged_verdict_percent() * tls.verdict.blocks) { run_as_band = false; run_stream[0] = run_stream[1] = st; }
+            if (bands && c == 1) {
+                // The first run (the top eighth of the surface) is in the bounded order and its pilot's estimate -- how many of its blocks a
+                // two-subset shape could still improve -- is counted right behind its {0,2} scan, which has been running under the upload
+                // of this run.  Content where nearly every block is listed (photographs) gains nothing from the bounded order, and for it
+                // the wide shape overlaps staged runs better (8.1 against 7.4 ms per 4096^2 call, profiles/r05c_*): the remaining runs
+                // then go one after the other in the wide shape, as in round 4.  The host never waits for the estimate: if it is not in
+                // yet, the previous call's verdict stands (successive calls of a save -- mip levels, slices -- hold similar content).
+                if (tls.verdict.valid && hipEventQuery(tls.verdict.event) == hipSuccess) {
+                    int32_t counts[2] = {0, 0};
+                    ITW_CHECK(hipMemcpyAsync(counts, tls.verdict.counts, sizeof counts, hipMemcpyDeviceToHost, cs));
+                    ITW_CHECK(hipStreamSynchronize(cs));
+                    tls.staged_wide = (int64_t)counts[0] * 100 > (int64_t)staged_verdict_percent() * counts[1];
+                } else (void)hipGetLastError();
+                if (tls.staged_wide) { run_as_band = false; run_stream[0] = run_stream[1] = st; }
             }
             if (nch > 1) {
                 ITW_CHECK(hipEventRecord(tls.ev_in[c], cs));

@@ -32,10 +32,11 @@ void set_bc7_pilot(int percent);
 // `mid` (may be null: no pilot): a third event, for the pilot of the bounded mode order (bc7.hip).  `single`: the call is one band of a
 // larger job whose bands the CALLER overlaps on two streams (the staged runs of a host-pointer call, abi.hip): deep shape whatever the
 // size, everything on `st`, no pilot, no inner bands.
-// `verdict` (optional, `single` calls): where a call that ran the bounded order reports how many of its blocks still needed modes 1/3 --
-// `event` is recorded behind the kernel that leaves the count; the caller of the first staged run reads it on the HOST (under the upload
-// of the next run) and picks the launch shape of the remaining runs (abi.hip).
-struct Bc7Verdict { hipEvent_t event; const int32_t* listed; int32_t blocks; bool valid; };
+// `verdict` (optional, `single` calls): where a call that runs the bounded order leaves the pilot's estimate for the HOST -- `counts` =
+// {blocks some two-subset shape can still improve, blocks looked at} in device memory, complete once `event` (recorded behind the kernel
+// that counts) has fired.  The caller of the first staged run polls it under the upload of the next run and picks the launch shape of the
+// remaining runs (abi.hip).
+struct Bc7Verdict { hipEvent_t event; const int32_t* counts; bool valid; };
 struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; hipEvent_t mid; bool single; Bc7Verdict* verdict; };   // wide_max_blocks: 0 = the library default
 void launch_bc7 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                  const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux = nullptr);
