@@ -107,7 +107,9 @@ struct ThreadCtx {
     void*  d_ws = nullptr;  size_t ws_cap = 0;      // BC7 inter-family workspace
     hipStream_t ws_stream = nullptr; bool ws_used = false;
     hipEvent_t  ws_event = nullptr;                 // recorded after each BC7 call: orders the workspace across streams
-    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr, false, nullptr};
+    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr, false, nullptr, false};
+    hipStream_t probe_stream = nullptr;             // the pilot's probe of a staged call whose runs take the wide shape
+    hipEvent_t  probe_done = nullptr;
     itw::Bc7Verdict verdict = {nullptr, nullptr, false};
     bool staged_wide = false;                       // what the last staged BC7 call's estimate said (used when this call's is not in yet)  // second stream + fork/join events for the parallel parts of small BC7 calls
     int    device = -1;
@@ -127,6 +129,8 @@ struct ThreadCtx {
         if (aux.join) (void)hipEventDestroy(aux.join);
         if (aux.mid) (void)hipEventDestroy(aux.mid);
         if (verdict.event) (void)hipEventDestroy(verdict.event);
+        if (probe_stream) (void)hipStreamDestroy(probe_stream);
+        if (probe_done) (void)hipEventDestroy(probe_done);
     }
 };
 thread_local ThreadCtx tls;
@@ -151,6 +155,8 @@ void bind_thread_to_current_device()
     if (tls.aux.join) { (void)hipEventDestroy(tls.aux.join); tls.aux.join = nullptr; }
     if (tls.aux.mid) { (void)hipEventDestroy(tls.aux.mid); tls.aux.mid = nullptr; }
     if (tls.verdict.event) { (void)hipEventDestroy(tls.verdict.event); tls.verdict.event = nullptr; }
+    if (tls.probe_stream) { (void)hipStreamDestroy(tls.probe_stream); tls.probe_stream = nullptr; }
+    if (tls.probe_done) { (void)hipEventDestroy(tls.probe_done); tls.probe_done = nullptr; }
     tls.device = dev;
 }
 
@@ -235,6 +241,8 @@ void ensure_bc7_aux()
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join, hipEventDisableTiming));
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.mid, hipEventDisableTiming));
     ITW_CHECK(hipEventCreateWithFlags(&tls.verdict.event, hipEventDisableTiming));
+    ITW_CHECK(hipStreamCreateWithFlags(&tls.probe_stream, hipStreamNonBlocking));
+    ITW_CHECK(hipEventCreateWithFlags(&tls.probe_done, hipEventDisableTiming));
 }
 
 // `band` >= 0: a staged run of a host-pointer BC7 call that compress() overlaps with its neighbours on two streams; it runs in the deep
@@ -248,12 +256,14 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
     case Fmt::BC7:
         ensure_bc7_aux();
         tls.aux.wide_max_blocks = staged ? staged_wide_max_blocks() : 0;
-        tls.aux.single = band >= 0;
-        if (band >= 0) {
-            tls.aux.verdict = band == 0 ? &tls.verdict : nullptr;   // the first run reports how many of its blocks needed modes 1/3
-            if (band == 0) tls.verdict.valid = false;
+        tls.aux.single = band >= 0 || band == -2;
+        if (tls.aux.single) {
+            // band 0 leaves the pilot's estimate for the host; band -2 is a PROBE: the estimate alone (the run itself takes the wide shape)
+            tls.aux.verdict = (band == 0 || band == -2) ? &tls.verdict : nullptr;
+            tls.aux.probe = band == -2;
+            if (tls.aux.verdict) tls.verdict.valid = false;
             itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(static_cast<uint8_t*>(tls.d_ws) + ws_off), st, &tls.aux);
-            tls.aux.verdict = nullptr;
+            tls.aux.verdict = nullptr; tls.aux.probe = false;
         } else {
             float* ws = bc7_workspace(w, h, st, tls.aux.wide_max_blocks);         // (sized and ordered already when ws_off != 0)
             itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(ws) + ws_off), st, &tls.aux);
@@ -349,31 +359,38 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
             for (int c = 0; c < n; c++) { int r = (int)(by * f[c]); cut[c + 1] = r < cut[c] + 1 ? cut[c] + 1 : (r > by - (n - c) ? by - (n - c) : r); }
         }
     }
-    // Round 5: the runs of a BC7 call are BANDS -- run c's kernels go to stream (c + 1) % 2 (the first, short run to the second stream), each run in the deep shape with its own slice of the
-    // workspace, so that one run's launch tails are filled by its neighbour's work as soon as that neighbour's texels have arrived (the
-    // device-resident path does the same with the two halves of a surface, bc7.hip).  ITW_STAGED_BANDS=0: round 4's runs, one after the
-    // other in the wide shape.
+    // Round 5: the runs of a BC7 call are BANDS -- run c's kernels go to stream (c + 1) % 2 (the first, short run to the second stream),
+    // each run in the deep shape with its own slice of the workspace, so that one run's launch tails are filled by its neighbour's work as
+    // soon as that neighbour's texels have arrived (the device-resident path does the same with the two halves of a surface, bc7.hip).
+    // Content where nearly every block still needs modes 1/3 (photographs) gains nothing from the bounded order, and for it the WIDE shape,
+    // one run after the other, overlaps staged runs better (8.1 against 7.4 ms per 4096^2 call, profiles/r05c_*).  Which it is comes
+    // from the pilot's estimate (bc7.hip bc7_pilot_estimate): counted behind the first run's {0,2} scan when that run is a band, by a
+    // probe on a stream of its own when it is wide.  The host never waits for it: the first run takes the shape the PREVIOUS call's
+    // estimate asked for (successive calls of a save -- mip levels, slices -- hold similar content), later runs this call's as soon as
+    // it is in (polled under the uploads), and it is read once more behind the call's last synchronisation for the next call.
+    // ITW_STAGED_BANDS=0: round 4's runs, one after the other in the wide shape.
     const bool bands = j.fmt == Fmt::BC7 && nch > 1 && !src_dev && itw::bc7_staged_bands_ok();
-    size_t ws_off[9] = {0};
-    hipStream_t run_stream[2] = {st, st};                    // [(c + 1) & 1] is run c's stream
+    size_t band_off[9] = {0}, probe_off = 0;                 // workspace: [wide runs (they follow each other on st)] [probe] [band 0] [band 1] ...
     if (bands) {
         ensure_bc7_aux();
         size_t total = 0;
         for (int c = 0; c < nch; c++) {
-            ws_off[c] = total;
+            const int run_rows = (cut[c + 1] - cut[c]) * 4;
+            if (run_rows <= 0) continue;
+            const size_t b = (itw::bc7_workspace_bytes(w, run_rows, staged_wide_max_blocks()) + 255) & ~(size_t)255;
+            if (b > total) total = b;
+        }
+        probe_off = total;
+        total += (itw::bc7_workspace_bytes(w, (cut[1] - cut[0]) * 4, 1) + 255) & ~(size_t)255;
+        for (int c = 0; c < nch; c++) {
+            band_off[c] = total;
             const int run_rows = (cut[c + 1] - cut[c]) * 4;
             if (run_rows > 0) total += (itw::bc7_workspace_bytes(w, run_rows, 1) + 255) & ~(size_t)255;
         }
-        for (int c = 1; c < nch; c++) {                       // a later run may take the wide shape instead (the verdict below): room for that too
-            const int run_rows = (cut[c + 1] - cut[c]) * 4;
-            if (run_rows <= 0) continue;
-            const size_t b = ws_off[1] + itw::bc7_workspace_bytes(w, run_rows, staged_wide_max_blocks());   // behind the first run's slice: that run may still be going
-            if (b > total) total = b;
-        }
         reserve_workspace(total, st);
-        run_stream[1] = tls.aux.stream;
-        ITW_CHECK(hipEventRecord(tls.aux.fork, st));          // the second stream starts behind whatever ordered the workspace on the first
-        ITW_CHECK(hipStreamWaitEvent(run_stream[1], tls.aux.fork, 0));
+        ITW_CHECK(hipEventRecord(tls.aux.fork, st));          // the other streams start behind whatever ordered the workspace on the first
+        ITW_CHECK(hipStreamWaitEvent(tls.aux.stream, tls.aux.fork, 0));
+        ITW_CHECK(hipStreamWaitEvent(tls.probe_stream, tls.aux.fork, 0));
     } else
     if (j.fmt == Fmt::BC7 || j.fmt == Fmt::BC6H) {
         // Size the workspace once for the most demanding run: growing it frees it, and hipFree waits for the runs in flight.
@@ -390,12 +407,25 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         if (need) reserve_workspace(need, st);
     }
     hipStream_t copy = (nch > 1) ? cs : st;
-    bool run_as_band = bands;
+    bool shape_wide = bands && tls.staged_wide && itw::bc7_has_order_verdict(*j.s7);   // the shape of the next run (profiles without a verdict: bands)
+    bool verdict_pending = false, probed = false;
+    auto poll_verdict = [&](bool wait) {                      // this call's estimate, if it is in (or, `wait`: now that everything is done)
+        if (!verdict_pending || !tls.verdict.valid) return;
+        if (!wait && hipEventQuery(tls.verdict.event) != hipSuccess) { (void)hipGetLastError(); return; }
+        int32_t counts[2] = {0, 0};
+        if (wait) ITW_CHECK(hipEventSynchronize(tls.verdict.event));
+        ITW_CHECK(hipMemcpyAsync(counts, tls.verdict.counts, sizeof counts, hipMemcpyDeviceToHost, cs));
+        ITW_CHECK(hipStreamSynchronize(cs));
+        if (counts[1] > 0) tls.staged_wide = (int64_t)counts[0] * 100 > (int64_t)staged_verdict_percent() * counts[1];
+        verdict_pending = false;
+    };
     int c = 0;
     for (c = 0; c < nch; c++) {
         const int row0 = cut[c], nb = cut[c + 1] - cut[c];
         const size_t y0 = (size_t)row0 * 4;
         const size_t nrows = (rows - y0 < (size_t)nb * 4) ? rows - y0 : (size_t)nb * 4;
+        if (bands && c > 0 && verdict_pending) { poll_verdict(false); if (!verdict_pending) shape_wide = tls.staged_wide; }
+        hipStream_t run_st = (bands && !shape_wide && ((c + 1) & 1)) ? tls.aux.stream : st;
         if (!src_dev) {
             const uint8_t* hs = src->ptr + (int64_t)y0 * src->stride;
             if ((int64_t)src->stride >= (int64_t)row_bytes) {      // (also for tight rows: measured faster than one linear pageable copy)
@@ -406,30 +436,23 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
                 for (size_t y = 0; y < nrows; y++)
                     ITW_CHECK(hipMemcpyAsync(in + (y0 + y) * pitch, hs + (int64_t)y * src->stride, row_bytes, hipMemcpyHostToDevice, copy));
             }
-            if (bands && c == 1) {
-                // The first run (the top eighth of the surface) is in the bounded order and its pilot's estimate -- how many of its blocks a
-                // two-subset shape could still improve -- is counted right behind its {0,2} scan, which has been running under the upload
-                // of this run.  Content where nearly every block is listed (photographs) gains nothing from the bounded order, and for it
-                // the wide shape overlaps staged runs better (8.1 against 7.4 ms per 4096^2 call, profiles/r05c_*): the remaining runs
-                // then go one after the other in the wide shape, as in round 4.  The host never waits for the estimate: if it is not in
-                // yet, the previous call's verdict stands (successive calls of a save -- mip levels, slices -- hold similar content).
-                if (tls.verdict.valid && hipEventQuery(tls.verdict.event) == hipSuccess) {
-                    int32_t counts[2] = {0, 0};
-                    ITW_CHECK(hipMemcpyAsync(counts, tls.verdict.counts, sizeof counts, hipMemcpyDeviceToHost, cs));
-                    ITW_CHECK(hipStreamSynchronize(cs));
-                    tls.staged_wide = (int64_t)counts[0] * 100 > (int64_t)staged_verdict_percent() * counts[1];
-                } else (void)hipGetLastError();
-                if (tls.staged_wide) { run_as_band = false; run_stream[0] = run_stream[1] = st; }
-            }
             if (nch > 1) {
                 ITW_CHECK(hipEventRecord(tls.ev_in[c], cs));
-                ITW_CHECK(hipStreamWaitEvent(run_stream[(c + 1) & 1], tls.ev_in[c], 0));
+                ITW_CHECK(hipStreamWaitEvent(run_st, tls.ev_in[c], 0));
             }
         }
-        launch(j, d_src + (int64_t)y0 * d_stride, d_stride, w, (int)nrows, d_dst + (size_t)row0 * bx * bpb, run_stream[(c + 1) & 1], !src_dev && !dst_dev,
-               run_as_band ? c : -1, run_as_band ? ws_off[c] : (bands ? ws_off[1] : 0));
+        const uint8_t* run_src = d_src + (int64_t)y0 * d_stride;
+        uint8_t* run_dst = d_dst + (size_t)row0 * bx * bpb;
+        if (bands && c == 0 && shape_wide) {                  // the first run goes wide: the estimate comes from a probe beside it
+            ITW_CHECK(hipStreamWaitEvent(tls.probe_stream, tls.ev_in[0], 0));
+            launch(j, run_src, d_stride, w, (int)nrows, run_dst, tls.probe_stream, true, -2, probe_off);
+            probed = true;
+        }
+        if (bands && !shape_wide) launch(j, run_src, d_stride, w, (int)nrows, run_dst, run_st, true, c, band_off[c]);
+        else                      launch(j, run_src, d_stride, w, (int)nrows, run_dst, run_st, !src_dev && !dst_dev);
+        if (bands && c == 0) verdict_pending = tls.verdict.valid;
         if (!dst_dev && nch > 1) {
-            ITW_CHECK(hipEventRecord(tls.ev_done[c], run_stream[(c + 1) & 1]));
+            ITW_CHECK(hipEventRecord(tls.ev_done[c], run_st));
             if (c > 0) {                               // download the previous run while this one computes
                 const size_t off = (size_t)cut[c - 1] * bx * bpb, len = (size_t)(cut[c] - cut[c - 1]) * bx * bpb;
                 ITW_CHECK(hipStreamWaitEvent(cs, tls.ev_done[c - 1], 0));
@@ -450,9 +473,14 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     if (bands) {                                              // everything back into st; the workspace's event behind all of it
         ITW_CHECK(hipEventRecord(tls.aux.join, tls.aux.stream));
         ITW_CHECK(hipStreamWaitEvent(st, tls.aux.join, 0));
+        if (probed) {
+            ITW_CHECK(hipEventRecord(tls.probe_done, tls.probe_stream));
+            ITW_CHECK(hipStreamWaitEvent(st, tls.probe_done, 0));
+        }
         ITW_CHECK(hipEventRecord(tls.ws_event, st));
     }
     ITW_CHECK(hipStreamSynchronize(st));
+    if (bands) poll_verdict(true);                            // for the next call, if it was not in before
 }
 
 // ---- joining concurrent small calls ----------------------------------------------------------------------------------

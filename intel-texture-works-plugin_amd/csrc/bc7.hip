@@ -1374,6 +1374,7 @@ struct ScanTasks { int n; int kind[3]; };      // WK_SCAN02 / WK_SCAN13 / WK_SCA
 // Round 5, the BANDS and the PILOT of the bounded order (launch_bc7): which chunks (runs of TPB blocks) of the surface a launch of
 // bc7_scan_all / bc7_finish_all walks, and whether it runs at all.
 //   kind 0  every chunk: workgroup i -> chunk i
+//   kind 2  every eighth chunk (8 i + 3): what bc7_pilot_estimate looks at, for a probe that scans nothing else
 //   kind 1  a BAND: the surface is cut into stripes of `stripe` chunks, even stripes are band 0, odd stripes band 1 (two interleaved
 //           halves, so that both see all of the surface's content); workgroup i takes the i-th chunk of band `band`
 // `gate` (optional): a device word written by bc7_pilot_estimate before this launch starts; the launch returns at once unless it holds
@@ -1382,6 +1383,7 @@ struct ChunkSel { int32_t kind, stripe, band; const int32_t* gate; int32_t want;
 __device__ __forceinline__ int32_t sel_chunk(const ChunkSel& s, int32_t i)
 {
     if (s.kind == 0) return i;
+    if (s.kind == 2) return i * 8 + 3;
     const int32_t q = i / s.stripe;
     return (2 * q + s.band) * s.stripe + (i - q * s.stripe);
 }
@@ -2023,6 +2025,11 @@ static bool bc7_compact_lists()
     static const bool on = [] { const char* e = std::getenv("ITW_BC7_COMPACT"); return !(e && e[0] == '0'); }();
     return on;
 }
+static bool bc7_fused_on()
+{
+    static const bool on = [] { const char* e = std::getenv("ITW_BC7_FUSED"); return !(e && e[0] == '0'); }();
+    return on;
+}
 static bool bc7_alpha_first(const bc7_enc_settings& S)
 {
     static const bool on = [] { const char* e = std::getenv("ITW_BC7_ALPHA_PRUNE"); return !(e && e[0] == '0'); }();
@@ -2195,6 +2202,17 @@ static void launch_bc7_wide(const uint8_t* src, int64_t stride, int bx, int64_t 
     hipLaunchKernelGGL(bc7_wide_commit, dim3(gx), blk, 0, st, cerr, cblk, (int32_t)n, active, reinterpret_cast<uint4*>(dst), vec ? 1 : 0);
 }
 
+// does a call with these settings run the bounded order of the RGB profiles (`slow`: the one order with a pilot)?
+bool bc7_has_order_verdict(const bc7_enc_settings& s)
+{
+    bc7_enc_settings S = s;
+    S.channels = (s.channels == 4) ? 4 : 3;
+    auto ranked = [](int t) { return t > 0 && t < 64; };
+    const bool on13 = S.mode_selection[1] && (S.fastSkipTreshold_mode1 > 0 || S.fastSkipTreshold_mode3 > 0);
+    return bc7_fused_on() && bc7_bounded_order() && S.mode_selection[0] && on13 && !ranked(S.fastSkipTreshold_mode1) && !ranked(S.fastSkipTreshold_mode3) &&
+           !(S.mode_selection[1] && S.fastSkipTreshold_mode7 > 0) && !bc7_alpha_first(S);
+}
+
 // Families run in the reference's order (kernel.ispc:1970-1977): {0,2} -> {1,3} -> {7} -> {4,5} -> {6}.
 void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                 const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux)
@@ -2206,6 +2224,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
     L.S = s;
     L.S.channels = (s.channels == 4) ? 4 : 3;
     const bool single = aux && aux->single;
+    if (aux && aux->probe && !bc7_has_order_verdict(L.S)) return;   // only the bounded order of the RGB profiles has a verdict to estimate
     if (!single && bc7_use_wide(n, L.S, aux ? aux->wide_max_blocks : 0)) { launch_bc7_wide(src, stride, bx, n, dst, L.S, workspace, st, aux); return; }
     L.err = reinterpret_cast<int32_t*>(workspace);
     L.wins = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(workspace) + (((size_t)n * sizeof(int32_t) + 15) & ~(size_t)15));
@@ -2218,7 +2237,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
     {
         // two launches (scan of all families, refinement of all modes) unless a ranked list is longer than 16 shapes (those
         // keep their keys in 64 KiB of LDS: the per-family kernels below) or ITW_BC7_FUSED=0
-        static const bool fused_on = [] { const char* e = std::getenv("ITW_BC7_FUSED"); return !(e && e[0] == '0'); }();
+        const bool fused_on = bc7_fused_on();
         const bool on02 = S.mode_selection[0];
         const bool on13 = S.mode_selection[1] && (S.fastSkipTreshold_mode1 > 0 || S.fastSkipTreshold_mode3 > 0);
         const bool on7 = S.mode_selection[1] && S.fastSkipTreshold_mode7 > 0;
@@ -2365,7 +2384,9 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                 };
                 if (!two) {
                     const Band B = band(0, st);
-                    head(B);
+                    const bool probe = aux && aux->probe && aux->verdict && aux->verdict->event;
+                    if (probe) scan_rgb(nullptr, nullptr, false, true, 0, ChunkSel{2, 1, 0, nullptr, 0}, (nchunks + 7) / 8, st);
+                    else head(B);
                     if (aux && aux->verdict && aux->verdict->event) {
                         // a staged run of a host-pointer call (abi.hip): the same estimate, left for the HOST to read under the next
                         // run's upload -- it picks the launch shape of the remaining runs
@@ -2375,6 +2396,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                         ITW_CHECK(hipEventRecord(aux->verdict->event, st));
                         aux->verdict->counts = pilot_ctr; aux->verdict->valid = true;
                     }
+                    if (probe) return;
                     tail(B);
                 } else {
                     hipStream_t s2 = aux->stream;

@@ -23,6 +23,7 @@ size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks = 0); 
 // BC7 launch shape: 0 = by call size (default), 1 = deep (one lane per block, a launch pair per mode family: fills the
 // chip on whole surfaces), 2 = wide (split scans + ordered argmin: small calls).  Same blocks either way.
 void set_bc7_path(int path);
+bool bc7_has_order_verdict(const bc7_enc_settings& s);   // the settings run the bounded order of the RGB profiles (the one with a pilot's estimate)
 bool bc7_staged_bands_ok();      // the staged runs of a host-pointer call may run as overlapped deep bands (not when the wide shape is forced / ITW_STAGED_BANDS=0)
 // The pilot of the bounded BC7 mode order (bc7.hip, launch_bc7): percent of the sample's blocks that may still need modes 1/3 for the rest of
 // the surface to take the bounded order; -1 = no pilot, the whole call in the bounded order.  Same blocks whatever the value.
@@ -37,7 +38,9 @@ void set_bc7_pilot(int percent);
 // that counts) has fired.  The caller of the first staged run polls it under the upload of the next run and picks the launch shape of the
 // remaining runs (abi.hip).
 struct Bc7Verdict { hipEvent_t event; const int32_t* counts; bool valid; };
-struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; hipEvent_t mid; bool single; Bc7Verdict* verdict; };   // wide_max_blocks: 0 = the library default
+// `probe` (with `single` and `verdict`): only the pilot's estimate is computed -- the {0,2} scan of every eighth chunk and the count -- nothing
+// is encoded (a staged call whose runs take the wide shape keeps its verdict fresh this way).
+struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; hipEvent_t mid; bool single; Bc7Verdict* verdict; bool probe; };   // wide_max_blocks: 0 = the library default
 void launch_bc7 (const uint8_t* src, int64_t stride, int width, int height, uint8_t* dst,
                  const bc7_enc_settings& s, float* workspace, hipStream_t st, const Bc7Aux* aux = nullptr);
 // test hook: bc7_exact.hpp's two_subset_bound of all 64 two-subset shapes of every block, out[block * 64 + shape] (device memory)

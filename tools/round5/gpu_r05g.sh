@@ -1,6 +1,6 @@
-# round 5, batch f: staged runs with the non-blocking estimate verdict; the reference's own callers
+# round 5, batch g: staged runs (shape of run 0 from the cached verdict, probe beside a wide run 0); the reference's own callers
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r05f; mkdir -p $O
+O=gpurun_out/r05g; mkdir -p $O
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_host_pointer_runs.py tests/test_gpu_bc7_bound.py tests/test_dispatch_layer.py tests/test_example_host.py -m gpu -x -q 2>&1 | tail -8 | tee $O/pytest_gpu.txt
 T="timeout 300 python tools/round5/order_timing.py"
@@ -10,4 +10,4 @@ T="timeout 300 python tools/round5/order_timing.py"
   ITW_STAGED_VERDICT_THR=0 $T I3 baboon
   ORDER_PROFILES=basic,alpha_slow $T I3 baboon
 } 2>&1 | grep -v amdgpu.ids | tee $O/order_timing.txt
-timeout 600 python tools/ref_caller_timing.py 4096 8,64 2>&1 | grep -v amdgpu.ids | tee $O/reference_caller_timing.jsonl
+
