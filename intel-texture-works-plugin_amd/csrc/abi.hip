@@ -414,8 +414,9 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         if (!wait && hipEventQuery(tls.verdict.event) != hipSuccess) { (void)hipGetLastError(); return; }
         int32_t counts[2] = {0, 0};
         if (wait) ITW_CHECK(hipEventSynchronize(tls.verdict.event));
-        ITW_CHECK(hipMemcpyAsync(counts, tls.verdict.counts, sizeof counts, hipMemcpyDeviceToHost, cs));
-        ITW_CHECK(hipStreamSynchronize(cs));
+        // (on the probe's stream, which holds nothing else: the copy stream has this call's downloads queued behind kernels)
+        ITW_CHECK(hipMemcpyAsync(counts, tls.verdict.counts, sizeof counts, hipMemcpyDeviceToHost, tls.probe_stream));
+        ITW_CHECK(hipStreamSynchronize(tls.probe_stream));
         if (counts[1] > 0) tls.staged_wide = (int64_t)counts[0] * 100 > (int64_t)staged_verdict_percent() * counts[1];
         verdict_pending = false;
     };
