@@ -108,8 +108,6 @@ struct ThreadCtx {
     hipStream_t ws_stream = nullptr; bool ws_used = false;
     hipEvent_t  ws_event = nullptr;                 // recorded after each BC7 call: orders the workspace across streams
     itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr, false, nullptr, false};
-    hipStream_t probe_stream = nullptr;             // the pilot's probe of a staged call whose runs take the wide shape
-    hipEvent_t  probe_done = nullptr;
     itw::Bc7Verdict verdict = {nullptr, nullptr, false};
     bool staged_wide = false;                       // what the last staged BC7 call's estimate said (used when this call's is not in yet)  // second stream + fork/join events for the parallel parts of small BC7 calls
     int    device = -1;
@@ -129,8 +127,6 @@ struct ThreadCtx {
         if (aux.join) (void)hipEventDestroy(aux.join);
         if (aux.mid) (void)hipEventDestroy(aux.mid);
         if (verdict.event) (void)hipEventDestroy(verdict.event);
-        if (probe_stream) (void)hipStreamDestroy(probe_stream);
-        if (probe_done) (void)hipEventDestroy(probe_done);
     }
 };
 thread_local ThreadCtx tls;
@@ -155,8 +151,6 @@ void bind_thread_to_current_device()
     if (tls.aux.join) { (void)hipEventDestroy(tls.aux.join); tls.aux.join = nullptr; }
     if (tls.aux.mid) { (void)hipEventDestroy(tls.aux.mid); tls.aux.mid = nullptr; }
     if (tls.verdict.event) { (void)hipEventDestroy(tls.verdict.event); tls.verdict.event = nullptr; }
-    if (tls.probe_stream) { (void)hipStreamDestroy(tls.probe_stream); tls.probe_stream = nullptr; }
-    if (tls.probe_done) { (void)hipEventDestroy(tls.probe_done); tls.probe_done = nullptr; }
     tls.device = dev;
 }
 
@@ -241,8 +235,6 @@ void ensure_bc7_aux()
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join, hipEventDisableTiming));
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.mid, hipEventDisableTiming));
     ITW_CHECK(hipEventCreateWithFlags(&tls.verdict.event, hipEventDisableTiming));
-    ITW_CHECK(hipStreamCreateWithFlags(&tls.probe_stream, hipStreamNonBlocking));
-    ITW_CHECK(hipEventCreateWithFlags(&tls.probe_done, hipEventDisableTiming));
 }
 
 // `band` >= 0: a staged run of a host-pointer BC7 call that compress() overlaps with its neighbours on two streams; it runs in the deep
@@ -365,7 +357,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     // Content where nearly every block still needs modes 1/3 (photographs) gains nothing from the bounded order, and for it the WIDE shape,
     // one run after the other, overlaps staged runs better (8.1 against 7.4 ms per 4096^2 call, profiles/r05c_*).  Which it is comes
     // from the pilot's estimate (bc7.hip bc7_pilot_estimate): counted behind the first run's {0,2} scan when that run is a band, by a
-    // probe on a stream of its own when it is wide.  The host never waits for it: the first run takes the shape the PREVIOUS call's
+    // probe on the second stream when it is wide.  The host never waits for it: the first run takes the shape the PREVIOUS call's
     // estimate asked for (successive calls of a save -- mip levels, slices -- hold similar content), later runs this call's as soon as
     // it is in (polled under the uploads), and it is read once more behind the call's last synchronisation for the next call.
     // ITW_STAGED_BANDS=0: round 4's runs, one after the other in the wide shape.
@@ -390,7 +382,6 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         reserve_workspace(total, st);
         ITW_CHECK(hipEventRecord(tls.aux.fork, st));          // the other streams start behind whatever ordered the workspace on the first
         ITW_CHECK(hipStreamWaitEvent(tls.aux.stream, tls.aux.fork, 0));
-        ITW_CHECK(hipStreamWaitEvent(tls.probe_stream, tls.aux.fork, 0));
     } else
     if (j.fmt == Fmt::BC7 || j.fmt == Fmt::BC6H) {
         // Size the workspace once for the most demanding run: growing it frees it, and hipFree waits for the runs in flight.
@@ -408,15 +399,16 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     }
     hipStream_t copy = (nch > 1) ? cs : st;
     bool shape_wide = bands && tls.staged_wide && itw::bc7_has_order_verdict(*j.s7);   // the shape of the next run (profiles without a verdict: bands)
-    bool verdict_pending = false, probed = false;
+    bool verdict_pending = false;
     auto poll_verdict = [&](bool wait) {                      // this call's estimate, if it is in (or, `wait`: now that everything is done)
         if (!verdict_pending || !tls.verdict.valid) return;
         if (!wait && hipEventQuery(tls.verdict.event) != hipSuccess) { (void)hipGetLastError(); return; }
         int32_t counts[2] = {0, 0};
         if (wait) ITW_CHECK(hipEventSynchronize(tls.verdict.event));
-        // (on the probe's stream, which holds nothing else: the copy stream has this call's downloads queued behind kernels)
-        ITW_CHECK(hipMemcpyAsync(counts, tls.verdict.counts, sizeof counts, hipMemcpyDeviceToHost, tls.probe_stream));
-        ITW_CHECK(hipStreamSynchronize(tls.probe_stream));
+        // a synchronous 8-byte copy: the event has fired, and the library's streams are non-blocking, so the null stream waits for nothing
+        // (not the copy stream: it has this call's downloads queued behind kernels; and no stream of its own: a process has four hardware
+        // queues, a fifth stream shares one with a neighbour and serialises with it -- measured: +0.8 ms per call)
+        ITW_CHECK(hipMemcpy(counts, tls.verdict.counts, sizeof counts, hipMemcpyDeviceToHost));
         if (counts[1] > 0) tls.staged_wide = (int64_t)counts[0] * 100 > (int64_t)staged_verdict_percent() * counts[1];
         verdict_pending = false;
     };
@@ -444,13 +436,13 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         }
         const uint8_t* run_src = d_src + (int64_t)y0 * d_stride;
         uint8_t* run_dst = d_dst + (size_t)row0 * bx * bpb;
-        if (bands && c == 0 && shape_wide) {                  // the first run goes wide: the estimate comes from a probe beside it
-            ITW_CHECK(hipStreamWaitEvent(tls.probe_stream, tls.ev_in[0], 0));
-            launch(j, run_src, d_stride, w, (int)nrows, run_dst, tls.probe_stream, true, -2, probe_off);
-            probed = true;
-        }
         if (bands && !shape_wide) launch(j, run_src, d_stride, w, (int)nrows, run_dst, run_st, true, c, band_off[c]);
         else                      launch(j, run_src, d_stride, w, (int)nrows, run_dst, run_st, !src_dev && !dst_dev);
+        if (bands && c == 0 && shape_wide) {
+            // the first run went wide: the estimate comes from a probe on the second stream, behind that run's single-subset modes
+            ITW_CHECK(hipStreamWaitEvent(tls.aux.stream, tls.ev_in[0], 0));
+            launch(j, run_src, d_stride, w, (int)nrows, run_dst, tls.aux.stream, true, -2, probe_off);
+        }
         if (bands && c == 0) verdict_pending = tls.verdict.valid;
         if (!dst_dev && nch > 1) {
             ITW_CHECK(hipEventRecord(tls.ev_done[c], run_st));
@@ -474,10 +466,6 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     if (bands) {                                              // everything back into st; the workspace's event behind all of it
         ITW_CHECK(hipEventRecord(tls.aux.join, tls.aux.stream));
         ITW_CHECK(hipStreamWaitEvent(st, tls.aux.join, 0));
-        if (probed) {
-            ITW_CHECK(hipEventRecord(tls.probe_done, tls.probe_stream));
-            ITW_CHECK(hipStreamWaitEvent(st, tls.probe_done, 0));
-        }
         ITW_CHECK(hipEventRecord(tls.ws_event, st));
     }
     ITW_CHECK(hipStreamSynchronize(st));
