@@ -88,14 +88,16 @@ def _make_surface(fmt, size, rank):
     return surfaces.ldr_smooth(size, size, seed=surfaces.SEED + 100 * rank)
 
 
-def plan(scaling, size, world, rank, fmt):
+def plan(scaling, size, world, rank, fmt, piece=0, pieces=1):
     """Geometry of the job and of this rank's share.  Pure (no GPU): tests/test_sharding_gloo.py checks it.
     weak  : surface = size wide x (size * world) tall, rank r owns the r-th size x size band.
-    strong: surface = size x size (BASELINE configs[4] at size 16384), rank r owns block rows [R*r/N, R*(r+1)/N).
+    strong: surface = size x size (BASELINE configs[4] at size 16384), rank r owns block rows [R*r/N, R*(r+1)/N) -- or, with
+            pieces = K > 1 (the content-aware partition, include/itw_multigpu.h), its `piece`-th of K interleaved sub-bands: sub-band
+            piece * N + r of K * N.
     Returns dict(width, height, y0, rows, band_off, band_bytes, total_bytes)."""
     from itw_amd import shard, abi
     width, height = (size, size * world) if scaling == "weak" else (size, size)
-    y0, rows, off, nbytes = shard.band_of(width, height, fmt, rank, world)
+    y0, rows, off, nbytes = shard.sub_band_of(width, height, fmt, rank, world, piece, pieces)
     total = (width // 4) * (height // 4) * abi.BYTES_PER_BLOCK[fmt]
     return {"width": width, "height": height, "y0": y0, "rows": rows, "band_off": off, "band_bytes": nbytes, "total_bytes": total}
 
@@ -133,7 +135,7 @@ def make_encoder(itw, fmt, prof, img, dev):
     return (lambda out: itw.compress(fmt, d_img, prof, out=out)), d_img
 
 
-def verify_gather(itw, dist, full, scaling, size, world, rank, fmt, prof, dev):
+def verify_gather(itw, dist, full, scaling, size, world, rank, fmt, prof, dev, pieces=1):
     """Correctness of the N > 1 job, after the timed region: `full` is the whole-image stream the last step's all-gather
     left on this rank.  This rank re-encodes (a) its own band -- it must have survived the in-place gather -- and (b) the
     bands of ranks rank+1 and rank+N/2 (so every band is checked by up to three different ranks) from the same seeded
@@ -144,14 +146,15 @@ def verify_gather(itw, dist, full, scaling, size, world, rank, fmt, prof, dev):
             targets.append(r)
     bad_bytes = 0
     for r in targets:
-        g = plan(scaling, size, world, r, fmt)
-        enc, keep = make_encoder(itw, fmt, prof, make_band(fmt, scaling, size, g, r), dev)
-        ref = torch.empty(g["band_bytes"], dtype=torch.uint8, device=dev)
-        enc(ref)
-        _sync()
-        bad_bytes += int((ref != full[g["band_off"]:g["band_off"] + g["band_bytes"]]).sum().item())
-        del ref, keep, enc
-    t = torch.tensor([bad_bytes, len(targets)], dtype=torch.int64, device=dev)
+        for k in range(pieces):                              # (pieces > 1: every sub-band of that rank)
+            g = plan(scaling, size, world, r, fmt, k, pieces)
+            enc, keep = make_encoder(itw, fmt, prof, make_band(fmt, scaling, size, g, r), dev)
+            ref = torch.empty(g["band_bytes"], dtype=torch.uint8, device=dev)
+            enc(ref)
+            _sync()
+            bad_bytes += int((ref != full[g["band_off"]:g["band_off"] + g["band_bytes"]]).sum().item())
+            del ref, keep, enc
+    t = torch.tensor([bad_bytes, len(targets) * pieces], dtype=torch.int64, device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return {"gather_verified": int(t[0].item()) == 0, "mismatching_bytes": int(t[0].item()), "band_checks": int(t[1].item()),
@@ -407,24 +410,25 @@ def cpp_job(itw, fmt, prof, size, ranks, steps, warmup, scatter_steps=0):
     two all-device synchronisations.  Afterwards EVERY band of the gathered image is compared with a fresh single-GPU encode."""
     ndev = torch.cuda.device_count()
     bands, geos = [], []
-    for r in range(ranks):
-        g = plan("strong", size, ranks, r, fmt)
+    K = itw.lib().itwMultiGpuPieces(size, ranks, 0)          # sub-bands per rank the library uses for this geometry (itw_multigpu.h; default 4)
+    for j in range(K * ranks):                               # sub-band j of K * ranks, resident on the device of rank j % ranks
+        g = plan("strong", size, ranks, j % ranks, fmt, j // ranks, K)
         geos.append(g)
-        bands.append(torch.from_numpy(make_band(fmt, "strong", size, g, r)).to(f"cuda:{r % ndev}"))
+        bands.append(torch.from_numpy(make_band(fmt, "strong", size, g, j % ranks)).to(f"cuda:{(j % ranks) % ndev}"))
     out = torch.zeros(geos[0]["total_bytes"], dtype=torch.uint8, device="cuda:0")
     st = itw.MultiGpuStats()
     for _ in range(warmup):
-        itw.compress_image_multigpu(fmt, (size, size), prof, bands=bands, out=out, stats=st)
+        itw.compress_image_multigpu(fmt, (size, size), prof, ranks=ranks, bands=bands, out=out, stats=st)
     first = st.as_dict() if warmup else None               # the first call of the process: communicator set-up, first connections
     _all_device_sync()
     t0 = time.perf_counter()
     for _ in range(steps):
-        itw.compress_image_multigpu(fmt, (size, size), prof, bands=bands, out=out, stats=st)
+        itw.compress_image_multigpu(fmt, (size, size), prof, ranks=ranks, bands=bands, out=out, stats=st)
     _all_device_sync()
     elapsed = time.perf_counter() - t0
     last = st.as_dict()
     bad = 0
-    for r in range(ranks):
+    for r in range(K * ranks):
         ref = itw.compress(fmt, bands[r], prof)
         torch.cuda.synchronize(ref.device)
         g = geos[r]
@@ -432,7 +436,7 @@ def cpp_job(itw, fmt, prof, size, ranks, steps, warmup, scatter_steps=0):
         del ref
     res = {"host": "cpp: one process, itwCompressImageMultiGPUEx, one host thread per rank", "elapsed_s": elapsed, "steps": steps, "warmup": warmup,
            "ms_per_step": round(elapsed / steps * 1e3, 4), "value": round(size * size * steps / elapsed / 1e6, 2), "unit": "Mpixels/s",
-           "gather_verified": bad == 0, "mismatching_bytes": bad, "band_checks": ranks,
+           "gather_verified": bad == 0, "mismatching_bytes": bad, "band_checks": K * ranks, "sub_bands_per_rank": K,
            "how": "every band of the gathered stream on GPU 0 compared byte for byte with a fresh single-GPU encode of the same texels",
            "ranks": ranks, "devices": ndev, "transport": last["transport"], "transport_note": last["transport_note"],
            "ranks_seen_by_rccl": last["rccl_ranks"], "peer_links": last["peer_links"], "stats_last_call": last,
@@ -440,7 +444,7 @@ def cpp_job(itw, fmt, prof, size, ranks, steps, warmup, scatter_steps=0):
     if scatter_steps > 0:
         # the other way a C++ host holds its texels: the WHOLE surface resident on GPU 0, scattered to the ranks by peer copies
         # inside the call (the second half-band's copy under the first's encode)
-        whole = torch.cat([b.to("cuda:0") for b in bands], dim=0)
+        whole = torch.cat([b.to("cuda:0") for b in bands], dim=0)          # (sub-bands are in surface order)
         o2 = torch.zeros_like(out)
         itw.compress_image_multigpu(fmt, whole, prof, ranks=ranks, out=o2, stats=st)
         _all_device_sync()
@@ -511,6 +515,8 @@ def main():
     ap.add_argument("--size", type=int, default=None, help="surface edge; default 4096 (N = 1 / weak) or 16384 (strong, N > 1)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
                     help="default: strong when N > 1 (BASELINE configs[4]: one 16384^2 surface sharded over the ranks), else weak")
+    ap.add_argument("--interleave", type=int, default=None, help="K sub-bands per rank of the strong-sharded job (content-aware partition, "
+                    "include/itw_multigpu.h); default 4 where the surface's block rows divide by K * N, else 1")
     ap.add_argument("--no-formats", action="store_true", help="skip the side measurements of the other formats")
     ap.add_argument("--no-16k", action="store_true", help="skip the 16384^2 BC1/BC3 side figures (tools/profile_gpu.sh: keeps the "
                     "per-kernel-name averages of rocprofv3 --stats those of the 4096^2 launches)")
@@ -569,21 +575,34 @@ def main():
         """One timed job: every step = encode of this rank's band + all-gather of the output bands over xGMI (RCCL; in
         place).  The gather of step i runs on RCCL's stream while step i+1 encodes (two whole-image buffers,
         shard.BandPipeline); all gathers are waited for inside the timed region.  Returns (elapsed_s max over ranks, ...)."""
-        geo = plan(scaling, size, world, rank, fmt)
-        img = make_band(fmt, scaling, size, geo, rank)
-        assert img.shape[0] == geo["rows"] and img.shape[1] == geo["width"]
-        equal = geo["band_bytes"] * world == geo["total_bytes"]
-        assert equal, "bench bands must be equal (in-place all-gather): pick a size whose block rows divide by N"
-        assert geo["band_off"] == rank * geo["band_bytes"]
-        encode_into, d_img = make_encoder(itw_amd, fmt, prof, img, dev)
+        # the partition: K interleaved sub-bands per rank where the geometry allows (strong scaling only; K = 1: one contiguous band)
+        K = 1
+        if scaling == "strong" and world > 1:
+            K = args.interleave if args.interleave else 4
+            while K > 1 and ((size // 4) % (K * world) != 0 or (size // 4) // (K * world) < 16):
+                K //= 2
+        geos = [plan(scaling, size, world, rank, fmt, k, K) for k in range(K)]
+        geo = dict(geos[0])
+        imgs = [make_band(fmt, scaling, size, g, rank) for g in geos]
+        for g, im in zip(geos, imgs):
+            assert im.shape[0] == g["rows"] and im.shape[1] == g["width"]
+            assert g["band_bytes"] * world * K == g["total_bytes"], "bench bands must be equal (in-place all-gather): pick a size whose block rows divide by K * N"
+        for k, g in enumerate(geos):
+            assert g["band_off"] == (k * world + rank) * g["band_bytes"]
+        encs = [make_encoder(itw_amd, fmt, prof, im, dev) for im in imgs]
+        encode_list = [e[0] for e in encs]
+        img, d_img = imgs[0], encs[0][1]
+        geo["rows"] = sum(g["rows"] for g in geos)             # texel rows this rank encodes per step, all its pieces
+        geo["pieces"] = K
         if os.environ.get("ITW_BENCH_CORRUPT_RANK") == str(rank):
             # test hook (tests/test_sharding_gloo.py): this rank damages its band after encoding it -- the verification must see it
-            clean = encode_into
+            clean = encode_list[0]
 
-            def encode_into(out):
+            def corrupting(out, clean=clean):
                 clean(out)
                 out[:1] ^= 0xFF
-        pipe = shard.BandPipeline(geo["band_bytes"], world, rank, dev, encode_into)
+            encode_list[0] = corrupting
+        pipe = shard.InterleavedPipeline(geos[0]["band_bytes"], world, rank, dev, encode_list)
         for _ in range(warmup):
             pipe.step()
         pipe.drain()
@@ -607,15 +626,26 @@ def main():
 
     elapsed, geo, img, d_img, pipe = run_job(scaling, size, steps, warmup)
     d_band = pipe.band[0]
-    nblocks = (geo["width"] // 4) * (geo["rows"] // 4)          # blocks this rank encodes per step
+    nblocks = (geo["width"] // 4) * (geo["rows"] // 4)          # blocks this rank encodes per step (all its pieces)
 
     # N > 1: is the gathered image the image?  (after the timed region; never inside it)
     verdict = None
     if world > 1:
-        verdict = verify_gather(itw_amd, dist, pipe.full[(pipe.steps - 1) % pipe.depth], scaling, size, world, rank, fmt, prof, dev)
+        verdict = verify_gather(itw_amd, dist, pipe.full[(pipe.steps - 1) % pipe.depth], scaling, size, world, rank, fmt, prof, dev, geo.get("pieces", 1))
 
     # kernel-only duration on the launch stream (HIP events), for the roofline
     k_avg_ms, k_min_ms = time_kernel(itw_amd, fmt, prof, d_img, d_band, steps=max(3, min(steps, 20)), warmup=1)
+    if geo.get("pieces", 1) > 1 and not FAKE:
+        # K sub-bands per rank: the rank's kernel time per step is the sum over its pieces (equal sizes; piece 0 measured above, the
+        # others re-derived from the same seeded surface here)
+        for k in range(1, geo["pieces"]):
+            gk = plan(scaling, size, world, rank, fmt, k, geo["pieces"])
+            dk = torch.from_numpy(make_band(fmt, scaling, size, gk, rank)).to(dev)
+            a, m = time_kernel(itw_amd, fmt, prof, dk, d_band, steps=max(3, min(steps, 20)), warmup=1)
+            k_avg_ms += a; k_min_ms += m
+            del dk
+    elif geo.get("pieces", 1) > 1:
+        k_avg_ms *= geo["pieces"]; k_min_ms *= geo["pieces"]
     per_rank_ms = [round(k_avg_ms, 4)]
     if dist is not None:
         t = torch.zeros(world, dtype=torch.float64, device=dev)
@@ -640,8 +670,9 @@ def main():
                        + f" on ONE synthetic {geo['width']}x{geo['height']} " + ("RGBA16F" if fmt == "bc6h" else "RGBA8")
                        + f" surface, {scaling}-sharded over {world} GPU(s) by block-row bands ({geo['rows']} texel rows per rank), "
                          "texels resident in HBM, device-pointer C ABI call",
-                       "blocks_per_gpu": nblocks, "sharding": "block-row bands, one per rank (itwBandForPart); all_gather of output bands over "
-                       "RCCL, overlapped with the next step's encode" if world > 1 else "single GPU",
+                       "blocks_per_gpu": nblocks, "sharding": (f"{geo.get('pieces', 1)} interleaved block-row sub-band(s) per rank (sub-band j of K*N on rank j % N: "
+                       "itwBandForPart; content-aware partition); one in-place all_gather per group of N sub-bands over RCCL, overlapped with the next encode")
+                       if world > 1 else "single GPU",
                        "ranks_seen_by_rccl": (dist.get_world_size() if dist is not None else 1),
                        "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if (dist is not None and not FAKE) else None),
                        "bc7_mode_order": ("reference order (ITW_BC7_BOUND=0)" if os.environ.get("ITW_BC7_BOUND", "")[:1] == "0" else

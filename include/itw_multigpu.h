@@ -36,6 +36,17 @@ extern "C" {
  * device r % device_count, so more ranks than devices is legal (how the 8-way path is exercised on a 1-GPU box). */
 int itwMultiGpuRanks(void);
 
+/* PARTITION (round 5).  K = sub-bands per rank.  K = 1 is the reference's rule (win32Threads.cpp:217-231 restated on block rows): rank r owns
+ * the contiguous band itwBandForPart(r, ranks), cut in two halves for overlap.  K > 1: the surface is cut into K * ranks sub-bands
+ * (itwBandForPart(j, K * ranks)) and sub-band j belongs to rank j % ranks -- every rank gets K stripes spread over the surface.  Since the
+ * bounded BC7 mode order a band's encode time depends on its content (1.4x between noise and a photograph), so contiguous bands of a
+ * mixed image leave the ranks unequally loaded; interleaved ones do not.  The output layout does not change: a rank's gather is K
+ * contiguous runs.  itwMultiGpuSetInterleave sets the requested K for the process (1..8; default 4, env ITW_MULTIGPU_INTERLEAVE); a call
+ * uses it where every sub-band still has 16 block rows, else K = 1: itwMultiGpuPieces(height, ranks, keep_partial_blocks) returns the K a
+ * call with that geometry uses. */
+void itwMultiGpuSetInterleave(int k);
+int  itwMultiGpuPieces(int32_t height, int ranks, int keep_partial_blocks);
+
 /* "rccl" or "peer": what the last call on this process used for device-resident gathers (static storage). */
 const char* itwMultiGpuTransport(void);
 
@@ -48,13 +59,13 @@ int itwMultiGpuPeerLinks(void);
  * error mode "return" (itwSetErrorMode) when some rank failed; itwLastError() then holds the message. */
 bool itwCompressImageMultiGPU(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks);
 
-/* What one call did, per rank (device-side durations from HIP events on the rank's own streams, summed over its two
- * half-bands) and as a whole.  `transport` = "rccl" | "peer" | "host" (output in host memory: every GPU downloads its own
+/* What one call did, per rank (device-side durations from HIP events on the rank's own streams, summed over its pieces:
+ * two half-bands, or K sub-bands) and as a whole.  `transport` = "rccl" | "peer" | "host" (output in host memory: every GPU downloads its own
  * band); `transport_note` says why RCCL was not used when it was not.  `rccl_ranks` = size of the communicator clique
  * the gather ran on (0 unless transport is "rccl"). */
 typedef struct itw_multigpu_rank_stats {
     int32_t rank, device;
-    int32_t block_row0, block_rows;      /* the rank's band (itwBandForPart's rule) */
+    int32_t block_row0, block_rows;      /* first block row of the rank's first piece; block rows of all its pieces together */
     float   upload_ms;                   /* host->GPU or owner GPU->GPU copies of the band's texels (0 when encoded in place) */
     float   encode_ms;                   /* the CompressBlocks* launches */
     float   gather_ms;                   /* D2H / ncclSend / peer copy of the band's blocks; on the owner rank: its grouped ncclRecv */
@@ -65,6 +76,7 @@ typedef struct itw_multigpu_stats {
     int32_t ranks, devices, peer_links, rccl_ranks;
     int32_t watchdog_fired;              /* 1 = a rank did not finish posting its work in time and the call was aborted */
     int32_t resident_bands;              /* 1 = the texels were already on the ranks' devices (no scatter) */
+    int32_t interleave;                  /* K the call used (1 = one contiguous band per rank) */
     float   wall_ms;                     /* host wall clock of the whole call */
     float   posted_ms;                   /* host wall clock until every rank had posted all its work (launch + enqueue cost) */
     char    transport[8];
@@ -73,9 +85,10 @@ typedef struct itw_multigpu_stats {
 } itw_multigpu_stats;
 
 /* The same call with two optional extras.
- *   resident_bands  NULL, or an array of `ranks` surfaces: band r of the image (block rows itwBandForPart(r, ranks)),
- *                   already resident on the device rank r runs on (device r % device_count) -- the tile-sharded input of
- *                   a pipeline that produced the texels where they are encoded.  No scatter happens; `input` then only
+ *   resident_bands  NULL, or an array of K * ranks surfaces, K = itwMultiGpuPieces(height, ranks, ..): sub-band j of the image (block
+ *                   rows itwBandForPart(j, K * ranks)), already resident on the device rank j % ranks runs on (device
+ *                   (j % ranks) % device_count) -- the tile-sharded input of a pipeline that produced the texels where they are
+ *                   encoded (K = 1: `ranks` surfaces, band r on rank r's device).  No scatter happens; `input` then only
  *                   carries width / height (its ptr may be NULL).  ranks must be given explicitly (> 0).
  *   stats           NULL, or where to leave the call's account (filled on failure too, as far as the call got).
  * Watchdog: a rank that has not posted all its work (launches, copies, ncclSend / ncclGroupEnd) within

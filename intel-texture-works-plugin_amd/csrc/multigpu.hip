@@ -47,6 +47,7 @@
 namespace {
 
 constexpr int MAX_RANKS = 64;
+constexpr int MAX_PIECES = 8;          // pieces of a rank's share: the 2 halves of its band, or up to 8 interleaved sub-bands
 using Clock = std::chrono::steady_clock;
 double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 
@@ -82,6 +83,7 @@ struct Call {                      // one itwCompressImageMultiGPU call, shared 
     CompressionFunc* fn = nullptr;
     const rgba_surface* bands = nullptr;                   // resident bands (one per rank, on the rank's device) or nullptr
     int bpb = 16, texel_bytes = 4, ranks = 1;
+    int interleave = 1;                                    // K: sub-bands per rank (1: one contiguous band per rank, cut in two halves)
     bool keep_partial = false;
     bool src_dev = false, dst_dev = false;
     int src_device = -1, dst_device = -1, dst_rank = -1;   // dst_rank: the rank (on dst_device) that posts the receives
@@ -89,15 +91,15 @@ struct Call {                      // one itwCompressImageMultiGPU call, shared 
     int fail_rank = -1, fail_stage = 0, stall_ms = 0;      // itwMultiGpuTestInjectFailure
 };
 
-// device-side timestamps of one rank and one call: [half][begin, end] per activity
+// device-side timestamps of one rank and one call: [piece][begin, end] per activity
 enum { T_UP = 0, T_ENC = 1, T_GATHER = 2, T_RECV = 3, T_KINDS = 4 };
 
 struct RankCtx {
     int rank = 0, device = 0;
     std::thread th;
     hipStream_t enc = nullptr, xfer = nullptr;
-    hipEvent_t ev[T_KINDS][2][2] = {};                     // [kind][half][begin | end], timing enabled
-    bool rec[T_KINDS][2] = {};                             // pair recorded in the current call
+    hipEvent_t ev[T_KINDS][MAX_PIECES][2] = {};            // [kind][piece][begin | end], timing enabled
+    bool rec[T_KINDS][MAX_PIECES] = {};                    // pair recorded in the current call
     void* d_in = nullptr;  size_t in_cap = 0;
     void* d_out = nullptr; size_t out_cap = 0;
     bool peers_enabled = false;
@@ -130,6 +132,7 @@ struct Group {
     char note[96] = {0};
     std::atomic<int> peer_links{0};     // directed device pairs with peer access enabled (xGMI instead of a bounce through the host)
     std::atomic<int> inject_rank{-1}, inject_stage{0}, inject_stall{0};
+    std::atomic<int> interleave{-1};    // requested sub-bands per rank (itwMultiGpuSetInterleave); -1: ITW_MULTIGPU_INTERLEAVE or the default, 4
     Group() { for (auto& c : comms) c.store(nullptr); }
 };
 Group& g = *new Group;             // never destroyed: rank threads outlive static destruction
@@ -163,6 +166,44 @@ int device_of(const void* p)
 // block rows [r0, r1) of rank r (itwBandForPart's rule), then the half-band cut
 void band_rows(int by, int rank, int ranks, int& r0, int& r1) { r0 = (int)((int64_t)by * rank / ranks); r1 = (int)((int64_t)by * (rank + 1) / ranks); }
 void half_cut(int r0, int r1, int (&cut)[3]) { cut[0] = r0; cut[1] = (r1 - r0 >= 2) ? r0 + (r1 - r0 + 1) / 2 : r1; cut[2] = r1; }
+
+// The pieces rank `rank` encodes, in posting order: block rows [cut[s][0], cut[s][1]).
+//   K = 1  the reference's partition (win32Threads.cpp:217-231 on block rows): one contiguous band per rank, cut in two halves so that
+//          the upload of the second and the gather of the first run under an encode;
+//   K > 1  (round 5) the surface is cut into K * ranks sub-bands (itwBandForPart(j, K * ranks)) and sub-band j belongs to rank j % ranks:
+//          since the bounded BC7 order a band's encode time depends on its content (1.4x between noise and a photograph), and K
+//          interleaved sub-bands give every rank a sample of the whole surface.  The output is where it always was, so a rank's gather
+//          is K contiguous runs instead of one.
+int pieces_of(int by, int rank, int ranks, int K, int (&cut)[MAX_PIECES][2])
+{
+    if (K <= 1) {
+        int r0, r1, h[3];
+        band_rows(by, rank, ranks, r0, r1);
+        half_cut(r0, r1, h);
+        cut[0][0] = h[0]; cut[0][1] = h[1]; cut[1][0] = h[1]; cut[1][1] = h[2];
+        return 2;
+    }
+    for (int s = 0; s < K; s++) band_rows(by, s * ranks + rank, K * ranks, cut[s][0], cut[s][1]);
+    return K;
+}
+// K as a call uses it: the requested value where every sub-band still has at least 16 block rows, else 1
+int effective_interleave(int by, int ranks, int K)
+{
+    if (K > MAX_PIECES) K = MAX_PIECES;
+    return (K > 1 && (int64_t)by >= (int64_t)16 * K * ranks) ? K : 1;
+}
+
+int requested_interleave()
+{
+    int k = g.interleave.load();
+    if (k < 0) {
+        const char* e = std::getenv("ITW_MULTIGPU_INTERLEAVE");
+        k = e ? std::atoi(e) : 4;
+        k = k < 1 ? 1 : (k > MAX_PIECES ? MAX_PIECES : k);
+        g.interleave.store(k);
+    }
+    return k;
+}
 
 // Peer access from this rank's device to every other device, once per rank thread: without it hipMemcpyPeerAsync and
 // hipMemcpy2DAsync(hipMemcpyDefault) between two GPUs may stage through host memory instead of using xGMI.
@@ -220,10 +261,10 @@ void drain(RankCtx& c) noexcept
     (void)hipGetLastError();
 }
 
-void mark(RankCtx& c, int kind, int half, int end, hipStream_t st)
+void mark(RankCtx& c, int kind, int piece, int end, hipStream_t st)
 {
-    ITW_CHECK(hipEventRecord(c.ev[kind][half][end], st));
-    if (end) c.rec[kind][half] = true;
+    ITW_CHECK(hipEventRecord(c.ev[kind][piece][end], st));
+    if (end) c.rec[kind][piece] = true;
 }
 
 // rows [y0, y1) of the input surface -> pitched staging on this GPU.  A signed / overlapping stride (bottom-up surfaces: the
@@ -246,9 +287,9 @@ void account(RankCtx& c) noexcept
 {
     float sums[T_KINDS] = {0, 0, 0, 0}, last = 0.f;
     hipEvent_t first = nullptr;
-    for (int kind = 0; kind < T_KINDS && !first; kind++) for (int h = 0; h < 2 && !first; h++) if (c.rec[kind][h]) first = c.ev[kind][h][0];
+    for (int kind = 0; kind < T_KINDS && !first; kind++) for (int h = 0; h < MAX_PIECES && !first; h++) if (c.rec[kind][h]) first = c.ev[kind][h][0];
     for (int kind = 0; kind < T_KINDS; kind++)
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < MAX_PIECES; h++) {
             if (!c.rec[kind][h]) continue;
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, c.ev[kind][h][0], c.ev[kind][h][1]) == hipSuccess) sums[kind] += ms;
@@ -263,21 +304,24 @@ void run_rank(RankCtx& c, const Call& k)
 {
     const int w = k.input.width, h = k.input.height;
     const int bx = k.keep_partial ? (w + 3) / 4 : w / 4, by = k.keep_partial ? (h + 3) / 4 : h / 4;
-    int r0, r1;
-    band_rows(by, c.rank, k.ranks, r0, r1);
-    const bool idle = r1 <= r0;
+    int cut[MAX_PIECES][2];
+    const int np = pieces_of(by, c.rank, k.ranks, k.interleave, cut);
+    int total_rows = 0;
+    for (int s = 0; s < np; s++) total_rows += cut[s][1] > cut[s][0] ? cut[s][1] - cut[s][0] : 0;
+    const bool idle = total_rows <= 0;
     const size_t row_bytes = (size_t)w * k.texel_bytes;
     const size_t pitch = (row_bytes + 15) & ~(size_t)15;
     const bool src_here = k.bands || (k.src_dev && k.src_device == c.device);       // texels already on this GPU: encoded in place
     const bool dst_here = k.dst_dev && k.dst_device == c.device;
-    const size_t band_out = idle ? 0 : (size_t)(r1 - r0) * bx * k.bpb;
-    const int64_t first_row = (int64_t)r0 * 4;
-    const int64_t last_row = (r1 == by) ? h : (int64_t)r1 * 4;                    // the last band keeps a partial block row (BC4/BC5)
+    // texel rows [y0, y1) of piece s: the piece that holds the surface's last block row keeps a partial block row (BC4/BC5)
+    auto rows_of = [&](int s, int64_t& y0, int64_t& y1) { y0 = (int64_t)cut[s][0] * 4; y1 = (cut[s][1] == by) ? h : (int64_t)cut[s][1] * 4; };
+    int64_t texel_rows = 0;
+    for (int s = 0; s < np; s++) { int64_t y0, y1; rows_of(s, y0, y1); if (cut[s][1] > cut[s][0]) texel_rows += y1 - y0; }
     uint8_t* in = nullptr;
     uint8_t* out = nullptr;
     std::memset(c.rec, 0, sizeof c.rec);
     c.st = itw_multigpu_rank_stats{};
-    c.st.rank = c.rank; c.st.device = c.device; c.st.block_row0 = r0; c.st.block_rows = idle ? 0 : r1 - r0;
+    c.st.rank = c.rank; c.st.device = c.device; c.st.block_row0 = cut[0][0]; c.st.block_rows = total_rows;
 
     // ---- PREPARE: everything that can fail for lack of resources, before any transfer is posted ----
     itw::Failure early;
@@ -286,18 +330,25 @@ void run_rank(RankCtx& c, const Call& k)
         if (!c.enc) {
             ITW_CHECK(hipStreamCreateWithFlags(&c.enc, hipStreamNonBlocking));
             ITW_CHECK(hipStreamCreateWithFlags(&c.xfer, hipStreamNonBlocking));
-            for (auto& kind : c.ev) for (auto& half : kind) for (auto& e : half) ITW_CHECK(hipEventCreate(&e));
+            for (auto& kind : c.ev) for (auto& piece : kind) for (auto& e : piece) ITW_CHECK(hipEventCreate(&e));
         }
         enable_peers(c);
         if (!idle) {
             if (k.bands) {
-                const rgba_surface& b = k.bands[c.rank];
-                if (!b.ptr || b.width != w || (int64_t)b.height < last_row - first_row)
-                    itw::fail_msg("resident band %d: %dx%d texels at %p, expected %d x %lld", c.rank, b.width, b.height, (void*)b.ptr, w, (long long)(last_row - first_row));
-                if (device_of(b.ptr) != c.device) itw::fail_msg("resident band %d is not on device %d (the device rank %d runs on)", c.rank, c.device, c.rank);
+                // resident input: K = 1: surface `rank` holds the rank's band; K > 1: surface s * ranks + rank holds its s-th sub-band
+                for (int s = 0; s < (k.interleave > 1 ? np : 1); s++) {
+                    const int idx = k.interleave > 1 ? s * k.ranks + c.rank : c.rank;
+                    int64_t y0, y1;
+                    if (k.interleave > 1) { if (cut[s][1] <= cut[s][0]) continue; rows_of(s, y0, y1); }
+                    else { y0 = (int64_t)cut[0][0] * 4; y1 = (cut[np - 1][1] == by) ? h : (int64_t)cut[np - 1][1] * 4; }
+                    const rgba_surface& b = k.bands[idx];
+                    if (!b.ptr || b.width != w || (int64_t)b.height < y1 - y0)
+                        itw::fail_msg("resident band %d: %dx%d texels at %p, expected %d x %lld", idx, b.width, b.height, (void*)b.ptr, w, (long long)(y1 - y0));
+                    if (device_of(b.ptr) != c.device) itw::fail_msg("resident band %d is not on device %d (the device rank %d runs on)", idx, c.device, c.rank);
+                }
             }
-            in = src_here ? nullptr : (uint8_t*)grow(c.d_in, c.in_cap, pitch * (size_t)(last_row - first_row));
-            out = dst_here ? k.output + (size_t)r0 * bx * k.bpb : (uint8_t*)grow(c.d_out, c.out_cap, band_out);
+            in = src_here ? nullptr : (uint8_t*)grow(c.d_in, c.in_cap, pitch * (size_t)texel_rows);
+            out = dst_here ? nullptr : (uint8_t*)grow(c.d_out, c.out_cap, (size_t)total_rows * bx * k.bpb);
         }
         if (k.fail_rank == c.rank && k.fail_stage == 1) itw::fail_msg("injected failure in PREPARE (itwMultiGpuTestInjectFailure)");
     } catch (const itw::Failure& f) { early = f; early_failed = true; }
@@ -317,41 +368,44 @@ void run_rank(RankCtx& c, const Call& k)
     if (idle) { c.posted_ms.store(ms_since(g.t0)); c.stage.store(2); return; }
 
     // ---- TRANSFER + ENCODE ----
-    // Posting order: upload 0, encode 0 | upload 1 on the transfer stream (runs under encode 0), encode 1 | gather 0, gather 1 on
-    // the transfer stream (gather 0 runs under encode 1).  The gathers are posted last because a download into pageable host
-    // memory blocks the posting thread until the copy is done: posted earlier it would hold back the second encode's launch.
+    // Posting order: upload 0, encode 0 | upload s on the transfer stream (runs under encode s-1), encode s | ... | the gathers on the
+    // transfer stream (gather s runs under encode s+1).  The gathers are posted last because a download into pageable host memory
+    // blocks the posting thread until the copy is done: posted earlier it would hold back the next encode's launch.
     try {
         itwSetStream(c.enc);
-        int cut[3];
-        half_cut(r0, r1, cut);
-        uint8_t* o[2] = {nullptr, nullptr};
-        size_t nbytes[2] = {0, 0};
-        for (int s = 0; s < 2; s++) {
-            const int a = cut[s], b = cut[s + 1];
+        uint8_t* o[MAX_PIECES] = {nullptr};
+        size_t nbytes[MAX_PIECES] = {0};
+        size_t in_rows_done = 0, out_rows_done = 0;
+        for (int s = 0; s < np; s++) {
+            const int a = cut[s][0], b = cut[s][1];
             if (b <= a) continue;
             if (g.abort.load()) itw::fail_msg("stopped: another rank failed");
-            const int64_t y0 = (int64_t)a * 4, y1 = (b == by) ? h : (int64_t)b * 4;
+            int64_t y0, y1;
+            rows_of(s, y0, y1);
             rgba_surface sub = k.input;
             sub.height = (int)(y1 - y0);
             if (k.bands) {
-                const rgba_surface& band = k.bands[c.rank];
-                sub.ptr = band.ptr + (y0 - first_row) * (int64_t)band.stride;
+                const rgba_surface& band = k.bands[k.interleave > 1 ? s * k.ranks + c.rank : c.rank];
+                const int64_t band_first = k.interleave > 1 ? y0 : (int64_t)cut[0][0] * 4;
+                sub.ptr = band.ptr + (y0 - band_first) * (int64_t)band.stride;
                 sub.stride = band.stride;
             } else if (src_here) {
                 sub.ptr = k.input.ptr + y0 * (int64_t)k.input.stride;
             } else {
-                // host -> this GPU over its own PCIe link, or owner GPU -> this GPU over xGMI; the second half on the transfer stream
-                uint8_t* dpos = in + (size_t)(y0 - first_row) * pitch;
+                // host -> this GPU over its own PCIe link, or owner GPU -> this GPU over xGMI; later pieces on the transfer stream
+                uint8_t* dpos = in + in_rows_done * pitch;
                 const hipStream_t up = (s == 0) ? c.enc : c.xfer;
                 mark(c, T_UP, s, 0, up);
                 upload_rows(dpos, pitch, k, y0, y1, row_bytes, up);
                 mark(c, T_UP, s, 1, up);
-                if (s == 1) ITW_CHECK(hipStreamWaitEvent(c.enc, c.ev[T_UP][1][1], 0));
+                if (s > 0) ITW_CHECK(hipStreamWaitEvent(c.enc, c.ev[T_UP][s][1], 0));
                 sub.ptr = dpos;
                 sub.stride = (int32_t)pitch;
+                in_rows_done += (size_t)(y1 - y0);
             }
-            o[s] = out + (size_t)(a - r0) * bx * k.bpb;
+            o[s] = dst_here ? k.output + (size_t)a * bx * k.bpb : out + out_rows_done * bx * k.bpb;     // (resident output: encoded in place)
             nbytes[s] = (size_t)(b - a) * bx * k.bpb;
+            out_rows_done += (size_t)(b - a);
             itwClearError();
             mark(c, T_ENC, s, 0, c.enc);
             k.fn(&sub, o[s]);                                                         // device pointers: asynchronous on c.enc
@@ -359,24 +413,26 @@ void run_rank(RankCtx& c, const Call& k)
             mark(c, T_ENC, s, 1, c.enc);
         }
         if (!dst_here) {                                                              // (else: encoded in place)
-            for (int s = 0; s < 2; s++) {
+            bool first_posted = false;
+            for (int s = 0; s < np; s++) {
                 if (!nbytes[s]) continue;
                 if (g.abort.load()) itw::fail_msg("stopped: another rank failed");
                 ITW_CHECK(hipStreamWaitEvent(c.xfer, c.ev[T_ENC][s][1], 0));
-                uint8_t* dpos = k.output + (size_t)cut[s] * bx * k.bpb;
+                uint8_t* dpos = k.output + (size_t)cut[s][0] * bx * k.bpb;
                 mark(c, T_GATHER, s, 0, c.xfer);
                 if (!k.dst_dev)      ITW_CHECK(hipMemcpyAsync(dpos, o[s], nbytes[s], hipMemcpyDeviceToHost, c.xfer));
                 else if (k.use_rccl) with_comm(c.rank, [&](ncclComm_t comm) { ITW_NCCL(g.rccl.Send(o[s], nbytes[s], ncclUint8, k.dst_rank, comm, c.xfer)); });
                 else                 ITW_CHECK(hipMemcpyPeerAsync(dpos, k.dst_device, o[s], c.device, nbytes[s], c.xfer));
                 mark(c, T_GATHER, s, 1, c.xfer);
-                if (s == 0 && k.fail_rank == c.rank && k.fail_stage == 2) itw::fail_msg("injected failure after the first half-band (itwMultiGpuTestInjectFailure)");
+                if (!first_posted && k.fail_rank == c.rank && k.fail_stage == 2) itw::fail_msg("injected failure after the first piece (itwMultiGpuTestInjectFailure)");
+                first_posted = true;
             }
         } else if (k.fail_rank == c.rank && k.fail_stage == 2) {
-            itw::fail_msg("injected failure after the first half-band (itwMultiGpuTestInjectFailure)");
+            itw::fail_msg("injected failure after the first piece (itwMultiGpuTestInjectFailure)");
         }
-        // the rank that owns `output` posts the matching receives, one group per half so halves complete independently
+        // the rank that owns `output` posts the matching receives, one group per piece index so pieces complete independently
         if (k.use_rccl && k.dst_dev && c.rank == k.dst_rank) {
-            for (int s = 0; s < 2; s++) {
+            for (int s = 0; s < np; s++) {
                 mark(c, T_RECV, s, 0, c.xfer);
                 with_comm(c.rank, [&](ncclComm_t comm) {
                     // an abort that could not take this communicator's mutex within its two seconds frees the handle
@@ -388,12 +444,10 @@ void run_rank(RankCtx& c, const Call& k)
                     for (int p = 0; p < k.ranks; p++) {
                         still_ours();
                         if (p == c.rank) continue;
-                        int p0, p1, pc[3];
-                        band_rows(by, p, k.ranks, p0, p1);
-                        if (p1 <= p0) continue;
-                        half_cut(p0, p1, pc);
-                        if (pc[s + 1] <= pc[s]) continue;
-                        ITW_NCCL(g.rccl.Recv(k.output + (size_t)pc[s] * bx * k.bpb, (size_t)(pc[s + 1] - pc[s]) * bx * k.bpb, ncclUint8, p, comm, c.xfer));
+                        int pc[MAX_PIECES][2];
+                        const int pn = pieces_of(by, p, k.ranks, k.interleave, pc);
+                        if (s >= pn || pc[s][1] <= pc[s][0]) continue;
+                        ITW_NCCL(g.rccl.Recv(k.output + (size_t)pc[s][0] * bx * k.bpb, (size_t)(pc[s][1] - pc[s][0]) * bx * k.bpb, ncclUint8, p, comm, c.xfer));
                     }
                     still_ours();
                     ITW_NCCL(g.rccl.GroupEnd());
@@ -555,6 +609,7 @@ bool compress_multi(const rgba_surface* input, uint8_t* output, CompressionFunc*
         if (bands && n > by) itw::fail_msg("itwCompressImageMultiGPUEx: %d resident bands for %d block rows", n, by);
         n = n > by ? by : n;
         k.ranks = n;
+        k.interleave = effective_interleave(by, n, requested_interleave());
         ensure_ranks(n);
         k.src_device = bands ? -1 : device_of(input->ptr); k.src_dev = k.src_device >= 0;
         k.dst_device = device_of(output);     k.dst_dev = k.dst_device >= 0;
@@ -602,7 +657,7 @@ bool compress_multi(const rgba_surface* input, uint8_t* output, CompressionFunc*
         const double wall = ms_since(g.t0);
         if (stats) {
             stats->ranks = n; stats->devices = g.devices; stats->peer_links = g.peer_links.load();
-            stats->watchdog_fired = fired ? 1 : 0; stats->resident_bands = bands ? 1 : 0;
+            stats->watchdog_fired = fired ? 1 : 0; stats->resident_bands = bands ? 1 : 0; stats->interleave = k.interleave;
             stats->wall_ms = (float)wall;
             std::snprintf(stats->transport, sizeof stats->transport, "%s", g.transport);
             std::snprintf(stats->transport_note, sizeof stats->transport_note, "%s", g.note);
@@ -646,6 +701,16 @@ bool compress_multi(const rgba_surface* input, uint8_t* output, CompressionFunc*
 } // namespace
 
 extern "C" {
+
+
+void itwMultiGpuSetInterleave(int k) { g.interleave.store(k < 1 ? 1 : (k > MAX_PIECES ? MAX_PIECES : k)); }
+
+int itwMultiGpuPieces(int32_t height, int ranks, int keep_partial_blocks)
+{
+    const int by = keep_partial_blocks ? (height + 3) / 4 : height / 4;
+    if (ranks <= 0 || by <= 0) return 0;
+    return effective_interleave(by, ranks > by ? by : ranks, requested_interleave());
+}
 
 int itwMultiGpuRanks(void)
 {

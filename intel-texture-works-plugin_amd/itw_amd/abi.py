@@ -25,7 +25,8 @@ EXPORTED_SYMBOLS = tuple(
     + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
        "itwConvertToRGBA8Device", "itwConvertToRGBA16FDevice"]
     # include/itw_multigpu.h: one surface over all GPUs, one process
-    + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU", "itwCompressImageMultiGPUEx"]
+    + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU", "itwCompressImageMultiGPUEx",
+       "itwMultiGpuSetInterleave", "itwMultiGpuPieces"]
     # include/itw_bc45.h: the DirectXTex formats of the plugin
     + ["CompressBlocksBC4", "CompressBlocksBC5", "itwWarmupBC45"]
     # include/itw_decode.h: device decoders
@@ -78,13 +79,13 @@ class MultiGpuRankStats(C.Structure):
 class MultiGpuStats(C.Structure):
     """struct itw_multigpu_stats (itw_multigpu.h)."""
     _fields_ = [("ranks", C.c_int32), ("devices", C.c_int32), ("peer_links", C.c_int32), ("rccl_ranks", C.c_int32),
-                ("watchdog_fired", C.c_int32), ("resident_bands", C.c_int32), ("wall_ms", C.c_float), ("posted_ms", C.c_float),
+                ("watchdog_fired", C.c_int32), ("resident_bands", C.c_int32), ("interleave", C.c_int32), ("wall_ms", C.c_float), ("posted_ms", C.c_float),
                 ("transport", C.c_char * 8), ("transport_note", C.c_char * 96), ("rank", MultiGpuRankStats * 64)]
 
     def as_dict(self):
         n = max(0, min(int(self.ranks), 64))
         return {"ranks": int(self.ranks), "devices": int(self.devices), "peer_links": int(self.peer_links), "rccl_ranks": int(self.rccl_ranks),
-                "watchdog_fired": bool(self.watchdog_fired), "resident_bands": bool(self.resident_bands),
+                "watchdog_fired": bool(self.watchdog_fired), "resident_bands": bool(self.resident_bands), "interleave": int(self.interleave),
                 "wall_ms": round(float(self.wall_ms), 4), "posted_ms": round(float(self.posted_ms), 4),
                 "transport": self.transport.decode(), "transport_note": self.transport_note.decode(),
                 "per_rank": [{"rank": int(r.rank), "device": int(r.device), "block_row0": int(r.block_row0), "block_rows": int(r.block_rows),
@@ -181,6 +182,10 @@ def _load(path, hooks):
                                              C.c_int64, C.c_void_p, C.c_void_p]
         L.itwCompressImageSliced.restype = C.c_bool
         L.itwMultiGpuRanks.restype = C.c_int
+        L.itwMultiGpuSetInterleave.argtypes = [C.c_int]
+        L.itwMultiGpuSetInterleave.restype = None
+        L.itwMultiGpuPieces.argtypes = [C.c_int32, C.c_int, C.c_int]
+        L.itwMultiGpuPieces.restype = C.c_int
         L.itwMultiGpuTransport.restype = C.c_char_p
         L.itwMultiGpuPeerLinks.restype = C.c_int
         L.itwCompressImageMultiGPU.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -394,18 +399,35 @@ def compress_image(fmt, img, profile=None, multithreaded=True, slice_pixels=0, p
     return bool(ok), out
 
 
-def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None, bands=None, stats=None, L=None):
+def multigpu_sub_bands(fmt, width, height, ranks, L=None):
+    """The partition a multi-GPU call uses (itw_multigpu.h): [(j, rank, first_texel_row, texel_rows, output_byte_offset)] for the
+    K * ranks sub-bands, K = itwMultiGpuPieces(height, ranks); sub-band j belongs to rank j % ranks."""
+    k = (L or lib()).itwMultiGpuPieces(height, ranks, 1 if fmt in KEEPS_PARTIAL_BLOCKS else 0)
+    out = []
+    for j in range(k * ranks):
+        y0, rows, off = band_for_part(width, height, fmt, j, k * ranks)
+        out.append((j, j % ranks, y0, rows, off))
+    return out
+
+
+def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None, bands=None, stats=None, L=None, interleave=None):
     """itwCompressImageMultiGPU[Ex]: img is a host numpy array or a CUDA torch tensor (H, W, 4); the block stream comes back in
     the same kind of container (or in `out`, which may be the other kind).  Synchronous.
-    bands: optional list of CUDA tensors, band r of the image resident on device r % device_count (no scatter; `img` may then be
-    a (height, width) tuple).  stats: an optional MultiGpuStats to fill (stats.as_dict()).  L: the library instance (default: the product;
+    bands: optional list of CUDA tensors: K * ranks sub-bands (K = itwMultiGpuPieces; sub-band j = block rows itwBandForPart(j, K * ranks),
+    resident on the device of rank j % ranks: multigpu_sub_bands() cuts a surface that way), no scatter; `img` may then be a
+    (height, width) tuple.  interleave: sets K for the process first (1 = the reference's contiguous bands).  stats: an optional MultiGpuStats to fill (stats.as_dict()).  L: the library instance (default: the product;
     the failure-injection tests pass test_lib(), whose hook arms that instance)."""
     import numpy as np
     L = L or lib()
+    if interleave is not None:
+        L.itwMultiGpuSetInterleave(int(interleave))      # process-wide (itw_multigpu.h): K sub-bands per rank
     if bands is not None:
         import torch
         h, w = (img if isinstance(img, tuple) else img.shape[:2])
-        ranks = len(bands)
+        if not ranks:
+            ranks = len(bands)                           # (K = 1: one surface per rank)
+        pieces = L.itwMultiGpuPieces(h, ranks, 1 if fmt in KEEPS_PARTIAL_BLOCKS else 0)
+        assert len(bands) == pieces * ranks, f"{len(bands)} resident surfaces for {ranks} ranks x {pieces} sub-bands"
         for b in bands:
             assert b.is_cuda and b.dim() == 3 and b.shape[2] == 4 and b.stride(2) == 1 and b.stride(1) == 4 and b.shape[1] == w
             torch.cuda.synchronize(b.device)

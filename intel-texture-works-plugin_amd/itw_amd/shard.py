@@ -67,6 +67,54 @@ def encode_sharded(fmt, surface, settings=None, group=None, encode=None):
     return gather_bands(local, w, h, fmt, group)
 
 
+def sub_band_of(width, height, fmt, rank, world, k, pieces):
+    """Round 5, the content-aware partition (include/itw_multigpu.h): the surface is cut into pieces * world sub-bands and sub-band j belongs
+    to rank j % world -- `k`-th piece of `rank` = sub-band k * world + rank.  Same return value as band_of."""
+    return band_of(width, height, fmt, k * world + rank, pieces * world)
+
+
+class InterleavedPipeline:
+    """BandPipeline for K interleaved sub-bands per rank: the whole-image buffer is K groups of `world` equal sub-bands; every step this
+    rank encodes its K sub-bands in place (group k, slot rank) and each group is all-gathered on its own, in NCCL's in-place form, as soon
+    as its sub-band is encoded -- K collectives of 1/K the size, each overlapped with the next sub-band's encode (and, across steps, with
+    the next step's, as before).  K = 1 is BandPipeline.
+
+    encode_into[k](out_piece) launches / performs the encode of this rank's k-th sub-band into `out_piece` (a uint8 view)."""
+
+    def __init__(self, piece_bytes, world, rank, device, encode_into, group=None, depth=2):
+        import torch
+        self.world, self.rank, self.group, self.depth = world, rank, group, depth
+        self.encode_into = list(encode_into)
+        self.pieces = len(self.encode_into)
+        self.full = [torch.empty(self.pieces * world * piece_bytes, dtype=torch.uint8, device=device) for _ in range(depth)]
+        self.groups = [[f[k * world * piece_bytes:(k + 1) * world * piece_bytes] for k in range(self.pieces)] for f in self.full]
+        self.piece = [[g[rank * piece_bytes:(rank + 1) * piece_bytes] for g in gs] for gs in self.groups]
+        self.band = [ps[0] for ps in self.piece]          # (K = 1: the rank's band, as BandPipeline exposes it)
+        self.work = [[] for _ in range(depth)]
+        self.steps = 0
+
+    def step(self):
+        """Encode + start the gathers; returns the index of the buffer that will hold this step's whole image."""
+        b = self.steps % self.depth
+        self.steps += 1
+        for w in self.work[b]:                       # the gathers that last used this buffer must be done with it
+            w.wait()
+        self.work[b] = []
+        for k in range(self.pieces):
+            self.encode_into[k](self.piece[b][k])
+            if self.world > 1:
+                import torch.distributed as dist
+                self.work[b].append(dist.all_gather_into_tensor(self.groups[b][k], self.piece[b][k], group=self.group, async_op=True))
+        return b
+
+    def drain(self):
+        """Wait for every gather in flight (stream-level on GPUs: follow with a device synchronize to read on the host)."""
+        for b in range(self.depth):
+            for w in self.work[b]:
+                w.wait()
+            self.work[b] = []
+
+
 class BandPipeline:
     """Steady state of a sharded encoder: every step this rank encodes its band and the bands are all-gathered, with
     the gather of step i overlapped with the encode of step i+1.  Two (depth) whole-image buffers alternate; the

@@ -189,17 +189,14 @@ def test_resident_bands_need_no_scatter(itw, gpu, oracle, fmt, prof, h, w, ranks
     img = _img(fmt, h, w)
     want = oracle.encode_mt(fmt, img, prof).reshape(-1)
     n_dev = _device_count()
-    bands = []
-    for r in range(ranks):
-        y0, rows, _ = itw.band_for_part(w, h, fmt, r, ranks)
-        bands.append(torch.from_numpy(np.ascontiguousarray(img[y0:y0 + rows])).to(f"cuda:{r % n_dev}"))
+    bands = [torch.from_numpy(np.ascontiguousarray(img[y0:y0 + rows])).to(f"cuda:{r % n_dev}") for _, r, y0, rows, _ in itw.multigpu_sub_bands(fmt, w, h, ranks)]
     st = itw.MultiGpuStats()
-    out = itw.compress_image_multigpu(fmt, (h, w), prof, bands=bands, stats=st)
+    out = itw.compress_image_multigpu(fmt, (h, w), prof, ranks=ranks, bands=bands, stats=st)
     torch.cuda.synchronize()
     assert first_mismatch(out.cpu().numpy(), want, itw.BYTES_PER_BLOCK[fmt]) is None
     d = st.as_dict()
     assert d["resident_bands"] and d["ranks"] == ranks and all(r["upload_ms"] == 0 for r in d["per_rank"])
-    host_out = itw.compress_image_multigpu(fmt, (h, w), prof, bands=bands, out=np.empty(want.size, dtype=np.uint8))
+    host_out = itw.compress_image_multigpu(fmt, (h, w), prof, ranks=ranks, bands=bands, out=np.empty(want.size, dtype=np.uint8))
     assert first_mismatch(host_out, want, itw.BYTES_PER_BLOCK[fmt]) is None
 
 
@@ -210,7 +207,7 @@ def test_a_band_on_the_wrong_device_or_of_the_wrong_size_fails_in_prepare(itw, g
     itw.set_error_mode(itw.ON_ERROR_RETURN)
     try:
         with pytest.raises(RuntimeError, match="resident band 1"):
-            itw.compress_image_multigpu("bc1", (64, 64), bands=bands)
+            itw.compress_image_multigpu("bc1", (64, 64), ranks=2, bands=bands)
     finally:
         itw.set_error_mode(itw.ON_ERROR_ABORT)
 
@@ -252,13 +249,84 @@ def test_real_devices_resident_bands_rccl_stats(itw, gpu, oracle):
     n = _device_count()
     img = _img("bc7", 64 * n, 256)
     want = oracle.encode_mt("bc7", img, "basic").reshape(-1)
-    bands = []
-    for r in range(n):
-        y0, rows, _ = itw.band_for_part(256, 64 * n, "bc7", r, n)
-        bands.append(torch.from_numpy(np.ascontiguousarray(img[y0:y0 + rows])).to(f"cuda:{r}"))
+    bands = [torch.from_numpy(np.ascontiguousarray(img[y0:y0 + rows])).to(f"cuda:{r}") for _, r, y0, rows, _ in itw.multigpu_sub_bands("bc7", 256, 64 * n, n)]
     st = itw.MultiGpuStats()
-    out = itw.compress_image_multigpu("bc7", (64 * n, 256), "basic", bands=bands, stats=st)
+    out = itw.compress_image_multigpu("bc7", (64 * n, 256), "basic", ranks=n, bands=bands, stats=st)
     torch.cuda.synchronize()
     assert first_mismatch(out.cpu().numpy(), want, 16) is None
     d = st.as_dict()
     assert d["transport"] == "rccl" and d["rccl_ranks"] == n and d["peer_links"] >= n - 1, d
+
+
+# ---- round 5: the content-aware partition -- K interleaved sub-bands per rank (itwMultiGpuSetInterleave) ----------------------------------
+
+@pytest.fixture
+def interleave(itw):
+    yield itw.lib().itwMultiGpuSetInterleave
+    itw.lib().itwMultiGpuSetInterleave(4)            # the library default
+
+
+def test_partition_geometry_covers_the_surface_once(itw, interleave):
+    """K * ranks sub-bands in surface order, sub-band j on rank j % ranks; K falls back to 1 where a sub-band would have fewer than 16
+    block rows; the byte offsets are itwBandForPart's, i.e. the output layout does not depend on K"""
+    for k in (1, 2, 4, 8):
+        interleave(k)
+        for fmt, w, h, ranks in (("bc7", 64, 4096, 8), ("bc1", 128, 2048, 3), ("bc5", 70, 1021, 2), ("bc7", 64, 256, 8)):
+            subs = itw.multigpu_sub_bands(fmt, w, h, ranks)
+            by = (h + 3) // 4 if fmt in ("bc4", "bc5") else h // 4
+            eff = k if by >= 16 * k * ranks else 1
+            assert len(subs) == eff * ranks and [r for _, r, _, _, _ in subs] == [j % ranks for j in range(eff * ranks)]
+            y = 0
+            for j, r, y0, rows, off in subs:
+                assert y0 == y and rows > 0
+                y += rows
+            assert y == (h if fmt in ("bc4", "bc5") else h // 4 * 4)
+
+
+@pytest.mark.parametrize("k", [1, 2, 4, 8])
+@pytest.mark.parametrize("fmt,prof,h,w,ranks", [("bc7", "veryfast", 1024, 64, 2), ("bc1", None, 2048, 32, 3), ("bc5", None, 1021, 70, 2)])
+def test_interleaved_sub_bands_host_device_and_resident(itw, gpu, oracle, interleave, k, fmt, prof, h, w, ranks):
+    """the same bytes whatever K: host -> host, device -> device (scatter by peer copies, gather into the resident output), and resident
+    sub-bands (surface j on rank j % ranks' device); the stats name the K the call used"""
+    import torch
+    interleave(k)
+    img = _img(fmt, h, w)
+    want = oracle.encode_mt(fmt, img, prof).reshape(-1)
+    bpb = itw.BYTES_PER_BLOCK[fmt]
+    st = itw.MultiGpuStats()
+    got = itw.compress_image_multigpu(fmt, img, prof, ranks=ranks, stats=st)
+    assert first_mismatch(got, want, bpb) is None
+    d = st.as_dict()
+    by = (h + 3) // 4 if fmt in ("bc4", "bc5") else h // 4
+    eff = k if by >= 16 * k * ranks else 1
+    assert d["interleave"] == eff and sum(r["block_rows"] for r in d["per_rank"]) == by
+    dev = torch.from_numpy(img).to(gpu)
+    out = itw.compress_image_multigpu(fmt, dev, prof, ranks=ranks)
+    torch.cuda.synchronize()
+    assert first_mismatch(out.cpu().numpy(), want, bpb) is None
+    n_dev = _device_count()
+    bands = [torch.from_numpy(np.ascontiguousarray(img[y0:y0 + rows])).to(f"cuda:{r % n_dev}") for _, r, y0, rows, _ in itw.multigpu_sub_bands(fmt, w, h, ranks)]
+    assert len(bands) == eff * ranks
+    out = itw.compress_image_multigpu(fmt, (h, w), prof, ranks=ranks, bands=bands)
+    torch.cuda.synchronize()
+    assert first_mismatch(out.cpu().numpy(), want, bpb) is None
+    host_out = itw.compress_image_multigpu(fmt, (h, w), prof, ranks=ranks, bands=bands, out=np.empty(want.size, dtype=np.uint8))
+    assert first_mismatch(host_out, want, bpb) is None
+
+
+def test_a_failing_rank_with_interleaved_sub_bands(itw, gpu, oracle, interleave):
+    """the failure paths do not depend on the partition: a rank that dies after its first sub-band ends the call, the next one is correct"""
+    interleave(4)
+    img = _img("bc7", 1024, 64)
+    want = oracle.encode_mt("bc7", img, "veryfast").reshape(-1)
+    T = itw.test_lib()
+    T.itwMultiGpuSetInterleave(4)
+    T.itwSetErrorMode(itw.ON_ERROR_RETURN)
+    T.itwMultiGpuTestInjectFailure(1, 2, 0)
+    try:
+        with pytest.raises(RuntimeError, match="injected failure"):
+            itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, L=T)
+    finally:
+        T.itwSetErrorMode(itw.ON_ERROR_ABORT)
+    got = itw.compress_image_multigpu("bc7", img, "veryfast", ranks=4, L=T)
+    assert first_mismatch(got, want, 16) is None

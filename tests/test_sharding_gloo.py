@@ -210,16 +210,19 @@ def _run_bench_world2(extra_env, extra_args=()):
     return outs
 
 
-@pytest.mark.parametrize("corrupt", [None, "0", "1"])
-def test_bench_n_gt_1_verifies_the_gathered_image(corrupt):
+@pytest.mark.parametrize("corrupt,interleave", [(None, 1), (None, 4), ("0", 4), ("1", 4)])
+def test_bench_n_gt_1_verifies_the_gathered_image(corrupt, interleave):
     """the N > 1 bench job checks what it gathered.  World 2 over gloo with the stand-in encoder (block
     bytes = a function of the band's texels): an intact run reports gather_verified = true; a rank that damages one byte of
     its band after encoding it (ITW_BENCH_CORRUPT_RANK) makes every rank's comparison of that band fail -> false, with the
     damaged bytes counted (its own check + the other rank's check of it, per job)."""
     import json
-    outs = _run_bench_world2({} if corrupt is None else {"ITW_BENCH_CORRUPT_RANK": corrupt})
+    outs = _run_bench_world2({} if corrupt is None else {"ITW_BENCH_CORRUPT_RANK": corrupt}, ("--interleave", str(interleave)))
     j = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
-    assert j["band_checks"] == 4 and len(j["per_rank_kernel_ms"]) == 2          # world 2: own band + the other's, on both ranks
+    # world 2: own share + the other's, on both ranks; round 5: a share is `interleave` sub-bands (K * N sub-bands dealt round-robin:
+    # the content-aware partition), each gathered by its own in-place all_gather
+    assert j["band_checks"] == 4 * interleave and len(j["per_rank_kernel_ms"]) == 2
+    assert f"{interleave} interleaved" in j["config"]["sharding"]
     if corrupt is None:
         assert j["gather_verified"] is True and j["mismatching_bytes"] == 0
     else:
@@ -279,3 +282,58 @@ def test_bench_n_gt_1_cpp_host_job_control_flow(child):
         assert j["config"]["host"].startswith("python") and j["value"] == j["python_side"]["value"] and "note" in j["cpp_host"]
         assert ("error" in j["cpp_host"]) == (child == "crash")
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+
+
+def _interleaved_worker(rank, world, port, pieces, q):
+    """InterleavedPipeline over gloo: K sub-bands per rank, each group of `world` sub-bands gathered in place by its own all_gather; the
+    stand-in encoder writes (step, sub-band index) so that every byte of every step's image is known"""
+    import torch
+    import torch.distributed as dist
+    from itw_amd import shard
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        pb = 96
+        state = {"step": 0}
+
+        def enc(k):
+            def f(out):
+                out.fill_((state["step"] * 16 + k * world + rank) % 251)
+            return f
+        pipe = shard.InterleavedPipeline(pb, world, rank, torch.device("cpu"), [enc(k) for k in range(pieces)])
+        ok = True
+        for step in range(5):
+            state["step"] = step
+            b = pipe.step()
+            pipe.drain()
+            want = torch.cat([torch.full((pb,), (step * 16 + j) % 251, dtype=torch.uint8) for j in range(pieces * world)])
+            ok = ok and bool((pipe.full[b] == want).all())
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,pieces", [(2, 1), (2, 4), (3, 2)])
+def test_interleaved_pipeline_gathers_every_sub_band_to_its_place(world, pieces):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_interleaved_worker, args=(r, world, port, pieces, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(world)]
+
+
+def test_sub_band_geometry_is_the_band_rule_on_k_times_n_parts():
+    from itw_amd import shard
+    w, h, fmt, world, k = 64, 1024, "bc7", 4, 4
+    seen = []
+    for piece in range(k):
+        for r in range(world):
+            y0, rows, off, nbytes = shard.sub_band_of(w, h, fmt, r, world, piece, k)
+            assert (y0, rows, off, nbytes) == shard.band_of(w, h, fmt, piece * world + r, k * world)
+            seen.append((y0, rows))
+    assert sorted(seen) == [(64 * j, 64) for j in range(16)]
