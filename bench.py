@@ -922,6 +922,69 @@ def main():
                 pass
             except Exception as e:
                 side["multigpu_cpp@8virtual_16384"] = {"error": repr(e)}
+            # the partition on MIXED content.  A 16384^2 mosaic -- top half photographs (baboon.png and monkey.png
+            # tiled: nearly every block still visits modes 1/3), bottom half the synthetic surface (30 % do) -- cut (a) into 8 contiguous
+            # bands, the reference's rule, and (b) into 32 sub-bands dealt round-robin to 8 ranks (K = 4, the library's default).  Every
+            # (sub-)band is encoded ALONE on this GPU (HIP events): a rank's load is the sum over its pieces, independent of how the
+            # ranks would share a device.  Then the same image through itwCompressImageMultiGPUEx with both partitions: same bytes.
+            try:
+                if args.no_16k:
+                    raise StopIteration
+                big = 16384
+                gi = np.load(os.path.join(ROOT, "tests", "golden", "inputs.npz"))
+
+                def tile4096(a):
+                    a = a[:a.shape[0] // 4 * 4, :a.shape[1] // 4 * 4]
+                    return np.ascontiguousarray(np.tile(a, (-(-4096 // a.shape[0]), -(-4096 // a.shape[1]), 1))[:4096, :4096])
+                nat = [torch.from_numpy(tile4096(gi[k])).to(dev) for k in ("baboon", "monkey")]
+                syn = torch.from_numpy(make_surface("bc7", 4096, 0)).to(dev)
+                rows = [torch.cat([nat[(i + j) % 2] for j in range(4)], dim=1) for i in range(2)] + [torch.cat([syn] * 4, dim=1)] * 2
+                d2 = torch.cat(rows, dim=0).contiguous()
+                d2[..., 3] = 255
+                del nat, syn, rows
+                o_ref = torch.empty((big // 4) ** 2 * 16, dtype=torch.uint8, device=dev)
+                itw_amd.compress("bc7", d2, "slow", out=o_ref)
+                torch.cuda.synchronize()
+
+                def loads(parts, ranks):
+                    ms = []
+                    for j in range(parts):
+                        y0, nrows, off = itw_amd.band_for_part(big, big, "bc7", j, parts)
+                        a, _ = time_kernel(itw_amd, "bc7", "slow", d2[y0:y0 + nrows], o_ref[off:off + (nrows // 4) * (big // 4) * 16], steps=2, warmup=1)
+                        ms.append(a)
+                    per_rank = [sum(ms[j] for j in range(parts) if j % ranks == r) for r in range(ranks)]
+                    return ms, per_rank
+                ms8, load8 = loads(8, 8)
+                ms32, load32 = loads(32, 8)
+                o3 = torch.zeros_like(o_ref)
+                wall = {}
+                same = True
+                for K in (1, 4):
+                    itw_amd.compress_image_multigpu("bc7", d2, "slow", ranks=8, out=o3, interleave=K)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(2):
+                        itw_amd.compress_image_multigpu("bc7", d2, "slow", ranks=8, out=o3)
+                    torch.cuda.synchronize()
+                    wall[K] = (time.perf_counter() - t0) / 2 * 1e3
+                    same = same and bool(torch.equal(o3, o_ref))
+                    o3.zero_()
+                itw_amd.lib().itwMultiGpuSetInterleave(4)
+                side["multigpu_cpp@8virtual_16384_mixed"] = {
+                    "what": "bc7 slow on a 16384^2 mosaic (top half baboon.png / monkey.png tiled, bottom half the synthetic surface): per-rank load of 8 ranks under the "
+                            "reference's contiguous bands vs 4 interleaved sub-bands per rank (itwMultiGpuSetInterleave; the default), each (sub-)band encoded alone on this GPU",
+                    "contiguous_band_ms": [round(v, 3) for v in ms8], "contiguous_max_over_mean": round(max(load8) / (sum(load8) / 8), 4),
+                    "interleaved_rank_ms": [round(v, 3) for v in load32], "interleaved_max_over_mean": round(max(load32) / (sum(load32) / 8), 4),
+                    "sum_of_bands_ms": {"contiguous": round(sum(ms8), 3), "interleaved": round(sum(ms32), 3)},
+                    "multigpu_8virtual_wall_ms": {"contiguous": round(wall[1], 3), "interleaved": round(wall[4], 3)},
+                    "identical_bytes": same,
+                    "reading": "on N devices the slowest rank sets the time: the ideal N-way speed-up is divided by max/mean"}
+                del d2, o_ref, o3
+                torch.cuda.empty_cache()
+            except StopIteration:
+                pass
+            except Exception as e:
+                side["multigpu_cpp@8virtual_16384_mixed"] = {"error": repr(e)}
             # SURVEY 8(d) input I4 / BASELINE configs[3]: the reference's monkey-32bit.hdr (RGBE -> RGBA16F, committed as a
             # fixture: tests/golden/inputs.npz) tiled 19 x 19 and cropped to 4096^2
             try:
