@@ -431,7 +431,7 @@ def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None, bands=Non
         for b in bands:
             assert b.is_cuda and b.dim() == 3 and b.shape[2] == 4 and b.stride(2) == 1 and b.stride(1) == 4 and b.shape[1] == w
             torch.cuda.synchronize(b.device)
-        arr = (RgbaSurface * ranks)(*[RgbaSurface(b.data_ptr(), w, b.shape[0], b.stride(0) * b.element_size()) for b in bands])
+        arr = (RgbaSurface * len(bands))(*[RgbaSurface(b.data_ptr(), w, b.shape[0], b.stride(0) * b.element_size()) for b in bands])
         on_gpu, src_ptr, stride = True, None, w * 4 * bands[0].element_size()
         first_dev = bands[0].device
     else:
