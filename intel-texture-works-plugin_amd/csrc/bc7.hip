@@ -2083,9 +2083,10 @@ static FusedLayout fused_layout(size_t n)
     FusedLayout W;
     size_t o = up4(5 * n);                                         // 5 winner rows
     W.inc = o;      o = up4(o + n);                                // a phase's error / incumbent
-    W.list0 = o;    o = up4(o + n);                                // three block lists (RGBA profiles)
-    W.list1 = o;    o = up4(o + n);
-    W.list2 = o;    o = up4(o + n);
+    const size_t lcap = 2 * (nchunks / 2 + 65) * TPB;              // three block lists (RGBA profiles), each with room for two bands' shares
+    W.list0 = o;    o = up4(o + lcap);
+    W.list1 = o;    o = up4(o + lcap);
+    W.list2 = o;    o = up4(o + lcap);
     W.counts = o;   o += 16;                                       // list lengths, the pilot's verdict
     for (int k = 0; k < 2; k++) {                                  // the two bands: lists and share winners ...
         ListRegion& r = W.band[k];
@@ -2260,7 +2261,6 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             int32_t* list7 = reinterpret_cast<int32_t*>(wins4 + W.list2);                      // [n] block ids (RGBA profiles, bounded order incl. mode 7)
             int32_t* rgb_count = reinterpret_cast<int32_t*>(wins4 + W.counts);                 // the lists' lengths, the pilot's list length and verdict
             int32_t* count13 = rgb_count + 1;
-            int32_t* count7 = rgb_count + 2;
             int32_t* band_count = rgb_count + 3;                                               // [2]: the bands' lists for modes 1/3
             int32_t* pilot_flag = rgb_count + 6;                                               // the pilot's verdict
             int32_t* pilot_ctr = rgb_count + 8;                                                // [3]: its counts (listed, sampled, workgroups done)
@@ -2291,18 +2291,22 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                     else       hipLaunchKernelGGL((bc7_scan_all<false, false, false>), grid, blk, 0, s, src, stride, bx, rows, wins, S, T, a13, a7, cnt, grain, list, count, split, sel, compact);
                 }
             };
-            auto scan_7 = [&](const int32_t* list = nullptr, const int32_t* count = nullptr, int32_t split = 0) {
+            auto scan_7 = [&](const int32_t* list = nullptr, const int32_t* count = nullptr, int32_t split = 0, int32_t cnt = -1, hipStream_t s = nullptr,
+                              uint32_t* wins = nullptr, int32_t rows = 0) {
                 if (!on7) return;
                 ScanTasks T7;
                 T7.n = 1; T7.kind[0] = WK_SCAN7;
-                const int32_t chunks8 = ((nchunks + 7) / 8) * 8;
+                if (cnt < 0) cnt = nchunks;
+                if (!s) s = st;
+                if (!wins) { wins = wins4; rows = (int32_t)n; }
+                const int32_t chunks8 = ((cnt + 7) / 8) * 8;
                 const dim3 grid((unsigned)chunks8);
                 if (r7) {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split, ALL, (const uint4*)nullptr);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split, ALL, (const uint4*)nullptr);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, ALL, (const uint4*)nullptr);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, ALL, (const uint4*)nullptr);
                 } else {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split, ALL, (const uint4*)nullptr);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S, T7, a13, a7, nchunks, chunks8, list, count, split, ALL, (const uint4*)nullptr);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, ALL, (const uint4*)nullptr);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, ALL, (const uint4*)nullptr);
                 }
             };
             // a finish phase: list phases launch one workgroup per possible list chunk (they return at once behind the list's end)
@@ -2323,14 +2327,38 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             if (bc7_alpha_first(S)) {
                 ITW_CHECK(hipMemsetAsync(rgb_count, 0, 16 * sizeof(int32_t), st));  // the finish phases append to the lists through them
                 if (bounded && on7 && !r7 && (S.mode_selection[2] || S.mode_selection[3])) {
-                    // mode 7 bounded too: modes 4,5,6 | 0,2 first, then 1,3 and 7 each over its own list
-                    finish(std::integral_constant<int, 6>{}, nullptr, nullptr, rgb_list, rgb_count, list7, count7);
-                    scan_rgb(rgb_list, rgb_count, false, true);
-                    finish(std::integral_constant<int, 5>{}, rgb_list, rgb_count, list13, count13, list7, count7);
-                    scan_rgb(list13, count13, true, false, 1);
-                    finish(std::integral_constant<int, 4>{}, list13, count13, nullptr, nullptr);
-                    scan_7(list7, count7, 1);
-                    finish(std::integral_constant<int, 7>{}, list7, count7, nullptr, nullptr);
+                    // mode 7 bounded too: modes 4,5,6 | 0,2 first, then 1,3 and 7 each over its own list.  Round 5: seven dependent launches
+                    // leave the chip partly empty seven times, so -- as for the RGB profiles below -- the surface is cut into two interleaved
+                    // bands, each with its own lists and share winners, one per stream.
+                    const bool two = bc7_bands() > 1 && aux && !aux->single && aux->stream && nchunks >= 32;
+                    int32_t stripe = nchunks / 16;
+                    stripe = stripe < 1 ? 1 : (stripe > 64 ? 64 : stripe);
+                    const int32_t stripes = (nchunks + stripe - 1) / stripe;
+                    auto chain = [&](int k, hipStream_t s) {
+                        const ChunkSel sel{two ? 1 : 0, stripe, k, nullptr, 0};
+                        const int32_t cnt = two ? ((stripes + 1 - k) / 2) * stripe : nchunks;
+                        const size_t cap = W.band[0].cap;                       // a band's share of each list region
+                        int32_t* lrgb = rgb_list + (two ? k * cap : 0); int32_t* l13 = list13 + (two ? k * cap : 0); int32_t* l7 = list7 + (two ? k * cap : 0);
+                        int32_t* crgb = rgb_count + (k ? 11 : 0); int32_t* c13 = rgb_count + (k ? 12 : 1); int32_t* c7 = rgb_count + (k ? 13 : 2);
+                        uint32_t* wins = two ? wins4 + W.band[k].wins : wins4;
+                        const int32_t rows = two ? cnt * TPB : (int32_t)n;
+                        finish(std::integral_constant<int, 6>{}, nullptr, nullptr, lrgb, crgb, l7, c7, sel, cnt, s);
+                        scan_rgb(lrgb, crgb, false, true, 0, ALL, cnt, s);
+                        finish(std::integral_constant<int, 5>{}, lrgb, crgb, l13, c13, l7, c7, ALL, cnt, s);
+                        scan_rgb(l13, c13, true, false, 1, ALL, cnt, s, wins, rows);
+                        finish(std::integral_constant<int, 4>{}, l13, c13, nullptr, nullptr, nullptr, nullptr, ALL, cnt, s, wins, rows);
+                        scan_7(l7, c7, 1, cnt, s, wins, rows);
+                        finish(std::integral_constant<int, 7>{}, l7, c7, nullptr, nullptr, nullptr, nullptr, ALL, cnt, s, wins, rows);
+                    };
+                    if (!two) chain(0, st);
+                    else {
+                        ITW_CHECK(hipEventRecord(aux->fork, st));
+                        ITW_CHECK(hipStreamWaitEvent(aux->stream, aux->fork, 0));
+                        chain(1, aux->stream);
+                        chain(0, st);
+                        ITW_CHECK(hipEventRecord(aux->join, aux->stream));
+                        ITW_CHECK(hipStreamWaitEvent(st, aux->join, 0));
+                    }
                 } else {
                     scan_7();
                     finish(std::integral_constant<int, 1>{}, nullptr, nullptr, rgb_list, rgb_count);
