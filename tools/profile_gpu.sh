@@ -31,7 +31,7 @@ for wl in bc1 bc3 bc4 bc5 bc7_slow bc6h_slow; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${wl}_$ctr -o pmc -- python $ROOT/bench.py --workload $wl --no-formats --no-cpu --steps $steps --warmup 1 > /dev/null 2> $OUT/pmc_${wl}_$ctr.log
     f=$(find $OUT/pmc_${wl}_$ctr -name '*counter_collection*.csv' | head -1)
-    if [ -n "$f" ]; then head -1 $f > $OUT/pmc_${wl}_$ctr.csv; grep -E "$KERNELS" $f | head -100 >> $OUT/pmc_${wl}_$ctr.csv; fi
+    if [ -n "$f" ]; then head -1 $f > $OUT/pmc_${wl}_$ctr.csv; grep -E "$KERNELS" $f | head -2000 >> $OUT/pmc_${wl}_$ctr.csv; fi
     rm -rf $OUT/pmc_${wl}_$ctr
   done
 done
@@ -39,7 +39,7 @@ done
 for wl in bc7_slow bc7_alpha_slow bc6h_slow bc1 bc3 bc4 bc5; do
   rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- python $ROOT/bench.py --workload $wl --no-formats --no-cpu --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_sq_$wl.log
   f=$(find $OUT/pmc_sq -name '*counter_collection*.csv' | head -1)
-  if [ -n "$f" ]; then head -1 $f > $OUT/pmc_sq_$wl.csv; grep -E "$KERNELS" $f | head -600 >> $OUT/pmc_sq_$wl.csv; fi
+  if [ -n "$f" ]; then head -1 $f > $OUT/pmc_sq_$wl.csv; grep -E "$KERNELS" $f | head -6000 >> $OUT/pmc_sq_$wl.csv; fi
   rm -rf $OUT/pmc_sq
 done
 cp $OUT/pmc_sq_bc7_slow.csv $OUT/pmc_sq_bc7.csv 2>/dev/null
