@@ -248,20 +248,23 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
     case Fmt::BC7:
         ensure_bc7_aux();
         tls.aux.wide_max_blocks = staged ? staged_wide_max_blocks() : 0;
-        tls.aux.single = band >= 0 || band == -2;
-        if (tls.aux.single) {
-            // band 0 leaves the pilot's estimate for the host; band -2 is a PROBE: the estimate alone (the run itself takes the wide shape)
-            tls.aux.verdict = (band == 0 || band == -2) ? &tls.verdict : nullptr;
-            tls.aux.probe = band == -2;
-            if (tls.aux.verdict) tls.verdict.valid = false;
-            itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(static_cast<uint8_t*>(tls.d_ws) + ws_off), st, &tls.aux);
-            tls.aux.verdict = nullptr; tls.aux.probe = false;
-        } else {
-            float* ws = bc7_workspace(w, h, st, tls.aux.wide_max_blocks);         // (sized and ordered already when ws_off != 0)
-            itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(ws) + ws_off), st, &tls.aux);
-            ITW_CHECK(hipEventRecord(tls.ws_event, st));
+        {
+            // the per-call fields of the shared aux block go back to their defaults however this call ends (a failure is a C++ exception here,
+            // and under ITW_ON_ERROR_RETURN the thread lives on)
+            struct Reset { itw::Bc7Aux& a; ~Reset() { a.single = false; a.verdict = nullptr; a.probe = false; } } reset{tls.aux};
+            tls.aux.single = band >= 0 || band == -2;
+            if (tls.aux.single) {
+                // band 0 leaves the pilot's estimate for the host; band -2 is a PROBE: the estimate alone (the run itself takes the wide shape)
+                tls.aux.verdict = (band == 0 || band == -2) ? &tls.verdict : nullptr;
+                tls.aux.probe = band == -2;
+                if (tls.aux.verdict) tls.verdict.valid = false;
+                itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(static_cast<uint8_t*>(tls.d_ws) + ws_off), st, &tls.aux);
+            } else {
+                float* ws = bc7_workspace(w, h, st, tls.aux.wide_max_blocks);         // (sized and ordered already when ws_off != 0)
+                itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(ws) + ws_off), st, &tls.aux);
+                ITW_CHECK(hipEventRecord(tls.ws_event, st));
+            }
         }
-        tls.aux.single = false;
         break;
     case Fmt::BC6H: {
         // the wide shape's workspace shares the per-thread BC7 workspace buffer (same ordering rules)

@@ -1989,7 +1989,7 @@ static bool bc7_bounded_order()
     static const bool on = [] { const char* e = std::getenv("ITW_BC7_BOUND"); return !(e && e[0] == '0'); }();
     return on;
 }
-// Round 5.  ITW_BC7_PILOT_THR: the pilot's threshold in percent of the sample's blocks that still need modes 1/3 -- at or below it the rest of
+// Round 5.  ITW_BC7_PILOT_THR: the pilot's threshold in percent of the blocks it looks at that its estimate lists for modes 1/3 -- at or below it the rest of
 // the surface takes the bounded order, above it the reference's; -1 = no pilot (always bounded), 0 = pilot, always the reference's order for the
 // rest, 100 = pilot, always bounded (tools/round5/gpu_pilot.sh measures both ends).  Returned in 1/256.
 #ifndef ITW_BC7_PILOT_THR_DEFAULT
@@ -2267,7 +2267,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             const bool compact_on = bc7_compact_lists();
             const dim3 blk(TPB);
             const ChunkSel ALL{0, 1, 0, nullptr, 0};
-            // `sel`: which chunks (ChunkSel); `cnt`: how many chunks that is; `rows`: length of a winner row (n; the pilot sample's list scan has its own rows)
+            // `sel`: which chunks (ChunkSel); `cnt`: how many chunks that is; `rows`: length of a winner row (n; a band's list scan has its own rows)
             auto scan_rgb = [&](const int32_t* list, const int32_t* count, bool do13, bool do02, int32_t split = 0, ChunkSel sel = ChunkSel{0, 1, 0, nullptr, 0},
                                 int32_t cnt = -1, hipStream_t s = nullptr, uint32_t* wins = nullptr, int32_t rows = 0, const uint4* compact = nullptr) {
                 ScanTasks T;

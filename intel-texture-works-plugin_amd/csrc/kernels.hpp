@@ -25,7 +25,7 @@ size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks = 0); 
 void set_bc7_path(int path);
 bool bc7_has_order_verdict(const bc7_enc_settings& s);   // the settings run the bounded order of the RGB profiles (the one with a pilot's estimate)
 bool bc7_staged_bands_ok();      // the staged runs of a host-pointer call may run as overlapped deep bands (not when the wide shape is forced / ITW_STAGED_BANDS=0)
-// The pilot of the bounded BC7 mode order (bc7.hip, launch_bc7): percent of the sample's blocks that may still need modes 1/3 for the rest of
+// The pilot of the bounded BC7 mode order (bc7.hip, launch_bc7): percent of the blocks the pilot looks at that its estimate may list for modes 1/3 for the rest of
 // the surface to take the bounded order; -1 = no pilot, the whole call in the bounded order.  Same blocks whatever the value.
 void set_bc7_pilot(int percent);
 // `aux` (optional): a second stream of the same device plus two events the launcher may use to run independent parts of a
