@@ -23,7 +23,10 @@
 //     refinement + modes 4/5/6 in one launch), calls too small to fill the chip run WIDE (each scan split over several
 //     waves, winners joined by an ordered argmin, single-subset modes on a second stream).  Families run in the
 //     reference's order and only communicate through "best error so far" (kernel.ispc:1358, 1638, 1684) and the search
-//     winners; the per-family search / finish kernel pairs of round 1 remain for ranked lists longer than 16 shapes;
+//     winners; the per-family search / finish kernel pairs of round 1 remain for ranked lists longer than 16 shapes.
+//     The slow profiles (every shape scanned) run the BOUNDED order instead (round 4: modes 1/3/7 last, only for the blocks an
+//     exact lower bound cannot exclude, compacted into lists) as two interleaved bands on two streams, and for the RGB
+//     profile a pilot kernel picks that order or the reference's per call, on the device (round 5; launch_bc7);
 //   * the scans produce a candidate's ERROR and nothing else: the level a texel takes
 //     and the packed indices matter for a mode's winner alone, so the winner record is
 //     {error, shape} and the finish kernel recomputes endpoints and indices of the
@@ -1991,7 +1994,7 @@ static bool bc7_bounded_order()
 }
 // Round 5.  ITW_BC7_PILOT_THR: the pilot's threshold in percent of the blocks it looks at that its estimate lists for modes 1/3 -- at or below it the rest of
 // the surface takes the bounded order, above it the reference's; -1 = no pilot (always bounded), 0 = pilot, always the reference's order for the
-// rest, 100 = pilot, always bounded (tools/round5/gpu_pilot.sh measures both ends).  Returned in 1/256.
+// rest, 100 = pilot, always bounded (tools/round5/order_timing.py under each setting: profiles/r05e_*).  Returned in 1/256.
 #ifndef ITW_BC7_PILOT_THR_DEFAULT
 #define ITW_BC7_PILOT_THR_DEFAULT 75
 #endif
