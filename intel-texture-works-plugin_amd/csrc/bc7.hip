@@ -2010,7 +2010,7 @@ static int bc7_pilot_threshold()
     }
     return pct < 0 ? -1 : pct * 256 / 100;
 }
-void set_bc7_pilot(int percent) { g_bc7_pilot.store(percent < 0 ? -1 : (percent > 100 ? 100 : percent), std::memory_order_relaxed); }
+void set_bc7_pilot(int percent) { g_bc7_pilot.store(percent < -1 ? -2 : (percent > 100 ? 100 : percent), std::memory_order_relaxed); }   // < -1: back to ITW_BC7_PILOT_THR / the default
 static bool bc7_pilot_debug()
 {
     static const bool on = [] { const char* e = std::getenv("ITW_BC7_PILOT_DEBUG"); return e && e[0] == '1'; }();

@@ -343,3 +343,46 @@ def test_one_line_bound_on_random_blocks_and_against_exact_arithmetic():
                 pal = ((64 - w4)[:, None] * e0[None, :] + w4[:, None] * e1[None, :] + 32) // 64
                 err = ((tex[b][:, None, :] - pal[None, :, :]) ** 2).sum(axis=2).min(axis=1).sum()
                 assert lb <= err, (b, lb, err)
+
+
+def test_bands_cover_every_chunk_once_and_their_list_scans_fit_their_rows():
+    """Round 5 (csrc/bc7.hip: ChunkSel kind 1, launch_bc7): a `slow` / `alpha_slow` surface is cut into stripes of `stripe` chunks, even
+    stripes = band 0, odd stripes = band 1; workgroup i of a band's launch takes that band's i-th chunk, the grid is whole stripes and
+    workgroups behind the surface return.  Restated here: for every chunk count the two bands cover every chunk exactly once; a band's
+    share of the workspace (lists, share winners: nchunks / 2 + 65 chunks) holds it; a band's list scan, whose winner rows are the band's
+    chunk count long, is covered by the band's grid (list_scan_parts x listed blocks <= rows); the pilot's estimate (every eighth
+    workgroup of band 0, + 3) looks at chunks of band 0 only and at 1/16 of the surface within one stripe's worth."""
+    TPB, MAXP = 256, 8
+
+    def sel(stripe, band, i):
+        q = i // stripe
+        return (2 * q + band) * stripe + (i - q * stripe)
+
+    for nchunks in (32, 33, 47, 63, 64, 65, 77, 128, 1000, 1023, 1024, 1025, 4096, 65536):
+        stripe = max(1, min(64, nchunks // 16))
+        stripes = (nchunks + stripe - 1) // stripe
+        seen = {}
+        cnts = []
+        for band in (0, 1):
+            cnt = ((stripes + 1 - band) // 2) * stripe
+            cnts.append(cnt)
+            assert cnt <= nchunks // 2 + 65                      # fused_layout(): a band's region
+            for i in range(cnt):
+                c = sel(stripe, band, i)
+                if c >= nchunks:
+                    continue                                     # behind the surface: the workgroup returns
+                assert c not in seen
+                seen[c] = band
+            # the band's list scan: rows = cnt * TPB; any list length up to every block of the band
+            rows = cnt * TPB
+            for count in (1, TPB, rows // 3, rows):
+                chunks8 = ((count + TPB - 1) // TPB + 7) & ~7
+                parts = max(1, min(MAXP, rows // (chunks8 * TPB)))
+                grid = (cnt + 7) // 8 * 8                        # scan_rgb: groups x grain >= ceil8(cnt)
+                assert parts * count <= rows or parts == 1
+                assert ((count + TPB - 1) // TPB) * parts <= grid or parts == 1, (nchunks, band, count, parts, grid)
+        assert sorted(seen) == list(range(nchunks)), nchunks
+        sampled = [sel(stripe, 0, 8 * j + 3) for j in range((cnts[0] + 7) // 8)]
+        sampled = [c for c in sampled if c < nchunks]
+        assert all(seen[c] == 0 for c in sampled) and len(set(sampled)) == len(sampled)
+        assert abs(len(sampled) - nchunks / 16) <= max(2, stripe / 8 + 1), (nchunks, len(sampled))
