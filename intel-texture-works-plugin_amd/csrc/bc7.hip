@@ -2295,7 +2295,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                 }
             };
             auto scan_7 = [&](const int32_t* list = nullptr, const int32_t* count = nullptr, int32_t split = 0, int32_t cnt = -1, hipStream_t s = nullptr,
-                              uint32_t* wins = nullptr, int32_t rows = 0, ChunkSel sel = ChunkSel{0, 1, 0, nullptr, 0}) {
+                              uint32_t* wins = nullptr, int32_t rows = 0) {
                 if (!on7) return;
                 ScanTasks T7;
                 T7.n = 1; T7.kind[0] = WK_SCAN7;
@@ -2305,11 +2305,11 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                 const int32_t chunks8 = ((cnt + 7) / 8) * 8;
                 const dim3 grid((unsigned)chunks8);
                 if (r7) {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, sel, (const uint4*)nullptr);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, sel, (const uint4*)nullptr);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, true, true>),  grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, ALL, (const uint4*)nullptr);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, true, true>), grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, ALL, (const uint4*)nullptr);
                 } else {
-                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, sel, (const uint4*)nullptr);
-                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, sel, (const uint4*)nullptr);
+                    if (L.vec) hipLaunchKernelGGL((bc7_scan_all<true, false, true>),  grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, ALL, (const uint4*)nullptr);
+                    else       hipLaunchKernelGGL((bc7_scan_all<false, false, true>), grid, blk, 0, s, src, stride, bx, rows, wins, S, T7, a13, a7, cnt, chunks8, list, count, split, ALL, (const uint4*)nullptr);
                 }
             };
             // a finish phase: list phases launch one workgroup per possible list chunk (they return at once behind the list's end)
@@ -2454,29 +2454,9 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                     }
                 }
             } else {
-                // every other profile (ranked lists: `basic`, `fast`, ...; ITW_BC7_BOUND=0): the reference's order in two or three launches.
-                // Round 5: in two interleaved bands on two streams as well -- fewer boundaries than the bounded chain, but the calls are
-                // shorter (1-3 ms), so a launch's ramp and tail weigh as much (ITW_BC7_BANDS=1: one band)
-                const bool two = bc7_bands() > 1 && aux && !aux->single && aux->stream && nchunks >= 64;
-                int32_t stripe = nchunks / 16;
-                stripe = stripe < 1 ? 1 : (stripe > 64 ? 64 : stripe);
-                const int32_t stripes = (nchunks + stripe - 1) / stripe;
-                auto chain = [&](int k, hipStream_t s) {
-                    const ChunkSel sel{two ? 1 : 0, stripe, k, nullptr, 0};
-                    const int32_t cnt = two ? ((stripes + 1 - k) / 2) * stripe : nchunks;
-                    scan_rgb(nullptr, nullptr, true, true, 0, sel, cnt, s);
-                    scan_7(nullptr, nullptr, 0, cnt, s, nullptr, 0, sel);
-                    finish(std::integral_constant<int, 0>{}, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sel, cnt, s);
-                };
-                if (!two) chain(0, st);
-                else {
-                    ITW_CHECK(hipEventRecord(aux->fork, st));
-                    ITW_CHECK(hipStreamWaitEvent(aux->stream, aux->fork, 0));
-                    chain(1, aux->stream);
-                    chain(0, st);
-                    ITW_CHECK(hipEventRecord(aux->join, aux->stream));
-                    ITW_CHECK(hipStreamWaitEvent(st, aux->join, 0));
-                }
+                scan_rgb(nullptr, nullptr, true, true);
+                scan_7();
+                finish(std::integral_constant<int, 0>{}, nullptr, nullptr, nullptr, nullptr);
             }
             return;
         }
