@@ -63,8 +63,8 @@ void itwSetBc7Path(int path);
  * for the blocks an exact lower bound cannot exclude ("bounded order"), which pays on content where few blocks need them and costs 4-6 %
  * where nearly all do.  A pilot -- 1/16 of the surface, spread over it, encoded first on a second stream -- decides per call, on the
  * device: `percent` = the share of the pilot's blocks that may still need modes 1/3 for the rest of the surface to take the bounded
- * order (default 75; env ITW_BC7_PILOT_THR presets it); 0 = the rest always takes the reference's order, 100 = always the bounded
- * order, -1 = no pilot (the whole call in the bounded order), any value below -1 = back to the preset (the environment's, else 75).  The
+ * order (default 90; env ITW_BC7_PILOT_THR presets it); 0 = the rest always takes the reference's order, 100 = always the bounded
+ * order, -1 = no pilot (the whole call in the bounded order), any value below -1 = back to the preset (the environment's, else 90).  The
  * emitted bytes are the same whatever the value. */
 void itwSetBc7Pilot(int percent);
 

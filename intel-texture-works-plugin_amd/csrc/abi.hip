@@ -222,7 +222,7 @@ int64_t staged_wide_max_blocks()
 // ITW_STAGED_VERDICT_THR: percent of the first staged run's sampled blocks the pilot's estimate may list for the remaining runs to stay deep bands
 int staged_verdict_percent()
 {
-    static const int v = [] { const char* e = std::getenv("ITW_STAGED_VERDICT_THR"); return e ? std::atoi(e) : 75; }();
+    static const int v = [] { const char* e = std::getenv("ITW_STAGED_VERDICT_THR"); return e ? std::atoi(e) : 80; }();
     return v;
 }
 

@@ -1996,7 +1996,7 @@ static bool bc7_bounded_order()
 // the surface takes the bounded order, above it the reference's; -1 = no pilot (always bounded), 0 = pilot, always the reference's order for the
 // rest, 100 = pilot, always bounded (tools/round5/order_timing.py under each setting: profiles/r05e_*).  Returned in 1/256.
 #ifndef ITW_BC7_PILOT_THR_DEFAULT
-#define ITW_BC7_PILOT_THR_DEFAULT 75
+#define ITW_BC7_PILOT_THR_DEFAULT 90     // forced either way by content (profiles/r05l_*): 74 % estimated -> bounded wins by 11 %, 91 % -> equal, 98 % -> reference order by 0.6 %
 #endif
 static std::atomic<int> g_bc7_pilot{-2};           // percent; -2 = not read yet
 static int bc7_pilot_threshold()

@@ -244,7 +244,7 @@ BC7_PATH = {"auto": 0, "deep": 1, "wide": 2}
 
 def set_bc7_pilot(percent):
     """itwSetBc7Pilot: threshold of the bounded mode order's pilot in percent (0 = reference order for the rest of the surface, 100 = bounded,
-    -1 = no pilot, None = back to the library's preset: ITW_BC7_PILOT_THR or 75); same bytes whatever the value."""
+    -1 = no pilot, None = back to the library's preset: ITW_BC7_PILOT_THR or 90); same bytes whatever the value."""
     lib().itwSetBc7Pilot(-2 if percent is None else int(percent))
 
 
