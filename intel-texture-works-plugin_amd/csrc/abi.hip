@@ -208,10 +208,11 @@ void reserve_workspace(size_t bytes, hipStream_t st)
     tls.ws_stream = st; tls.ws_used = true;
 }
 
-// `staged`: a run of a host-pointer call.  Its upload / download overlap the neighbouring runs' kernels, and the wide BC7
-// shape (scans and single-subset modes side by side on two streams) fills the gaps between runs better than five dependent
-// launches: measured 8.75 -> 7.89 ms for a 4096^2 `slow` call.  Device-resident calls keep the deep shape above 262144
-// blocks (same time, a fifth of the HBM traffic and workspace).
+// `staged`: a run of a host-pointer call.  Its upload / download overlap the neighbouring runs' kernels.  A BC7 run that is not a band
+// (compress() below: round 4's shape, and what content that needs modes 1/3 everywhere still gets) takes the wide shape up to 2^20
+// blocks -- scans and single-subset modes side by side on two streams fill the gaps between runs better than a chain of dependent
+// launches on one stream (8.75 -> 7.89 ms for a 4096^2 `slow` call in round 2).  Device-resident calls keep the deep shape above
+// 262144 blocks (a fifth of the HBM traffic and workspace).
 // ITW_STAGED_WIDE_MAX: up to how many blocks a staged run of a host-pointer BC7 call takes the wide launch shape (tuning knob)
 int64_t staged_wide_max_blocks()
 {

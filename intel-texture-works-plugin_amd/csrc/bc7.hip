@@ -1146,7 +1146,6 @@ __device__ __forceinline__ void load_block(Tex& tx, const uint8_t* __restrict__ 
 
 // Round 5: the blocks a finish phase lists for a later scan also leave their 64 B of texels in a compact buffer, in list order, so the
 // list scans (up to 8 shares per block) and their refinement read contiguous lines instead of gathering 64 B out of every 128 B line
-template <bool = true>
 __device__ __forceinline__ void load_block_compact(Tex& tx, const uint4* __restrict__ compact, int32_t slot)
 {
     const uint4* p = compact + (int64_t)slot * 4;
