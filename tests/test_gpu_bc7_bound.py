@@ -169,3 +169,36 @@ def test_mode_6_skipped_by_its_bound_changes_nothing(itw, gpu, oracle, deep):
         want = oracle.encode("bc7", img, o)
         got = _encode(itw, gpu, img, s)
         assert first_mismatch(got, want, 16) is None, (prof, first_mismatch(got, want, 16))
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_pilot_and_bands_under_random_settings_in_the_bounded_territory(itw, gpu, oracle, deep, golden_inputs, seed):
+    """random settings structs that keep the bounded order's conditions (both multi-subset groups on, every two-subset shape scanned, no mode 7
+    or -- RGBA -- mode 7 scanned in full) but vary everything else (refinement counts incl. 0, mode 2 on / off, modes 4/5 and 6 on / off, the first
+    mode-4/5 rotation, RGB / RGBA), on a surface large enough for two bands and the pilot, with the pilot's verdict forced either way by turns"""
+    rng = np.random.default_rng(seed)
+    img = _mixed_content(golden_inputs, 516, 604)
+    rgba = bool(seed % 3 == 0)
+    if rgba:
+        img = img.copy()
+        img[::3, :, 3] = rng.integers(0, 256, img[::3, :, 3].shape)
+    s, o = itw.bc7_profile("alpha_slow" if rgba else "slow"), oracle.bc7_profile("alpha_slow" if rgba else "slow")
+    for t in (s, o):
+        t.skip_mode2 = int(seed % 2)
+        t.mode_selection[2] = int(seed % 4 != 1)
+        t.mode_selection[3] = int(seed % 4 != 2)
+        t.mode45_channel0 = seed % 3 if not rgba else seed % 4
+    its = rng.integers(0, 5, 8)
+    ch = int(rng.integers(0, 5))
+    for t in (s, o):
+        for i in range(8):
+            t.refineIterations[i] = int(its[i])
+        t.refineIterations_channel = ch
+    want = oracle.encode_mt("bc7", img, o)
+    for pilot in ((0, 100) if seed % 2 else (100, 0)):
+        itw.set_bc7_pilot(pilot)
+        try:
+            got = _encode(itw, gpu, img, s)
+        finally:
+            itw.set_bc7_pilot(None)
+        assert first_mismatch(got, want, 16) is None, (seed, pilot, first_mismatch(got, want, 16))
