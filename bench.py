@@ -517,6 +517,58 @@ def run_cpp_child(args, world, size, steps, warmup):
         return {"error": f"unreadable result of the C++ multi-GPU job: {e}"}
 
 
+def sliced_side(itw_amd, size, make_surface):
+    """formats["sliced@64"]: the plugin's slice loop (IntelPlugin.cpp:851-879: 0x40000-pixel slices, SetProgress between them) through
+    itwCompressImageSliced with a progress callback installed, HOST pointers (pageable memory), per trampoline the plugin selects (+ `slow`):
+    the pipeline (windows of slices in flight, csrc/abi.hip compress_sliced) beside the literal loop and ONE CompressImageST call."""
+    import ctypes as C
+    L = itw_amd.lib()
+    out = {"what": "4096^2, 64 slices of 0x40000 px, host pointers, progress callback per slice; Mpixels/s = best of 5 synchronous calls after a warm-up",
+           "slices": max(1, size * size // 0x40000)}
+    calls = []
+    cb = itw_amd.PROGRESS_FUNC(lambda i, n, u: calls.append(i) or True)
+    for fmt, prof in (("bc1", None), ("bc3", None), ("bc7", "veryfast"), ("bc7", "basic"), ("bc7", "alpha_veryfast"), ("bc7", "alpha_basic"),
+                      ("bc7", "slow"), ("bc6h", "fast"), ("bc6h", "slow")):
+        name = fmt + ("_" + prof if prof else "")
+        try:
+            img = make_surface(fmt, size, 0)
+            h, w = img.shape[:2]
+            nbytes = itw_amd.block_count(fmt, w, h) * itw_amd.BYTES_PER_BLOCK[fmt]
+            got, want = np.zeros(nbytes, dtype=np.uint8), np.zeros(nbytes, dtype=np.uint8)
+            surf = itw_amd.RgbaSurface(img.ctypes.data, w, h, img.strides[0])
+            fn, code = itw_amd.image_func(fmt, prof), itw_amd.DXGI_FORMAT[fmt]
+            pitch = itw_amd.block_count(fmt, w, 4) * itw_amd.BYTES_PER_BLOCK[fmt]
+
+            def best(f):
+                f()
+                ts = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    f()
+                    ts.append(time.perf_counter() - t0)
+                return min(ts) * 1e3
+            one = best(lambda: L.CompressImageST(C.byref(surf), want.ctypes.data, fn, code))
+            row = {"one_call_ms": round(one, 3), "one_call_Mpixels/s": round(w * h / one / 1e3, 1)}
+            for key, W in (("literal_loop", -1), ("pipeline", 0)):
+                L.itwSetSliceWindow(W)
+                got[:] = 0
+                del calls[:]
+                ms = best(lambda: L.itwCompressImageSliced(C.byref(surf), got.ctypes.data, pitch, fn, code, False, 0, C.cast(cb, C.c_void_p), None))
+                row[key + "_ms"] = round(ms, 3)
+                row[key + "_Mpixels/s"] = round(w * h / ms / 1e3, 1)
+                row[key + "_bytes_equal_one_call"] = bool(np.array_equal(got, want))
+                if W == 0:
+                    row["window_slices"] = int(L.itwSliceWindow(code, w, h, 0))
+                    row["progress_calls_per_run"] = len(calls) // 6
+            L.itwSetSliceWindow(0)
+            row["pipeline_over_one_call"] = round(one / row["pipeline_ms"], 3)
+            out[name] = row
+        except Exception as e:
+            itw_amd.lib().itwSetSliceWindow(0)
+            out[name] = {"error": repr(e)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -890,6 +942,8 @@ def main():
                                                              "what": "one synchronous CompressBlocksBC7 call with pageable host pointers: upload + kernels + download"}
             except Exception as e:
                 side["@baboon_tiled"] = {"error": repr(e)}
+            # the plugin's own calling pattern -- 64 slices with SetProgress between them -- through the pipelined slice loop
+            side["sliced@64"] = sliced_side(itw_amd, size, make_surface)
             # BC1 / BC3 are the HBM-side kernels: the same kernel on the 16384^2 surface of configs[4], where the launch ramp and
             # tail (about 6 us) stop mattering -- the steady-state fraction of the HBM roofline
             try:

@@ -74,13 +74,33 @@ void CompressImageBC6H_slow(const rgba_surface* input, uint8_t* output);
 void CompressImageBC6H_veryslow(const rgba_surface* input, uint8_t* output);
 
 /* The plugin's slice loop with progress / early out (IntelPlugin.cpp:851-879): the surface is cut into
- * `slices = width*height / slice_pixels` (>= 1) runs of block rows, `progress(i, slices, user)` is polled before every
- * slice but the first and aborts the job when it returns false (the call then returns false; slices already written
- * stay written).  `target` is the block array with `block_row_pitch` bytes between block rows (the reference passes
- * the DDS image's rowPitch).  slice_pixels <= 0 selects the reference's 0x40000; a GPU caller wants it much larger. */
+ * `slices = width*height / slice_pixels` (>= 1) runs of block rows (rows [i*h/slices & ~3, (i+1)*h/slices & ~3), the reference's
+ * arithmetic), `progress(i, slices, user)` is called for i = 1 .. slices-1 in order and aborts the job when it returns false (the
+ * call then returns false).  `target` is the block array with `block_row_pitch` bytes between block rows (the reference passes the
+ * DDS image's rowPitch); slice_pixels <= 0 selects the reference's 0x40000.
+ *
+ * The reference encodes slice i between progress(i) and progress(i+1), one synchronous CompressImageMT/ST call each.  Here, when
+ * `cmpFunc` is one of THIS library's CompressImage* trampolines and one GPU serves the call, the slices run as a PIPELINE instead:
+ * W consecutive slices form a window (upload, kernels and download of neighbouring windows overlap on three streams; W =
+ * itwSliceWindow(...), at most slices/8 -- slices/4 for BC1/BC3/BC4/BC5 -- so a progress bar keeps real steps), and progress(i) is called once slice i-1 -- and
+ * every slice before it -- is in `target`.  What a caller can observe of the difference:
+ *   * when progress(i) returns false, slices < i are written like in the reference, and so may be up to W-1 slices after them (the
+ *     rest of slice i-1's window); the window being encoded at that moment is drained and NOT copied back;
+ *   * progress calls of one window arrive back to back.
+ * Any other `cmpFunc` (a caller's own function: opaque), several GPUs with host memory, itwSetSliceWindow(-1) or a single slice:
+ * the literal loop.  Host or device pointers; synchronous either way. */
 typedef bool (ItwProgressFunc)(int done, int total, void* user);
 bool itwCompressImageSliced(const rgba_surface* source, uint8_t* target, int64_t block_row_pitch, CompressionFunc* cmpFunc,
                             int dxgi_format, bool multithreaded, int64_t slice_pixels, ItwProgressFunc* progress, void* user);
+/* The pipeline itself, for callers that hold a settings struct rather than a trampoline: `settings` = bc7_enc_settings* (BC7),
+ * bc6h_enc_settings* (BC6H), ignored otherwise.  Same slices, progress contract and return value. */
+bool itwCompressImageSlicedEx(const rgba_surface* source, uint8_t* target, int64_t block_row_pitch, int dxgi_format, const void* settings,
+                              int64_t slice_pixels, ItwProgressFunc* progress, void* user);
+/* W: slices per window.  itwSetSliceWindow(n > 0) fixes it process-wide (1 = the reference's early-out granularity exactly), 0 = by
+ * format and size (default; env ITW_SLICE_WINDOW presets it), n < 0 = no pipeline: itwCompressImageSliced runs the literal loop
+ * (also env ITW_SLICED_PIPELINE=0).  itwSliceWindow reports what a call would use (0: the literal loop). */
+void itwSetSliceWindow(int slices);
+int  itwSliceWindow(int dxgi_format, int width, int height, int64_t slice_pixels);
 
 /* Pad to multiples of 4 by edge replication (IntelPlugin.cpp:893-928): the step immediately before the ABI.
  * pixel_size = 4 (RGBA8) or 8 (RGBA16F).  Host version: returns a surface whose ptr was allocated with malloc()

@@ -14,6 +14,7 @@
 #include <cstring>
 #include "../../include/itw_amd.h"
 #include "../../include/itw_bc45.h"
+#include "../../include/itw_dispatch.h"
 #ifdef ITW_TEST_HOOKS
 #include "../../include/itw_test_hooks.h"
 #endif
@@ -290,6 +291,19 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
 
 bool coalesce_small_call(const Job& j, const rgba_surface* src, uint8_t* dst, int64_t blocks);
 
+// texel rows of a host surface into the tight staging image
+void upload_rows(uint8_t* d_rows, size_t pitch, const uint8_t* hs, int64_t stride, size_t row_bytes, size_t nrows, hipStream_t copy)
+{
+    if (stride >= (int64_t)row_bytes) {                      // (also for tight rows: measured faster than one linear pageable copy)
+        ITW_CHECK(hipMemcpy2DAsync(d_rows, pitch, hs, (size_t)stride, row_bytes, nrows, hipMemcpyHostToDevice, copy));
+    } else {
+        // bottom-up (negative stride) or overlapping rows: the reference just indexes ptr + y*stride with a
+        // signed stride (kernel.ispc:105-151), which a pitched copy cannot express -- stage row by row
+        for (size_t y = 0; y < nrows; y++)
+            ITW_CHECK(hipMemcpyAsync(d_rows + y * pitch, hs + (int64_t)y * stride, row_bytes, hipMemcpyHostToDevice, copy));
+    }
+}
+
 void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coalesce = true)
 {
     if (may_coalesce) itw::clear_failure();
@@ -424,15 +438,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         if (bands && c > 0 && verdict_pending) { poll_verdict(false); if (!verdict_pending) shape_wide = tls.staged_wide; }
         hipStream_t run_st = (bands && !shape_wide && ((c + 1) & 1)) ? tls.aux.stream : st;
         if (!src_dev) {
-            const uint8_t* hs = src->ptr + (int64_t)y0 * src->stride;
-            if ((int64_t)src->stride >= (int64_t)row_bytes) {      // (also for tight rows: measured faster than one linear pageable copy)
-                ITW_CHECK(hipMemcpy2DAsync(in + y0 * pitch, pitch, hs, (size_t)src->stride, row_bytes, nrows, hipMemcpyHostToDevice, copy));
-            } else {
-                // bottom-up (negative stride) or overlapping rows: the reference just indexes ptr + y*stride with a
-                // signed stride (kernel.ispc:105-151), which a pitched copy cannot express -- stage row by row
-                for (size_t y = 0; y < nrows; y++)
-                    ITW_CHECK(hipMemcpyAsync(in + (y0 + y) * pitch, hs + (int64_t)y * src->stride, row_bytes, hipMemcpyHostToDevice, copy));
-            }
+            upload_rows(in + y0 * pitch, pitch, src->ptr + (int64_t)y0 * src->stride, src->stride, row_bytes, nrows, copy);
             if (nch > 1) {
                 ITW_CHECK(hipEventRecord(tls.ev_in[c], cs));
                 ITW_CHECK(hipStreamWaitEvent(run_st, tls.ev_in[c], 0));
@@ -474,6 +480,170 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     }
     ITW_CHECK(hipStreamSynchronize(st));
     if (bands) poll_verdict(true);                            // for the next call, if it was not in before
+}
+
+// ---- the plugin's slice loop as a pipeline (include/itw_dispatch.h: itwCompressImageSlicedEx) -----------------------------
+// IntelPlugin.cpp:851-879 cuts a save into 0x40000-pixel slices and makes one synchronous CompressImageMT/ST call per slice, polling
+// SetProgress between them.  Restated literally on a GPU every slice is upload -> a latency-bound launch chain over 1/64 of the
+// chip-filling work -> download -> synchronise (BC7 `basic`: 1 274 Mpix/s against 4 175 for one call over the surface).  Here the same
+// slices, progress calls and early out run as a PIPELINE: consecutive slices form a WINDOW (the unit of upload / launch / download; at
+// most an eighth of the slices -- a quarter for the PCIe-bound formats --, so the progress bar keeps real steps), window k's kernels run on stream k % 2 with its
+// upload and the previous window's download on the copy stream, and `progress(i, slices)` is called for every slice i of a window -- in
+// order, each call only after the slices before it are in `target` -- once that window's bytes have arrived.  A false return stops the
+// job: nothing further is issued or copied back, the one window in flight is drained, and every slice below i (and the rest of i's own
+// window, at most W - 1 slices more) stays written, like the reference's early out.
+std::atomic<int> g_slice_window{0};                // itwSetSliceWindow: 0 = by format and size, -1 = no pipeline (the literal loop)
+
+int slice_window_setting()
+{
+    int W = g_slice_window.load(std::memory_order_relaxed);
+    if (W == 0) {
+        static const int env = [] {
+            const char* off = std::getenv("ITW_SLICED_PIPELINE");
+            if (off && off[0] == '0') return -1;
+            const char* e = std::getenv("ITW_SLICE_WINDOW");
+            return e ? std::atoi(e) : 0;
+        }();
+        W = env;
+    }
+    return W;
+}
+
+int slice_window(Fmt fmt, int64_t slice_blocks, int slices)
+{
+    int W = slice_window_setting();
+    if (W <= 0) {
+        // BC7 / BC6H: a window must fill the chip (131 072 blocks = one block per lane of 2 waves per SIMD; two windows are in flight);
+        // BC1 / BC3 / BC4 / BC5 are PCIe-bound: fewer, larger copies
+        const int64_t target = (fmt == Fmt::BC7 || fmt == Fmt::BC6H) ? 131072 : 262144;
+        const int64_t per = slice_blocks < 1 ? 1 : slice_blocks;
+        W = (int)((target + per / 2) / per);
+        // the caller's progress bar keeps >= 8 real steps (>= 4 for the PCIe-bound formats, where a window is two pageable copies of ~40 us
+        // fixed cost each: 4096^2 BC1 runs at 8 200 Mpix/s with 8 windows, 11 200 with 4, 12 100 as one call; profiles/r06a_sliced_timing.jsonl)
+        const int cap = slices / ((fmt == Fmt::BC7 || fmt == Fmt::BC6H) ? 8 : 4);
+        if (W > cap) W = cap;
+    }
+    if (W < 1) W = 1;
+    if (W > slices) W = slices;
+    return W;
+}
+
+struct SliceRows { int64_t y0, y1; };
+// rows of slice i of `slices` (IntelPlugin.cpp:861-865); the formats that keep partial blocks end the last slice at `height`
+SliceRows slice_rows(int i, int slices, int height, bool keep_partial)
+{
+    SliceRows r;
+    r.y0 = ((int64_t)i * height / slices) & ~(int64_t)3;
+    r.y1 = ((int64_t)(i + 1) * height / slices) & ~(int64_t)3;
+    if (r.y1 > height) r.y1 = height;
+    if (i == slices - 1 && keep_partial) r.y1 = height;
+    return r;
+}
+
+// returns true when every slice was encoded, false when `progress` stopped the job
+bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user)
+{
+    itw::clear_failure();
+    if (!src) itw::fail_msg("null surface");
+    const int w = src->width, h = src->height;
+    const bool keep_partial = (j.fmt == Fmt::BC4 || j.fmt == Fmt::BC5);
+    const int bx = keep_partial ? (w > 0 ? (w + 3) / 4 : 0) : w / 4, by = keep_partial ? (h > 0 ? (h + 3) / 4 : 0) : h / 4;
+    if (slices < 1) slices = 1;
+    auto poll = [&](int first, int last) {               // progress(i) for i in [first, last], i < slices; false = stop
+        for (int i = first; i <= last && i < slices; i++)
+            if (i > 0 && progress && !progress(i, slices, user)) return false;
+        return true;
+    };
+    if (bx <= 0 || by <= 0) return poll(1, slices - 1);   // nothing to encode: the reference's loop still polls
+    if (!src->ptr || !dst) itw::fail_msg("null texel or destination pointer");
+    const int bpb = (j.fmt == Fmt::BC1 || j.fmt == Fmt::BC4) ? 8 : 16;
+    const int texel_bytes = (j.fmt == Fmt::BC6H) ? 8 : 4;
+    const size_t row_bytes = keep_partial ? (size_t)w * 4 : (size_t)bx * 4 * texel_bytes;
+    const size_t rows = keep_partial ? (size_t)h : (size_t)by * 4;
+    const size_t out_bytes = (size_t)bx * by * bpb;
+    const bool src_dev = is_device_pointer(src->ptr), dst_dev = is_device_pointer(dst);
+
+    const int W = slice_window(j.fmt, (int64_t)bx * by / slices, slices);
+    const int nwin = (slices + W - 1) / W;
+
+    ensure_device_ctx();
+    ensure_bc7_aux();
+    hipStream_t k0 = tls.own_stream, k1 = tls.aux.stream, cs = tls.copy_stream;
+    // whatever produced a device surface (or still reads the destination) on the caller's stream comes first
+    if ((src_dev || dst_dev) && tls.user_stream != k0) ITW_CHECK(hipStreamSynchronize(tls.user_stream));
+    const size_t pitch = (row_bytes + 15) & ~(size_t)15;
+    uint8_t* in = src_dev ? nullptr : (uint8_t*)grow(tls.d_in, tls.in_cap, pitch * rows);
+    const uint8_t* d_src = src_dev ? src->ptr : in;
+    const int64_t d_stride = src_dev ? (int64_t)src->stride : (int64_t)pitch;
+    uint8_t* d_dst = dst_dev ? dst : (uint8_t*)grow(tls.d_out, tls.out_cap, out_bytes);
+
+    // BC7: one slice of the per-thread workspace per kernel stream, sized for the tallest window (deep shape: `single` in launch())
+    size_t ws_off[2] = {0, 0};
+    if (j.fmt == Fmt::BC7) {
+        int64_t tallest = 0;
+        for (int k = 0; k < nwin; k++) {
+            const int s1 = (k + 1) * W < slices ? (k + 1) * W : slices;
+            const int64_t r = slice_rows(s1 - 1, slices, h, false).y1 - slice_rows(k * W, slices, h, false).y0;
+            if (r > tallest) tallest = r;
+        }
+        const size_t b = (itw::bc7_workspace_bytes(w, (int)tallest, 1) + 255) & ~(size_t)255;
+        ws_off[1] = b;
+        reserve_workspace(2 * b, k0);
+    }
+    ITW_CHECK(hipEventRecord(tls.aux.fork, k0));          // the second stream starts behind whatever ordered the workspace on the first
+    ITW_CHECK(hipStreamWaitEvent(k1, tls.aux.fork, 0));
+
+    // However this ends, nothing of this call is left in flight on the thread's streams and buffers (a failure is a C++ exception here)
+    struct Drain {
+        hipStream_t a, b, c; bool bc7;
+        ~Drain() {
+            (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b); (void)hipStreamSynchronize(c);
+            if (bc7 && tls.ws_event) (void)hipEventRecord(tls.ws_event, a);
+            (void)hipGetLastError();
+        }
+    } drain{k0, k1, cs, j.fmt == Fmt::BC7};
+
+    struct Window { int s0, s1; int64_t y0, y1; int row0, nb; };
+    auto window = [&](int k) {
+        Window v;
+        v.s0 = k * W; v.s1 = (k + 1) * W < slices ? (k + 1) * W : slices;
+        v.y0 = slice_rows(v.s0, slices, h, keep_partial).y0;
+        v.y1 = slice_rows(v.s1 - 1, slices, h, keep_partial).y1;
+        v.row0 = (int)(v.y0 / 4);
+        v.nb = (int)((v.y1 - v.y0 + 3) / 4);
+        return v;
+    };
+    auto issue = [&](int k) {
+        const Window v = window(k);
+        if (v.y1 <= v.y0) return;
+        hipStream_t ks = (k & 1) ? k1 : k0;
+        const size_t nrows = (size_t)(v.y1 - v.y0);
+        if (!src_dev) {
+            upload_rows(in + (size_t)v.y0 * pitch, pitch, src->ptr + v.y0 * (int64_t)src->stride, src->stride, row_bytes, nrows, cs);
+            ITW_CHECK(hipEventRecord(tls.ev_in[k & 7], cs));
+            ITW_CHECK(hipStreamWaitEvent(ks, tls.ev_in[k & 7], 0));
+        }
+        launch(j, d_src + v.y0 * d_stride, d_stride, w, (int)nrows, d_dst + (size_t)v.row0 * bx * bpb, ks, true, j.fmt == Fmt::BC7 ? 1 : -1, ws_off[k & 1]);
+        ITW_CHECK(hipEventRecord(tls.ev_done[k & 7], ks));
+    };
+    auto retire = [&](int k) {                            // window k's bytes into `dst`; returns when they are there
+        const Window v = window(k);
+        if (v.y1 <= v.y0) return;
+        if (dst_dev) { ITW_CHECK(hipEventSynchronize(tls.ev_done[k & 7])); return; }
+        const size_t off = (size_t)v.row0 * bx * bpb, len = (size_t)v.nb * bx * bpb;
+        ITW_CHECK(hipStreamWaitEvent(cs, tls.ev_done[k & 7], 0));
+        ITW_CHECK(hipMemcpyAsync(dst + off, d_dst + off, len, hipMemcpyDeviceToHost, cs));
+        ITW_CHECK(hipStreamSynchronize(cs));
+    };
+    for (int k = 0; k <= nwin; k++) {
+        if (k < nwin) issue(k);
+        if (k > 0) {
+            retire(k - 1);
+            const Window v = window(k - 1);
+            if (!poll(v.s0 + 1, v.s1)) return false;     // window k (if any) is in flight: ~Drain waits for it, its bytes are not copied back
+        }
+    }
+    return true;
 }
 
 // ---- joining concurrent small calls ----------------------------------------------------------------------------------
@@ -748,6 +918,51 @@ void CompressBlocksBC4(const rgba_surface* src, uint8_t* dst)
 void CompressBlocksBC5(const rgba_surface* src, uint8_t* dst)
 {
     itw::guarded([&] { Job j; j.fmt = Fmt::BC5; compress(j, src, dst); });
+}
+
+bool itwCompressImageSlicedEx(const rgba_surface* source, uint8_t* target, int64_t block_row_pitch, int dxgi_format, const void* settings,
+                              int64_t slice_pixels, ItwProgressFunc* progress, void* user)
+{
+    bool done = false;
+    const bool ok = itw::guarded([&] {
+        if (!source) itw::fail_msg("null surface");
+        Job j;
+        switch (dxgi_format) {
+        case ITW_DXGI_FORMAT_BC1_UNORM: case ITW_DXGI_FORMAT_BC1_UNORM_SRGB: j.fmt = Fmt::BC1; break;
+        case ITW_DXGI_FORMAT_BC3_UNORM: case ITW_DXGI_FORMAT_BC3_UNORM_SRGB: j.fmt = Fmt::BC3; break;
+        case ITW_DXGI_FORMAT_BC4_UNORM: j.fmt = Fmt::BC4; break;
+        case ITW_DXGI_FORMAT_BC5_UNORM: j.fmt = Fmt::BC5; break;
+        case ITW_DXGI_FORMAT_BC6H_UF16: case ITW_DXGI_FORMAT_BC6H_SF16: j.fmt = Fmt::BC6H; j.s6 = static_cast<const bc6h_enc_settings*>(settings); break;
+        case ITW_DXGI_FORMAT_BC7_UNORM: case ITW_DXGI_FORMAT_BC7_UNORM_SRGB: j.fmt = Fmt::BC7; j.s7 = static_cast<const bc7_enc_settings*>(settings); break;
+        default: itw::fail_msg("itwCompressImageSlicedEx: DXGI format %d is not one this library encodes", dxgi_format);
+        }
+        if ((j.fmt == Fmt::BC7 || j.fmt == Fmt::BC6H) && !settings) itw::fail_msg("itwCompressImageSlicedEx: null settings");
+        const bool keep = j.fmt == Fmt::BC4 || j.fmt == Fmt::BC5;
+        const int64_t tight = (int64_t)(keep ? (source->width + 3) / 4 : source->width / 4) * ((j.fmt == Fmt::BC1 || j.fmt == Fmt::BC4) ? 8 : 16);
+        if (block_row_pitch != tight) itw::fail_msg("itwCompressImageSlicedEx: block_row_pitch %lld != %lld (tight)", (long long)block_row_pitch, (long long)tight);
+        if (slice_pixels <= 0) slice_pixels = 0x40000;                               // IntelPlugin.cpp:851
+        int64_t slices = ((int64_t)source->width * source->height) / slice_pixels;
+        if (slices < 1) slices = 1;
+        if (slices > (1 << 24)) itw::fail_msg("itwCompressImageSlicedEx: %lld slices", (long long)slices);
+        done = compress_sliced(j, source, target, (int)slices, progress, user);
+    });
+    return ok && done;
+}
+
+void itwSetSliceWindow(int slices) { g_slice_window.store(slices < 0 ? -1 : slices, std::memory_order_relaxed); }
+
+int itwSliceWindow(int dxgi_format, int width, int height, int64_t slice_pixels)
+{
+    if (slice_window_setting() < 0) return 0;
+    if (slice_pixels <= 0) slice_pixels = 0x40000;
+    int64_t slices = ((int64_t)width * height) / slice_pixels;
+    if (slices < 1) slices = 1;
+    if (slices > (1 << 24)) slices = 1 << 24;
+    const bool keep = dxgi_format == ITW_DXGI_FORMAT_BC4_UNORM || dxgi_format == ITW_DXGI_FORMAT_BC5_UNORM;
+    const int64_t blocks = keep ? (int64_t)((width + 3) / 4) * ((height + 3) / 4) : (int64_t)(width / 4) * (height / 4);
+    const bool heavy = dxgi_format == ITW_DXGI_FORMAT_BC7_UNORM || dxgi_format == ITW_DXGI_FORMAT_BC7_UNORM_SRGB ||
+                       dxgi_format == ITW_DXGI_FORMAT_BC6H_UF16 || dxgi_format == ITW_DXGI_FORMAT_BC6H_SF16;
+    return slice_window(heavy ? Fmt::BC7 : Fmt::BC1, blocks / slices, (int)slices);
 }
 
 void  itwSetStream(void* s) { tls.user_stream = (hipStream_t)s; }

@@ -234,6 +234,35 @@ ITW_BC7_TRAMPOLINE(alpha_ultrafast) ITW_BC7_TRAMPOLINE(alpha_veryfast) ITW_BC7_T
 ITW_BC7_TRAMPOLINE(alpha_basic) ITW_BC7_TRAMPOLINE(alpha_slow)
 ITW_BC6H_TRAMPOLINE(veryfast) ITW_BC6H_TRAMPOLINE(fast) ITW_BC6H_TRAMPOLINE(basic) ITW_BC6H_TRAMPOLINE(slow) ITW_BC6H_TRAMPOLINE(veryslow)
 
+// The library's own trampolines are recognised by address: for them the slice loop runs as a pipeline (abi.hip, compress_sliced) with the
+// format and the preset's settings in hand.  Any other CompressionFunc is opaque -- it can only be called, synchronously, slice by slice.
+static bool resolve_trampoline(CompressionFunc* fn, int dxgi_format, bc7_enc_settings* s7, bc6h_enc_settings* s6, const void** settings)
+{
+    *settings = nullptr;
+    const bool bc7 = dxgi_format == ITW_DXGI_FORMAT_BC7_UNORM || dxgi_format == ITW_DXGI_FORMAT_BC7_UNORM_SRGB;
+    const bool bc6 = dxgi_format == ITW_DXGI_FORMAT_BC6H_UF16 || dxgi_format == ITW_DXGI_FORMAT_BC6H_SF16;
+    if (fn == &CompressImageBC1) return dxgi_format == ITW_DXGI_FORMAT_BC1_UNORM || dxgi_format == ITW_DXGI_FORMAT_BC1_UNORM_SRGB;
+    if (fn == &CompressImageBC3) return dxgi_format == ITW_DXGI_FORMAT_BC3_UNORM || dxgi_format == ITW_DXGI_FORMAT_BC3_UNORM_SRGB;
+    if (fn == &CompressImageBC4) return dxgi_format == ITW_DXGI_FORMAT_BC4_UNORM;
+    if (fn == &CompressImageBC5) return dxgi_format == ITW_DXGI_FORMAT_BC5_UNORM;
+    struct P7 { CompressionFunc* fn; void (*get)(bc7_enc_settings*); };
+    static const P7 p7[] = {
+        {&CompressImageBC7_ultrafast, &GetProfile_ultrafast}, {&CompressImageBC7_veryfast, &GetProfile_veryfast}, {&CompressImageBC7_fast, &GetProfile_fast},
+        {&CompressImageBC7_basic, &GetProfile_basic}, {&CompressImageBC7_slow, &GetProfile_slow},
+        {&CompressImageBC7_alpha_ultrafast, &GetProfile_alpha_ultrafast}, {&CompressImageBC7_alpha_veryfast, &GetProfile_alpha_veryfast},
+        {&CompressImageBC7_alpha_fast, &GetProfile_alpha_fast}, {&CompressImageBC7_alpha_basic, &GetProfile_alpha_basic},
+        {&CompressImageBC7_alpha_slow, &GetProfile_alpha_slow}};
+    for (const P7& e : p7)
+        if (fn == e.fn) { if (!bc7) return false; std::memset(s7, 0, sizeof *s7); e.get(s7); *settings = s7; return true; }
+    struct P6 { CompressionFunc* fn; void (*get)(bc6h_enc_settings*); };
+    static const P6 p6[] = {
+        {&CompressImageBC6H_veryfast, &GetProfile_bc6h_veryfast}, {&CompressImageBC6H_fast, &GetProfile_bc6h_fast}, {&CompressImageBC6H_basic, &GetProfile_bc6h_basic},
+        {&CompressImageBC6H_slow, &GetProfile_bc6h_slow}, {&CompressImageBC6H_veryslow, &GetProfile_bc6h_veryslow}};
+    for (const P6& e : p6)
+        if (fn == e.fn) { if (!bc6) return false; std::memset(s6, 0, sizeof *s6); e.get(s6); *settings = s6; return true; }
+    return false;
+}
+
 bool itwCompressImageSliced(const rgba_surface* source, uint8_t* target, int64_t block_row_pitch, CompressionFunc* cmpFunc,
                             int dxgi_format, bool multithreaded, int64_t slice_pixels, ItwProgressFunc* progress, void* user)
 {
@@ -247,6 +276,14 @@ bool itwCompressImageSliced(const rgba_surface* source, uint8_t* target, int64_t
         std::fprintf(stderr, "itwCompressImageSliced: block_row_pitch %lld != %lld (tight)\n", (long long)block_row_pitch, (long long)tight);
         return false;
     }
+    // One GPU behind the call (one worker, or a surface that lives on a device): the slices run as a pipeline.  With several GPUs
+    // CompressImageMT hands every slice's bands to all of them, as the reference's pool does with its threads.
+    bc7_enc_settings s7;
+    bc6h_enc_settings s6;
+    const void* settings = nullptr;
+    if (slices > 1 && itwSliceWindow(dxgi_format, source->width, source->height, slice_pixels) > 0 && resolve_trampoline(cmpFunc, dxgi_format, &s7, &s6, &settings) &&
+        (!multithreaded || worker_count() == 1 || is_device_pointer(source->ptr) || is_device_pointer(target)))
+        return itwCompressImageSlicedEx(source, target, block_row_pitch, dxgi_format, settings, slice_pixels, progress, user);
     for (int i = 0; i < slices; i++) {
         if (i > 0 && progress && !progress(i, slices, user)) return false;          // allow an early out
         int ylo = (int)((int64_t)i * source->height / slices) & ~0x3;

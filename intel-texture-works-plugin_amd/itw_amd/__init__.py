@@ -12,6 +12,6 @@ GPU is present, calls raise / the library aborts.  Nothing here imports oracle/.
 from .abi import (  # noqa: F401
     lib, test_lib, TEST_HOOK_SYMBOLS, lib_path, RgbaSurface, Bc7Settings, Bc6hSettings, BC7_PROFILES, BC6H_PROFILES,
     bc7_profile, bc6h_profile, compress, compress_numpy, band_for_part, version, device_info,
-    BYTES_PER_BLOCK, EXPORTED_SYMBOLS, DXGI_FORMAT, DdsDesc, image_func, compress_image, pad_to_multiple_of_4, dds_file, decode, block_count, KEEPS_PARTIAL_BLOCKS,
+    BYTES_PER_BLOCK, EXPORTED_SYMBOLS, DXGI_FORMAT, DdsDesc, image_func, compress_image, PROGRESS_FUNC, pad_to_multiple_of_4, dds_file, decode, block_count, KEEPS_PARTIAL_BLOCKS,
     available, set_error_mode, last_error, ON_ERROR_ABORT, ON_ERROR_RETURN, set_bc7_path, set_bc7_pilot, compress_image_multigpu, multigpu_sub_bands, MultiGpuStats, source_sha256, bc7_two_subset_bounds,
 )

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = tuple(
     + ["GetProcessorCount", "InitWin32Threads", "DestroyThreads", "GetBytesPerBlock", "CompressImageMT", "CompressImageST",
        "CompressImageBC1", "CompressImageBC3", "CompressImageBC4", "CompressImageBC5"]
     + ["CompressImageBC7_" + p for p in BC7_PROFILES] + ["CompressImageBC6H_" + p for p in BC6H_PROFILES]
-    + ["itwCompressImageSliced", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
+    + ["itwCompressImageSliced", "itwCompressImageSlicedEx", "itwSetSliceWindow", "itwSliceWindow", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
        "itwConvertToRGBA8Device", "itwConvertToRGBA16FDevice"]
     # include/itw_multigpu.h: one surface over all GPUs, one process
     + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU", "itwCompressImageMultiGPUEx",
@@ -181,6 +181,12 @@ def _load(path, hooks):
         L.itwCompressImageSliced.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_bool,
                                              C.c_int64, C.c_void_p, C.c_void_p]
         L.itwCompressImageSliced.restype = C.c_bool
+        L.itwCompressImageSlicedEx.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.itwCompressImageSlicedEx.restype = C.c_bool
+        L.itwSetSliceWindow.argtypes = [C.c_int]
+        L.itwSetSliceWindow.restype = None
+        L.itwSliceWindow.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64]
+        L.itwSliceWindow.restype = C.c_int
         L.itwMultiGpuRanks.restype = C.c_int
         L.itwMultiGpuSetInterleave.argtypes = [C.c_int]
         L.itwMultiGpuSetInterleave.restype = None
@@ -386,16 +392,34 @@ def image_func(fmt, profile=None, L=None):
     return C.cast(getattr(L or lib(), name), C.c_void_p)
 
 
-def compress_image(fmt, img, profile=None, multithreaded=True, slice_pixels=0, progress=None):
+def compress_image(fmt, img, profile=None, multithreaded=True, slice_pixels=0, progress=None, out=None, settings=None):
     """The plugin's save path below the pixel conversion (IntelPlugin.cpp:816-884): slice loop -> CompressImageMT/ST ->
-    trampoline -> CompressBlocks*.  img: host numpy (H, W, 4) uint8 / uint16 half bits.  Returns (ok, blocks)."""
+    trampoline -> CompressBlocks* (itwCompressImageSliced; with `settings` -- a Bc7Settings / Bc6hSettings -- through
+    itwCompressImageSlicedEx).  img: host numpy (H, W, 4) uint8 / uint16 half bits, or a CUDA torch tensor of that shape
+    (then `out` is a CUDA uint8 tensor too unless given).  Returns (ok, blocks)."""
     import numpy as np
     h, w = img.shape[:2]
-    out = np.zeros(block_count(fmt, w, h) * BYTES_PER_BLOCK[fmt], dtype=np.uint8)
-    surf = RgbaSurface(img.ctypes.data, w, h, img.strides[0])
+    nbytes = block_count(fmt, w, h) * BYTES_PER_BLOCK[fmt]
+    on_device = hasattr(img, "data_ptr")
+    if on_device:
+        import torch
+        if out is None:
+            out = torch.zeros(nbytes, dtype=torch.uint8, device=img.device)
+        surf = RgbaSurface(img.data_ptr(), w, h, img.stride(0) * img.element_size())
+        lib().itwSetStream(torch.cuda.current_stream(img.device).cuda_stream)
+    else:
+        if out is None:
+            out = np.zeros(nbytes, dtype=np.uint8)
+        surf = RgbaSurface(img.ctypes.data, w, h, img.strides[0])
+    dst = out.data_ptr() if hasattr(out, "data_ptr") else out.ctypes.data
     cb = PROGRESS_FUNC(progress) if progress else None
-    ok = lib().itwCompressImageSliced(C.byref(surf), out.ctypes.data, block_count(fmt, w, 4) * BYTES_PER_BLOCK[fmt], image_func(fmt, profile),
-                                      DXGI_FORMAT[fmt], multithreaded, slice_pixels, C.cast(cb, C.c_void_p) if cb else None, None)
+    pitch = block_count(fmt, w, 4) * BYTES_PER_BLOCK[fmt]
+    if settings is not None:
+        ok = lib().itwCompressImageSlicedEx(C.byref(surf), dst, pitch, DXGI_FORMAT[fmt], C.cast(C.byref(settings), C.c_void_p), slice_pixels,
+                                            C.cast(cb, C.c_void_p) if cb else None, None)
+    else:
+        ok = lib().itwCompressImageSliced(C.byref(surf), dst, pitch, image_func(fmt, profile),
+                                          DXGI_FORMAT[fmt], multithreaded, slice_pixels, C.cast(cb, C.c_void_p) if cb else None, None)
     return bool(ok), out
 
 

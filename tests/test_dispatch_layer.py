@@ -77,6 +77,131 @@ def test_slice_loop_progress_and_abort(itw, gpu, oracle):
     assert ok and np.array_equal(out, oracle.encode("bc5", odd).reshape(-1))
 
 
+PLUGIN_TRAMPOLINES = [("bc1", None), ("bc3", None), ("bc7", "veryfast"), ("bc7", "basic"), ("bc7", "alpha_veryfast"), ("bc7", "alpha_basic"),
+                      ("bc6h", "fast"), ("bc6h", "slow"), ("bc7", "slow"), ("bc7", "alpha_slow"), ("bc4", None), ("bc5", None)]
+
+
+def _slice_bounds(i, slices, h):
+    return (i * h // slices) & ~3
+
+
+@pytest.fixture
+def slice_window(itw):
+    """itwSetSliceWindow for one test, back to the default afterwards."""
+    yield itw.lib().itwSetSliceWindow
+    itw.lib().itwSetSliceWindow(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resident", [False, True])
+def test_sliced_pipeline_every_plugin_trampoline_vs_oracle(itw, gpu, oracle, resident, slice_window):
+    """itwCompressImageSliced as a pipeline (windows of slices in flight, itw_dispatch.h): every trampoline the plugin selects
+    (IntelPlugin.cpp:816-848) + the slow presets + BC4/BC5 on 64 slices, host and device pointers: bytes of the oracle, one progress
+    call per slice boundary, in order."""
+    import torch
+    from itw_amd import surfaces
+    ldr = surfaces.ldr_smooth(384, 256)                       # 98304 px -> 64 slices of 1536 px = 6 texel rows: slices of 4 and 8 rows alternate
+    hdr = surfaces.hdr_smooth(384, 256)
+    odd = np.ascontiguousarray(ldr[:382, :253])               # partial last block row / column (BC4 / BC5)
+    for fmt, prof in PLUGIN_TRAMPOLINES:
+        img = hdr if fmt == "bc6h" else (odd if fmt in ("bc4", "bc5") else ldr)
+        h, w = img.shape[:2]
+        slice_pixels = w * h // 64
+        assert itw.lib().itwSliceWindow(itw.DXGI_FORMAT[fmt], w, h, slice_pixels) == (8 if fmt in ("bc7", "bc6h") else 16)
+        want = oracle.encode(fmt, img, prof).reshape(-1)
+        calls = []
+        src = torch.from_numpy(img.view(np.int16) if fmt == "bc6h" else img).to(gpu) if resident else img
+        ok, out = itw.compress_image(fmt, src, prof, multithreaded=False, slice_pixels=slice_pixels, progress=lambda i, n, u: calls.append((i, n)) or True)
+        got = out.cpu().numpy() if resident else out
+        assert ok and calls == [(i, 64) for i in range(1, 64)], (fmt, prof, calls[:5])
+        assert np.array_equal(got, want), (fmt, prof, resident)
+    # every window size gives the same bytes (1 = the reference's granularity; 64 = one window)
+    want = oracle.encode("bc7", ldr, "basic").reshape(-1)
+    for W in (1, 3, 5, 64):
+        slice_window(W)
+        src = torch.from_numpy(ldr).to(gpu) if resident else ldr
+        ok, out = itw.compress_image("bc7", src, "basic", slice_pixels=1536, progress=lambda i, n, u: True)
+        assert ok and np.array_equal(out.cpu().numpy() if resident else out, want), W
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 32, 63])
+def test_sliced_pipeline_abort_contract(itw, gpu, oracle, k, slice_window):
+    """progress(k) returns false = "abort after slice k-1": the call returns false after exactly k progress calls, slices < k hold the
+    oracle's bytes, at most the rest of slice k-1's window is written behind them and nothing of the window in flight is copied back
+    (host memory); with a window of one slice it is the reference's early out to the byte (IntelPlugin.cpp:857-858)."""
+    import torch
+    from itw_amd import surfaces
+    img = surfaces.ldr_smooth(512, 256)                       # 64 slices of 8 texel rows = 2 block rows of 64 blocks
+    want = oracle.encode("bc7", img, "veryfast").reshape(-1)
+    slice_bytes = 2 * 64 * 16
+    for W in (0, 1):                                          # default (8 slices per window here) and the reference's granularity
+        slice_window(W)
+        win = itw.lib().itwSliceWindow(98, 256, 512, 2048)
+        assert win == (8 if W == 0 else 1)
+        for resident in (False, True):
+            calls = []
+            src = torch.from_numpy(img).to(gpu) if resident else img
+            ok, out = itw.compress_image("bc7", src, "veryfast", multithreaded=False, slice_pixels=2048,
+                                         progress=lambda i, n, u: calls.append(i) or i != k)
+            got = out.cpu().numpy() if resident else out
+            assert not ok and calls == list(range(1, k + 1)), (W, resident, calls)
+            assert itw.lib().itwLastError() is None            # an early out is not a failure
+            done = k * slice_bytes
+            assert np.array_equal(got[:done], want[:done]), (W, resident)
+            window_end = ((k - 1) // win + 1) * win * slice_bytes   # end of the window slice k-1 belongs to
+            assert np.array_equal(got[done:window_end], want[done:window_end])
+            if not resident:                                  # the window in flight is drained, not copied back
+                assert not got[window_end:].any(), (W, k)
+    # the next call on the same thread starts clean (streams drained, workspace ordered)
+    slice_window(0)
+    ok, out = itw.compress_image("bc7", img, "veryfast", slice_pixels=2048, progress=lambda i, n, u: True)
+    assert ok and np.array_equal(out, want)
+
+
+@pytest.mark.gpu
+def test_sliced_ex_with_a_settings_struct_and_literal_loop_switch(itw, gpu, oracle, slice_window):
+    """itwCompressImageSlicedEx takes the caller's settings struct; itwSetSliceWindow(-1) turns itwCompressImageSliced back into the
+    literal loop (same bytes, same progress calls); a caller's own CompressionFunc is opaque and always takes the literal loop."""
+    from itw_amd import surfaces
+    img = surfaces.ldr_smooth(256, 256)
+    st = itw.bc7_profile("basic")
+    st.fastSkipTreshold_mode1 = 5; st.fastSkipTreshold_mode3 = 3; st.refineIterations[1] = 1
+    want = oracle.encode("bc7", img, _as_oracle_settings(oracle, st)).reshape(-1)
+    calls = []
+    ok, out = itw.compress_image("bc7", img, slice_pixels=4096, settings=st, progress=lambda i, n, u: calls.append(i) or True)
+    assert ok and calls == list(range(1, 16)) and np.array_equal(out, want)
+    hdr = surfaces.hdr_smooth(128, 256)
+    s6 = itw.bc6h_profile("basic"); s6.fastSkipTreshold = 3
+    ok, out = itw.compress_image("bc6h", hdr, slice_pixels=2048, settings=s6, progress=lambda i, n, u: True)
+    assert ok and np.array_equal(out, oracle.encode("bc6h", hdr, _as_oracle_settings(oracle, s6)).reshape(-1))
+    slice_window(-1)
+    assert itw.lib().itwSliceWindow(98, 256, 256, 4096) == 0
+    calls = []
+    want = oracle.encode("bc7", img, "alpha_basic").reshape(-1)
+    ok, out = itw.compress_image("bc7", img, "alpha_basic", slice_pixels=4096, progress=lambda i, n, u: calls.append(i) or True)
+    assert ok and calls == list(range(1, 16)) and np.array_equal(out, want)
+    slice_window(0)
+    # an opaque CompressionFunc (here a ctypes callback that forwards to the library): literal loop, one call per slice
+    seen = []
+    def own(surf_p, dst):
+        seen.append(surf_p.contents.height)
+        itw.lib().CompressImageBC7_alpha_basic(surf_p, dst)
+    fn = C.CFUNCTYPE(None, C.POINTER(itw.RgbaSurface), C.c_void_p)(own)
+    out = np.zeros_like(want)
+    surf = itw.RgbaSurface(img.ctypes.data, 256, 256, img.strides[0])
+    assert itw.lib().itwCompressImageSliced(C.byref(surf), out.ctypes.data, 64 * 16, C.cast(fn, C.c_void_p), 98, False, 4096, None, None)
+    assert seen == [16] * 16 and np.array_equal(out, want)
+
+
+def _as_oracle_settings(oracle, st):
+    """The binding's settings struct as the oracle's (same layout, ispc_texcomp.h:27-50)."""
+    cls = oracle.Bc7Settings if C.sizeof(st) == 64 else oracle.Bc6hSettings
+    o = cls()
+    C.memmove(C.byref(o), C.byref(st), C.sizeof(st))
+    return o
+
+
 @pytest.mark.gpu
 def test_device_pad_kernel(itw, gpu):
     import torch
