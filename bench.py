@@ -63,7 +63,7 @@ WORKLOADS = {
     "bc1": ("bc1", None), "bc3": ("bc3", None), "bc4": ("bc4", None), "bc5": ("bc5", None),
     "bc7_ultrafast": ("bc7", "ultrafast"), "bc7_veryfast": ("bc7", "veryfast"), "bc7_fast": ("bc7", "fast"),
     "bc7_basic": ("bc7", "basic"), "bc7_slow": ("bc7", "slow"),
-    "bc7_alpha_basic": ("bc7", "alpha_basic"), "bc7_alpha_slow": ("bc7", "alpha_slow"),
+    "bc7_alpha_veryfast": ("bc7", "alpha_veryfast"), "bc7_alpha_basic": ("bc7", "alpha_basic"), "bc7_alpha_slow": ("bc7", "alpha_slow"),
     "bc6h_fast": ("bc6h", "fast"), "bc6h_basic": ("bc6h", "basic"), "bc6h_slow": ("bc6h", "slow"),
 }
 
@@ -126,13 +126,21 @@ def fake_blocks(fmt, img):
     return np.ascontiguousarray(np.tile(tl, (1, reps))[:, :bpb]).reshape(-1)
 
 
+ABI_CALLS = [0]        # C-ABI encode calls this process has made: tools/summarize_profiles.py divides a profiled run's counters by it
+
+
+def _compress(itw, fmt, d_img, prof, out):
+    ABI_CALLS[0] += 1
+    return itw.compress(fmt, d_img, prof, out=out)
+
+
 def make_encoder(itw, fmt, prof, img, dev):
     """(encode_into(out_band), device texels or None) for one band of texels."""
     if FAKE:
         blocks = torch.from_numpy(fake_blocks(fmt, img))
         return (lambda out: out.copy_(blocks)), None
     d_img = torch.from_numpy(img).to(dev)
-    return (lambda out: itw.compress(fmt, d_img, prof, out=out)), d_img
+    return (lambda out: _compress(itw, fmt, d_img, prof, out)), d_img
 
 
 def verify_gather(itw, dist, full, scaling, size, world, rank, fmt, prof, dev, pieces=1):
@@ -180,13 +188,13 @@ def time_kernel(itw, fmt, prof, d_img, d_out, steps, warmup, back_to_back=False)
     if FAKE:
         return 1.0, 1.0
     for _ in range(warmup):
-        itw.compress(fmt, d_img, prof, out=d_out)
+        _compress(itw, fmt, d_img, prof, d_out)
     torch.cuda.synchronize()
     if back_to_back:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         for _ in range(steps):
-            itw.compress(fmt, d_img, prof, out=d_out)
+            _compress(itw, fmt, d_img, prof, d_out)
         b.record()
         torch.cuda.synchronize()
         t = a.elapsed_time(b) / steps
@@ -194,7 +202,7 @@ def time_kernel(itw, fmt, prof, d_img, d_out, steps, warmup, back_to_back=False)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     for a, b in evs:
         a.record()
-        itw.compress(fmt, d_img, prof, out=d_out)
+        _compress(itw, fmt, d_img, prof, d_out)
         b.record()
     torch.cuda.synchronize()
     ts = [a.elapsed_time(b) for a, b in evs]
@@ -302,6 +310,31 @@ def pmc_valu(workload):
     if not j or workload not in j:
         return None, None, None
     return j[workload].get("SQ_INSTS_VALU"), j[workload].get("per_kernel"), j.get("_source_sha256")
+
+
+def isolated_kernels(workload, cur_sha):
+    """rocprof_kernels.isolated: per kernel of one C-ABI call, from the SERIALISED dispatches of the committed SQ counter pass
+    (profiles/*_valu_by_workload.json `isolated`, tools/summarize_profiles.py): ms, VALU wave-instructions, the lane-op fraction of the
+    78.6 T peak and the issue fraction (cycles per instruction of that kernel from the weighted ISA model).  These durations do not
+    overlap -- the kernel-trace summary's do since a call is two bands on two streams -- so their sum is >= the call's time."""
+    path, j = _latest_profile("_valu_by_workload.json")
+    if not j or workload not in j or j.get("_source_sha256") != cur_sha or "isolated" not in j[workload]:
+        return None
+    _, model = _latest_profile("_issue_model.json")
+    by_name = (model or {}).get("by_rocprof_name", {}) if (model or {}).get("_source_sha256") == cur_sha else {}
+    rows = {}
+    for k, v in j[workload]["isolated"].items():
+        if v["ms"] <= 0:
+            continue
+        lane = v["wave_valu"] * 64 / (v["ms"] * 1e-3) / 1e12
+        row = {"ms": round(v["ms"], 4), "dispatches_per_call": v["dispatches"], "wave_valu": int(v["wave_valu"]),
+               "lane_op_frac": round(lane / VALU_PEAK_TOPS, 4), "vgprs": v.get("vgprs"), "lds_bytes_per_workgroup": v.get("lds_bytes")}
+        hit = [m for n, m in by_name.items() if n.split("(")[0].strip() in k]
+        if hit:
+            row["issue_frac"] = round(v["wave_valu"] * hit[0]["cycles_per_instruction"] / (v["ms"] * 1e-3 * 2.4e9 * 1024), 4)
+        rows[k] = row
+    return {"kernels": rows, "sum_ms": round(sum(r["ms"] for r in rows.values()), 4),
+            "source": os.path.relpath(path, ROOT) + " (rocprofv3 --pmc SQ pass: dispatches serialised, durations include the counter readout)"}
 
 
 def issue_block(per_kernel, insts, kernel_ms, cur_sha):
@@ -744,7 +777,7 @@ def main():
                                           "streams; same bytes either way; the time is content dependent: formats[*@baboon_tiled] is the natural-image end") if fmt == "bc7" else None,
                        "device": ("CONTROL-FLOW TEST ON CPU -- not a measurement" if FAKE else itw_amd.device_info()), "lib": itw_amd.version()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "hbm_frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": pmc_traffic(args.workload, cur_sha) if (world == 1 and size == 4096) else None,   # PMC passes were taken at 4096^2
                          "kernel_ms_avg": round(k_avg_ms, 4), "kernel_ms_min": round(k_min_ms, 4),
                          "algorithmic_bytes_per_launch": alg,
@@ -778,6 +811,9 @@ def main():
             # the call is several kernels for BC7; `achieved` uses the whole call.  For the slow / alpha_slow profiles the
             # kernels listed are exactly the call's (the ranked variants <.., 1|2, ..> belong to the faster presets).
             result["roofline"]["rocprof_kernels"] = rk
+        iso = isolated_kernels(args.workload, cur_sha) if at_profile_size else None
+        if iso:
+            result["roofline"].setdefault("rocprof_kernels", {})["isolated"] = iso
         if insts and at_profile_size and valu_sha == cur_sha:
             result["roofline"]["valu"] = valu_block(insts, k_avg_ms)
             result["roofline"]["valu"]["note"] = (
@@ -787,6 +823,13 @@ def main():
             issue = issue_block(per_kernel, insts, k_avg_ms, cur_sha)
             if issue:
                 result["roofline"]["issue"] = issue
+            # the binding roofline as scalars (the driver's record keeps scalar roofline fields only): BC7 / BC6H are VALU-issue bound
+            result["roofline"]["valu_frac"] = result["roofline"]["valu"]["frac"]
+            result["roofline"]["issue_frac"] = issue["frac"] if issue else None
+            if fmt in ("bc7", "bc6h"):
+                result["roofline"]["bound"] = "valu-issue"
+                result["roofline"]["frac_is"] = ("hbm_frac (the contract's field: algorithmic bytes / kernel time / 8 TB/s); the fractions of the roofline "
+                                                 "that binds are valu_frac (lane-ops / 78.6 T) and issue_frac (issue cycles needed / available)")
         else:
             insts = None
 
@@ -864,7 +907,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_formats and size == 4096:
         size, nblocks = size_side, (size_side // 4) ** 2
         side = {}
-        for wl in ("bc1", "bc3", "bc4", "bc5", "bc7_basic", "bc7_slow", "bc7_alpha_slow", "bc6h_fast", "bc6h_slow"):
+        # the presets IntelPlugin.cpp:832-843 selects (veryfast / basic / alpha_veryfast / alpha_basic, BC6H fast / slow) ride along with the slow ones
+        for wl in ("bc1", "bc3", "bc4", "bc5", "bc7_veryfast", "bc7_basic", "bc7_alpha_veryfast", "bc7_alpha_basic", "bc7_slow", "bc7_alpha_slow", "bc6h_fast", "bc6h_slow"):
             if wl == args.workload:
                 continue
             f2, p2 = WORKLOADS[wl]
@@ -1096,6 +1140,7 @@ def main():
         result["cpu_baseline"] = None
 
     if rank == 0:
+        result["abi_calls"] = ABI_CALLS[0]      # encode calls of this process (headline legs; tools/summarize_profiles.py normalises profiler counters by it)
         print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()

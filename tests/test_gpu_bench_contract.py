@@ -31,7 +31,19 @@ def test_one_json_line_with_the_contract_keys(gpu):
     rf = j["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rf, k
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert rf["unit"] == "GB/s" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4 and rf["hbm_frac"] == rf["frac"]
+    assert j["abi_calls"] == 3 + 1 + 1 + 3                    # timed + warm-up steps, then the HIP-event leg's warm-up + launches
+    # The binding roofline as scalars: present whenever the committed counter pass was taken on these kernel sources.
+    # BC7 is VALU-issue bound; `frac` stays the contract's HBM fraction and says so.
+    if rf.get("profile_matches_source", {}).get("valu"):
+        assert rf["bound"] == "valu-issue" and 0 < rf["valu_frac"] <= 1.0 and rf["valu_frac"] == rf["valu"]["frac"] and "frac_is" in rf
+        assert rf["issue_frac"] is None or 0 < rf["issue_frac"] <= 1.05
+        iso = rf["rocprof_kernels"]["isolated"]
+        # serialised per-kernel durations: their sum cannot be below the overlapped call (two bands on two streams)
+        assert iso["sum_ms"] >= rf["kernel_ms_avg"] * 0.97 and all(0 < k["lane_op_frac"] <= 1.0 for k in iso["kernels"].values())
+        assert abs(sum(k["wave_valu"] for k in iso["kernels"].values()) - rf["valu"]["wave_instructions_per_call"]) <= 0.02 * rf["valu"]["wave_instructions_per_call"]
+    else:
+        assert rf["bound"] == "hbm"
     assert rf["algorithmic_bytes_per_launch"] == 80 * (4096 // 4) ** 2
     assert 0 < rf["kernel_ms_avg"] <= j["ms_per_step"] * 1.05                     # the kernels of a step fit inside the step
     if "valu" in rf:

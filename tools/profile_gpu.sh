@@ -25,19 +25,23 @@ find $OUT/trace -name '*kernel_stats*.csv' -exec cp {} $OUT/kernel_stats_all_for
 find $OUT/trace -name '*kernel_trace*.csv' | head -1 | xargs -I{} sh -c "grep -m3 bc13_kernel {} >> $OUT/kernel_trace_head.csv; grep -m3 bc6h_ {} >> $OUT/kernel_trace_head.csv; grep -m3 bc45_ {} >> $OUT/kernel_trace_head.csv"
 rm -rf $OUT/trace
 
-# 2. PMC passes, one counter group per run, short workloads
-for wl in bc1 bc3 bc4 bc5 bc7_slow bc6h_slow; do
+# 2. PMC passes, one counter group per run, short workloads.  The bench line of every pass is kept beside its counter file: its `abi_calls` is
+#    the number of C-ABI calls the counters are divided by (tools/summarize_profiles.py; never inferred from dispatch counts).
+#    The presets the plugin selects (IntelPlugin.cpp:832-843: veryfast / basic / alpha_veryfast / alpha_basic, BC6H fast / slow) are profiled like the slow ones.
+WLS=${ITW_PROFILE_WORKLOADS:-"bc7_slow bc7_alpha_slow bc7_basic bc7_veryfast bc7_alpha_basic bc7_alpha_veryfast bc6h_slow bc6h_fast bc1 bc3 bc4 bc5"}
+for wl in $WLS; do
   steps=3; case $wl in bc1|bc3|bc4|bc5) steps=10;; esac
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${wl}_$ctr -o pmc -- python $ROOT/bench.py --workload $wl --no-formats --no-cpu --steps $steps --warmup 1 > /dev/null 2> $OUT/pmc_${wl}_$ctr.log
+    rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${wl}_$ctr -o pmc -- python $ROOT/bench.py --workload $wl --no-formats --no-cpu --steps $steps --warmup 1 > $OUT/pmc_${wl}_$ctr.json 2> $OUT/pmc_${wl}_$ctr.log
     f=$(find $OUT/pmc_${wl}_$ctr -name '*counter_collection*.csv' | head -1)
-    if [ -n "$f" ]; then head -1 $f > $OUT/pmc_${wl}_$ctr.csv; grep -E "$KERNELS" $f | head -2000 >> $OUT/pmc_${wl}_$ctr.csv; fi
+    if [ -n "$f" ]; then head -1 $f > $OUT/pmc_${wl}_$ctr.csv; grep -E "$KERNELS" $f | head -4000 >> $OUT/pmc_${wl}_$ctr.csv; fi
     rm -rf $OUT/pmc_${wl}_$ctr
   done
 done
-# 3. SQ counters (VALU instruction counts, wave cycles) per workload: the roofline that binds for every format
-for wl in bc7_slow bc7_alpha_slow bc6h_slow bc1 bc3 bc4 bc5; do
-  rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- python $ROOT/bench.py --workload $wl --no-formats --no-cpu --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_sq_$wl.log
+# 3. SQ counters (VALU instruction counts, wave cycles) per workload: the roofline that binds for every format.
+#    A --pmc run serialises the dispatches, so this pass also gives every kernel's ISOLATED duration (bench.py: roofline.rocprof_kernels.isolated).
+for wl in $WLS; do
+  rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $OUT/pmc_sq -o pmc -- python $ROOT/bench.py --workload $wl --no-formats --no-cpu --steps 2 --warmup 1 > $OUT/pmc_sq_$wl.json 2> $OUT/pmc_sq_$wl.log
   f=$(find $OUT/pmc_sq -name '*counter_collection*.csv' | head -1)
   if [ -n "$f" ]; then head -1 $f > $OUT/pmc_sq_$wl.csv; grep -E "$KERNELS" $f | head -6000 >> $OUT/pmc_sq_$wl.csv; fi
   rm -rf $OUT/pmc_sq
