@@ -40,7 +40,7 @@ def test_one_json_line_with_the_contract_keys(gpu):
         assert rf["issue_frac"] is None or 0 < rf["issue_frac"] <= 1.05
         iso = rf["rocprof_kernels"]["isolated"]
         # serialised per-kernel durations: their sum cannot be below the overlapped call (two bands on two streams)
-        assert iso["sum_ms"] >= rf["kernel_ms_avg"] * 0.97 and all(0 < k["lane_op_frac"] <= 1.0 for k in iso["kernels"].values())
+        assert iso["sum_ms"] >= rf["kernel_ms_avg"] * 0.97 and all(0 <= k["lane_op_frac"] <= 1.0 for k in iso["kernels"].values())
         assert abs(sum(k["wave_valu"] for k in iso["kernels"].values()) - rf["valu"]["wave_instructions_per_call"]) <= 0.02 * rf["valu"]["wave_instructions_per_call"]
     else:
         assert rf["bound"] == "hbm"
