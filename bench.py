@@ -102,6 +102,45 @@ def plan(scaling, size, world, rank, fmt, piece=0, pieces=1):
     return {"width": width, "height": height, "y0": y0, "rows": rows, "band_off": off, "band_bytes": nbytes, "total_bytes": total}
 
 
+def pieces_for(size, world, interleave=None):
+    """K of the strong-sharded job: the requested sub-bands per rank (default 4) halved until the block rows divide by K * N and every
+    sub-band keeps 16 block rows (equal sub-bands: the all-gather is in place)."""
+    K = interleave if interleave else 4
+    while K > 1 and ((size // 4) % (K * world) != 0 or (size // 4) // (K * world) < 16):
+        K //= 2
+    return max(1, K)
+
+
+def dry_run_plan(size, world, fmt, interleave=None):
+    """--dry-run-plan N: what `--gpus N` WILL do on the strong-sharded surface, without a GPU -- every rank's sub-bands (texel rows, input
+    bytes, offset and length in the block stream), the K in-place all-gathers with their message sizes, and the C++ job's sends to the
+    owner.  tests/test_sharding_gloo.py checks it against itwBandForPart; the first hardware run can be compared line by line."""
+    from itw_amd import abi
+    K = pieces_for(size, world, interleave)
+    bpb = abi.BYTES_PER_BLOCK[fmt]
+    texel = 8 if fmt == "bc6h" else 4
+    ranks = []
+    for r in range(world):
+        subs = []
+        for k in range(K):
+            g = plan("strong", size, world, r, fmt, k, K)
+            subs.append({"sub_band": k * world + r, "piece": k, "first_texel_row": g["y0"], "texel_rows": g["rows"],
+                         "input_bytes": g["rows"] * size * texel, "out_offset": g["band_off"], "out_bytes": g["band_bytes"]})
+        ranks.append({"rank": r, "device": r, "sub_bands": subs, "texel_rows": sum(x["texel_rows"] for x in subs),
+                      "input_bytes": sum(x["input_bytes"] for x in subs), "out_bytes": sum(x["out_bytes"] for x in subs)})
+    piece_bytes = ranks[0]["sub_bands"][0]["out_bytes"]
+    total = (size // 4) ** 2 * bpb
+    return {"plan": f"{fmt} on ONE {size}x{size} surface, strong-sharded over {world} ranks", "size": size, "ranks": world, "sub_bands_per_rank": K,
+            "bytes_per_block": bpb, "total_out_bytes": total, "per_rank": ranks,
+            "python_job_collectives": [{"group": k, "op": "all_gather_into_tensor (in place)", "send_bytes_per_rank": piece_bytes,
+                                        "recv_bytes_per_rank": piece_bytes * (world - 1), "buffer_offset": k * world * piece_bytes,
+                                        "buffer_bytes": world * piece_bytes, "overlaps": f"encode of piece {k + 1}" if k + 1 < K else "next step's first encode"}
+                                       for k in range(K)],
+            "cpp_job_gather": {"op": "grouped ncclSend / ncclRecv to the rank that owns the output (rank 0)", "groups": K,
+                               "send_bytes_per_rank_per_group": piece_bytes, "owner_recv_bytes_total": total - K * piece_bytes},
+            "xgmi_bytes_per_link_python": piece_bytes * K, "note": "all-gather: every rank sends its K pieces to each of the N-1 peers, one xGMI link per peer"}
+
+
 def make_band(fmt, scaling, size, geo, rank):
     """Texels of this rank's band.  weak: an independent size x size surface per rank.  strong: rows [y0, y0+rows) of
     I5 = the 4096^2 synthetic surface tiled up to size x size -- every rank derives them from the same
@@ -620,7 +659,12 @@ def main():
     ap.add_argument("--host", choices=["auto", "cpp", "python"], default="auto",
                     help="N > 1: who drives the GPUs (see the module docstring); auto = both, C++ job as the headline")
     ap.add_argument("--cpp-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry-run-plan", type=int, default=0, metavar="N", help="print what --gpus N will do on the strong-sharded surface (every rank's "
+                    "sub-bands, offsets, message sizes) as one JSON line and exit; needs no GPU")
     args = ap.parse_args()
+    if args.dry_run_plan:
+        print(json.dumps(dry_run_plan(args.size or 16384, args.dry_run_plan, WORKLOADS[args.workload][0], args.interleave)), flush=True)
+        return
     if args.cpp_worker:
         args.size = args.size or 16384
         args.steps = args.steps if args.steps is not None else 10
@@ -672,11 +716,7 @@ def main():
         place).  The gather of step i runs on RCCL's stream while step i+1 encodes (two whole-image buffers,
         shard.BandPipeline); all gathers are waited for inside the timed region.  Returns (elapsed_s max over ranks, ...)."""
         # the partition: K interleaved sub-bands per rank where the geometry allows (strong scaling only; K = 1: one contiguous band)
-        K = 1
-        if scaling == "strong" and world > 1:
-            K = args.interleave if args.interleave else 4
-            while K > 1 and ((size // 4) % (K * world) != 0 or (size // 4) // (K * world) < 16):
-                K //= 2
+        K = pieces_for(size, world, args.interleave) if (scaling == "strong" and world > 1) else 1
         geos = [plan(scaling, size, world, rank, fmt, k, K) for k in range(K)]
         geo = dict(geos[0])
         imgs = [make_band(fmt, scaling, size, g, rank) for g in geos]
@@ -743,11 +783,22 @@ def main():
     elif geo.get("pieces", 1) > 1:
         k_avg_ms *= geo["pieces"]; k_min_ms *= geo["pieces"]
     per_rank_ms = [round(k_avg_ms, 4)]
+    per_rank_gather_ms = None
     if dist is not None:
-        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        # the gathers of one step on their own (nothing encoding): this rank's K in-place all-gathers, wall clock between synchronisations
+        dist.barrier()
+        _sync()
+        tg = time.perf_counter()
+        for k in range(pipe.pieces):
+            dist.all_gather_into_tensor(pipe.groups[0][k], pipe.piece[0][k])
+        _sync()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        t = torch.zeros(2 * world, dtype=torch.float64, device=dev)
         t[rank] = k_avg_ms
+        t[world + rank] = gather_ms
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        per_rank_ms = [round(float(v), 4) for v in t.tolist()]
+        per_rank_ms = [round(float(v), 4) for v in t[:world].tolist()]
+        per_rank_gather_ms = [round(float(v), 4) for v in t[world:].tolist()]
 
     result = None
     if rank == 0:
@@ -787,6 +838,11 @@ def main():
         if verdict is not None:
             result.update(verdict)
             result["per_rank_kernel_ms"] = per_rank_ms
+            # N > 1: what the first hardware run is read by -- per rank, and how unequal the ranks are
+            result["config"]["per_rank_encode_ms"] = per_rank_ms
+            result["config"]["per_rank_gather_ms"] = per_rank_gather_ms
+            result["config"]["max_over_mean"] = round(max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms)), 4) if min(per_rank_ms) > 0 else None
+            result["config"]["sub_bands_per_rank"] = geo.get("pieces", 1)
             # the same job on ONE GPU, from the latest committed single-GPU run of this geometry: what a strong-scaling ratio of
             # this line should be taken against (the default N = 1 line is BASELINE configs[2], a 4096^2 surface -- another job)
             try:
@@ -893,6 +949,13 @@ def main():
                                                 "to GPU 0 by RCCL ncclSend / grouped ncclRecv on a second stream, a rank's first half-band under its second half's encode")
                 result["config"]["ranks_seen_by_rccl"] = cpp["ranks_seen_by_rccl"]
                 result["config"]["transport"] = cpp["transport"]
+                pr = (cpp.get("stats_last_call") or {}).get("per_rank") or []
+                if pr:                                         # the headline job's own account (device-side HIP events per rank)
+                    enc = [r["encode_ms"] for r in pr]
+                    result["config"]["per_rank_encode_ms"] = enc
+                    result["config"]["per_rank_gather_ms"] = [r["gather_ms"] for r in pr]
+                    result["config"]["max_over_mean"] = round(max(enc) / (sum(enc) / len(enc)), 4) if min(enc) > 0 else None
+                    result["config"]["sub_bands_per_rank"] = cpp.get("sub_bands_per_rank")
                 result["timing"] = ("C++ job: K synchronous itwCompressImageMultiGPUEx calls (every rank stream drained before a call returns) between two "
                                     "all-device synchronisations, wall clock of the one process that drives all N GPUs; python_side: barrier + "
                                     "synchronize on both sides, MAX over ranks")

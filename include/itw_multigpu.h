@@ -76,20 +76,21 @@ typedef struct itw_multigpu_stats {
     int32_t ranks, devices, peer_links, rccl_ranks;
     int32_t watchdog_fired;              /* 1 = a rank did not finish posting its work in time and the call was aborted */
     int32_t resident_bands;              /* 1 = the texels were already on the ranks' devices (no scatter) */
-    int32_t interleave;                  /* K the call used (1 = one contiguous band per rank) */
     float   wall_ms;                     /* host wall clock of the whole call */
     float   posted_ms;                   /* host wall clock until every rank had posted all its work (launch + enqueue cost) */
     char    transport[8];
     char    transport_note[96];
     itw_multigpu_rank_stats rank[64];
+    /* fields added after round 4 are appended, so the offsets above never move: */
+    int32_t interleave;                  /* K the call used (1 = one contiguous band per rank) */
 } itw_multigpu_stats;
 
 /* The same call with two optional extras.
- *   resident_bands  NULL, or an array of K * ranks surfaces, K = itwMultiGpuPieces(height, ranks, ..): sub-band j of the image (block
- *                   rows itwBandForPart(j, K * ranks)), already resident on the device rank j % ranks runs on (device
- *                   (j % ranks) % device_count) -- the tile-sharded input of a pipeline that produced the texels where they are
- *                   encoded (K = 1: `ranks` surfaces, band r on rank r's device).  No scatter happens; `input` then only
- *                   carries width / height (its ptr may be NULL).  ranks must be given explicitly (> 0).
+ *   resident_bands  NULL, or an array of `ranks` surfaces: band r of the image (block rows itwBandForPart(r, ranks)), already resident on
+ *                   the device rank r runs on (device r % device_count) -- the tile-sharded input of a pipeline that produced the texels
+ *                   where they are encoded.  No scatter happens; `input` then only carries width / height (its ptr may be NULL); ranks
+ *                   must be given explicitly (> 0).  A call with resident bands always uses ONE band per rank (K = 1), whatever
+ *                   itwMultiGpuSetInterleave says: the array's length is the caller's word, and this entry point's word is `ranks`.
  *   stats           NULL, or where to leave the call's account (filled on failure too, as far as the call got).
  * Watchdog: a rank that has not posted all its work (launches, copies, ncclSend / ncclGroupEnd) within
  * ITW_MULTIGPU_POST_TIMEOUT_S (default 30) -- the first RCCL call of a process sets up its peer connections inside those
@@ -97,6 +98,13 @@ typedef struct itw_multigpu_stats {
  * as a failing rank (ncclCommAbort on every communicator); the call fails with "watchdog" in the message. */
 bool itwCompressImageMultiGPUEx(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks,
                                 const rgba_surface* resident_bands, itw_multigpu_stats* stats);
+
+/* Resident input cut into K interleaved sub-bands per rank: `resident_bands` holds n_resident_bands = K * ranks surfaces (K = 1 .. 8),
+ * sub-band j = block rows itwBandForPart(j, K * ranks) resident on the device of rank j % ranks.  K is stated by THIS call through the
+ * array's length -- it is validated (a multiple of `ranks`, at most 8 per rank, no more sub-bands than block rows; `ranks` itself at most
+ * 64 and at most the number of block rows) and never taken from process-wide state.  Everything else as itwCompressImageMultiGPUEx. */
+bool itwCompressImageMultiGPUBands(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks,
+                                   const rgba_surface* resident_bands, int n_resident_bands, itw_multigpu_stats* stats);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

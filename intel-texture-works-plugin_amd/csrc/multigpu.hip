@@ -586,8 +586,10 @@ bool prepare_rccl(int ranks)
     return true;
 }
 
+// n_bands: how many surfaces `bands` holds -- K * ranks for K sub-bands per rank, stated by the caller per call (the library cannot see
+// the array's length); 0 = the round-4 contract: `ranks` surfaces, band r on rank r (K = 1), whatever the process-wide interleave is.
 bool compress_multi(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks,
-                    const rgba_surface* bands, itw_multigpu_stats* stats)
+                    const rgba_surface* bands, int n_bands, itw_multigpu_stats* stats)
 {
     bool ok = false;
     itwClearError();
@@ -609,7 +611,17 @@ bool compress_multi(const rgba_surface* input, uint8_t* output, CompressionFunc*
         if (bands && n > by) itw::fail_msg("itwCompressImageMultiGPUEx: %d resident bands for %d block rows", n, by);
         n = n > by ? by : n;
         k.ranks = n;
-        k.interleave = effective_interleave(by, n, requested_interleave());
+        if (bands) {
+            // resident input: K comes with the call, never from process-wide state another thread may change between the caller's
+            // itwMultiGpuPieces() and this call
+            k.interleave = 1;
+            if (n_bands > 0) {
+                if (n != ranks) itw::fail_msg("itwCompressImageMultiGPUBands: %d ranks asked for, %d usable (at most %d, and one block row each)", ranks, n, MAX_RANKS);
+                if (n_bands % n != 0 || n_bands / n > MAX_PIECES) itw::fail_msg("itwCompressImageMultiGPUBands: %d resident sub-bands for %d ranks (K = 1..%d per rank)", n_bands, n, MAX_PIECES);
+                if (n_bands > by) itw::fail_msg("itwCompressImageMultiGPUBands: %d resident sub-bands for %d block rows", n_bands, by);
+                k.interleave = n_bands / n;
+            }
+        } else k.interleave = effective_interleave(by, n, requested_interleave());
         ensure_ranks(n);
         k.src_device = bands ? -1 : device_of(input->ptr); k.src_dev = k.src_device >= 0;
         k.dst_device = device_of(output);     k.dst_dev = k.dst_device >= 0;
@@ -709,6 +721,7 @@ int itwMultiGpuPieces(int32_t height, int ranks, int keep_partial_blocks)
 {
     const int by = keep_partial_blocks ? (height + 3) / 4 : height / 4;
     if (ranks <= 0 || by <= 0) return 0;
+    if (ranks > MAX_RANKS) ranks = MAX_RANKS;                  // exactly compress_multi's clamps
     return effective_interleave(by, ranks > by ? by : ranks, requested_interleave());
 }
 
@@ -732,13 +745,24 @@ void itwMultiGpuTestInjectFailure(int rank, int stage, int stall_ms)
 
 bool itwCompressImageMultiGPU(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks)
 {
-    return compress_multi(input, output, cmpFunc, dxgi_format, ranks, nullptr, nullptr);
+    return compress_multi(input, output, cmpFunc, dxgi_format, ranks, nullptr, 0, nullptr);
 }
 
 bool itwCompressImageMultiGPUEx(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks,
                                 const rgba_surface* resident_bands, itw_multigpu_stats* stats)
 {
-    return compress_multi(input, output, cmpFunc, dxgi_format, ranks, resident_bands, stats);
+    return compress_multi(input, output, cmpFunc, dxgi_format, ranks, resident_bands, 0, stats);
+}
+
+bool itwCompressImageMultiGPUBands(const rgba_surface* input, uint8_t* output, CompressionFunc* cmpFunc, int dxgi_format, int ranks,
+                                   const rgba_surface* resident_bands, int n_resident_bands, itw_multigpu_stats* stats)
+{
+    if (!resident_bands || n_resident_bands <= 0) {
+        itwClearError();
+        itw::guarded([&] { itw::fail_msg("itwCompressImageMultiGPUBands: no resident sub-bands (use itwCompressImageMultiGPUEx for a surface in one piece)"); });
+        return false;
+    }
+    return compress_multi(input, output, cmpFunc, dxgi_format, ranks, resident_bands, n_resident_bands, stats);
 }
 
 } // extern "C"

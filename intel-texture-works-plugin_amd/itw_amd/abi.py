@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = tuple(
     + ["itwCompressImageSliced", "itwCompressImageSlicedEx", "itwSetSliceWindow", "itwSliceWindow", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
        "itwConvertToRGBA8Device", "itwConvertToRGBA16FDevice"]
     # include/itw_multigpu.h: one surface over all GPUs, one process
-    + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU", "itwCompressImageMultiGPUEx",
+    + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU", "itwCompressImageMultiGPUEx", "itwCompressImageMultiGPUBands",
        "itwMultiGpuSetInterleave", "itwMultiGpuPieces"]
     # include/itw_bc45.h: the DirectXTex formats of the plugin
     + ["CompressBlocksBC4", "CompressBlocksBC5", "itwWarmupBC45"]
@@ -79,8 +79,9 @@ class MultiGpuRankStats(C.Structure):
 class MultiGpuStats(C.Structure):
     """struct itw_multigpu_stats (itw_multigpu.h)."""
     _fields_ = [("ranks", C.c_int32), ("devices", C.c_int32), ("peer_links", C.c_int32), ("rccl_ranks", C.c_int32),
-                ("watchdog_fired", C.c_int32), ("resident_bands", C.c_int32), ("interleave", C.c_int32), ("wall_ms", C.c_float), ("posted_ms", C.c_float),
-                ("transport", C.c_char * 8), ("transport_note", C.c_char * 96), ("rank", MultiGpuRankStats * 64)]
+                ("watchdog_fired", C.c_int32), ("resident_bands", C.c_int32), ("wall_ms", C.c_float), ("posted_ms", C.c_float),
+                ("transport", C.c_char * 8), ("transport_note", C.c_char * 96), ("rank", MultiGpuRankStats * 64),
+                ("interleave", C.c_int32)]          # appended after round 4: the offsets above never move
 
     def as_dict(self):
         n = max(0, min(int(self.ranks), 64))
@@ -199,6 +200,9 @@ def _load(path, hooks):
         L.itwCompressImageMultiGPUEx.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(RgbaSurface),
                                                  C.POINTER(MultiGpuStats)]
         L.itwCompressImageMultiGPUEx.restype = C.c_bool
+        L.itwCompressImageMultiGPUBands.argtypes = [C.POINTER(RgbaSurface), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(RgbaSurface), C.c_int,
+                                                    C.POINTER(MultiGpuStats)]
+        L.itwCompressImageMultiGPUBands.restype = C.c_bool
         L.itwPadToMultipleOf4.argtypes = [C.POINTER(RgbaSurface), C.c_int]
         L.itwPadToMultipleOf4.restype = RgbaSurface
         L.itwFreeSurface.argtypes = [C.POINTER(RgbaSurface)]
@@ -437,9 +441,11 @@ def multigpu_sub_bands(fmt, width, height, ranks, L=None):
 def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None, bands=None, stats=None, L=None, interleave=None):
     """itwCompressImageMultiGPU[Ex]: img is a host numpy array or a CUDA torch tensor (H, W, 4); the block stream comes back in
     the same kind of container (or in `out`, which may be the other kind).  Synchronous.
-    bands: optional list of CUDA tensors: K * ranks sub-bands (K = itwMultiGpuPieces; sub-band j = block rows itwBandForPart(j, K * ranks),
-    resident on the device of rank j % ranks: multigpu_sub_bands() cuts a surface that way), no scatter; `img` may then be a
-    (height, width) tuple.  interleave: sets K for the process first (1 = the reference's contiguous bands).  stats: an optional MultiGpuStats to fill (stats.as_dict()).  L: the library instance (default: the product;
+    bands: optional list of CUDA tensors, K * ranks of them (K = 1..8, stated by the list's length): sub-band j = block rows
+    itwBandForPart(j, K * ranks), resident on the device of rank j % ranks (multigpu_sub_bands() cuts a surface the way a call WITHOUT
+    resident bands would); no scatter; `img` may then be a (height, width) tuple; goes through itwCompressImageMultiGPUBands, or -- K = 1 --
+    through itwCompressImageMultiGPUEx.  interleave: sets K of calls without resident bands for the process first (1 = the reference's
+    contiguous bands).  stats: an optional MultiGpuStats to fill (stats.as_dict()).  L: the library instance (default: the product;
     the failure-injection tests pass test_lib(), whose hook arms that instance)."""
     import numpy as np
     L = L or lib()
@@ -450,8 +456,7 @@ def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None, bands=Non
         h, w = (img if isinstance(img, tuple) else img.shape[:2])
         if not ranks:
             ranks = len(bands)                           # (K = 1: one surface per rank)
-        pieces = L.itwMultiGpuPieces(h, ranks, 1 if fmt in KEEPS_PARTIAL_BLOCKS else 0)
-        assert len(bands) == pieces * ranks, f"{len(bands)} resident surfaces for {ranks} ranks x {pieces} sub-bands"
+        assert len(bands) % ranks == 0, f"{len(bands)} resident surfaces for {ranks} ranks"
         for b in bands:
             assert b.is_cuda and b.dim() == 3 and b.shape[2] == 4 and b.stride(2) == 1 and b.stride(1) == 4 and b.shape[1] == w
             torch.cuda.synchronize(b.device)
@@ -478,6 +483,9 @@ def compress_image_multigpu(fmt, img, profile=None, ranks=0, out=None, bands=Non
     surf = RgbaSurface(src_ptr, w, h, stride)
     if bands is None and stats is None:
         ok = L.itwCompressImageMultiGPU(C.byref(surf), dst_ptr, image_func(fmt, profile, L), DXGI_FORMAT[fmt], ranks)
+    elif bands is not None and len(bands) != ranks:
+        ok = L.itwCompressImageMultiGPUBands(C.byref(surf), dst_ptr, image_func(fmt, profile, L), DXGI_FORMAT[fmt], ranks, arr, len(bands),
+                                             C.byref(stats) if stats is not None else None)
     else:
         ok = L.itwCompressImageMultiGPUEx(C.byref(surf), dst_ptr, image_func(fmt, profile, L), DXGI_FORMAT[fmt], ranks, arr,
                                           C.byref(stats) if stats is not None else None)

@@ -188,3 +188,21 @@ print("survived")
 """ % os.path.join(ROOT, "intel-texture-works-plugin_amd")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "survived" not in r.stdout and "no CPU fallback" in r.stderr
+
+
+def test_multigpu_stats_layout_is_append_only(itw, tmp_path):
+    """itw_multigpu_stats (itw_multigpu.h): the binding's layout is the header's, and the fields a round-4 caller read (wall_ms,
+    posted_ms, transport, rank[]) sit where they sat before `interleave` was added -- new fields are appended."""
+    import subprocess
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "itw_multigpu.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(itw_multigpu_stats), offsetof(itw_multigpu_stats, resident_bands), '
+                   'offsetof(itw_multigpu_stats, wall_ms), offsetof(itw_multigpu_stats, posted_ms), offsetof(itw_multigpu_stats, transport), '
+                   'offsetof(itw_multigpu_stats, rank), offsetof(itw_multigpu_stats, interleave)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    S = itw.MultiGpuStats
+    assert got == [C.sizeof(S), S.resident_bands.offset, S.wall_ms.offset, S.posted_ms.offset, S.transport.offset, S.rank.offset, S.interleave.offset]
+    assert S.wall_ms.offset == 24 and S.posted_ms.offset == 28 and S.transport.offset == 32 and S.rank.offset == 136      # the round-4 offsets
+    assert S.interleave.offset == 136 + 64 * 32

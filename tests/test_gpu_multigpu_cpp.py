@@ -200,6 +200,47 @@ def test_resident_bands_need_no_scatter(itw, gpu, oracle, fmt, prof, h, w, ranks
     assert first_mismatch(host_out, want, itw.BYTES_PER_BLOCK[fmt]) is None
 
 
+def test_resident_bands_take_K_from_the_call_not_from_the_process(itw, gpu, oracle):
+    """a caller written against the round-4 contract passes `ranks` surfaces (band r on rank r) to
+    itwCompressImageMultiGPUEx; the process-wide interleave (default 4, and 4 applies to this geometry for calls WITHOUT resident
+    bands) must not make the library read K * ranks entries.  K > 1 with resident input is opted into per call through
+    itwCompressImageMultiGPUBands, whose sub-band count is validated."""
+    import ctypes as C
+    import torch
+    h, w, ranks = 512, 64, 2                                   # 128 block rows: K = 4 for a call without resident bands
+    img = _img("bc1", h, w)
+    want = oracle.encode("bc1", img).reshape(-1)
+    L = itw.lib()
+    L.itwMultiGpuSetInterleave(4)
+    assert L.itwMultiGpuPieces(h, ranks, 0) == 4
+    n_dev = _device_count()
+    two = [torch.from_numpy(np.ascontiguousarray(img[r * 256:(r + 1) * 256])).to(f"cuda:{r % n_dev}") for r in range(ranks)]
+    st = itw.MultiGpuStats()
+    out = itw.compress_image_multigpu("bc1", (h, w), ranks=ranks, bands=two, stats=st)          # len(bands) == ranks -> the Ex entry
+    torch.cuda.synchronize()
+    assert first_mismatch(out.cpu().numpy(), want, 8) is None and st.as_dict()["interleave"] == 1
+    eight = [torch.from_numpy(np.ascontiguousarray(img[j * 64:(j + 1) * 64])).to(f"cuda:{(j % ranks) % n_dev}") for j in range(8)]
+    out = itw.compress_image_multigpu("bc1", (h, w), ranks=ranks, bands=eight, stats=st)        # K = 4, stated by the call
+    torch.cuda.synchronize()
+    assert first_mismatch(out.cpu().numpy(), want, 8) is None and st.as_dict()["interleave"] == 4
+    # K = 2 although the process asks for 4: the call's word counts
+    four = [torch.from_numpy(np.ascontiguousarray(img[j * 128:(j + 1) * 128])).to(f"cuda:{(j % ranks) % n_dev}") for j in range(4)]
+    out = itw.compress_image_multigpu("bc1", (h, w), ranks=ranks, bands=four, stats=st)
+    torch.cuda.synchronize()
+    assert first_mismatch(out.cpu().numpy(), want, 8) is None and st.as_dict()["interleave"] == 2
+    # a sub-band count the library cannot accept is refused before anything is read
+    itw.set_error_mode(itw.ON_ERROR_RETURN)
+    try:
+        surf = itw.RgbaSurface(None, w, h, w * 4)
+        arr = (itw.RgbaSurface * 18)(*[itw.RgbaSurface(eight[0].data_ptr(), w, 64, w * 4)] * 18)
+        dst = torch.empty(want.size, dtype=torch.uint8, device=gpu)
+        for n_bands, what in ((3, "3 resident sub-bands for 2 ranks"), (18, "18 resident sub-bands for 2 ranks"), (0, "no resident sub-bands")):
+            assert not L.itwCompressImageMultiGPUBands(C.byref(surf), dst.data_ptr(), itw.image_func("bc1"), 71, ranks, arr, n_bands, None)
+            assert what in L.itwLastError().decode()
+    finally:
+        itw.set_error_mode(itw.ON_ERROR_ABORT)
+
+
 def test_a_band_on_the_wrong_device_or_of_the_wrong_size_fails_in_prepare(itw, gpu):
     import torch
     img = _img("bc1", 64, 64)

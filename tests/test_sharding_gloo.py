@@ -258,6 +258,10 @@ def test_bench_n_gt_1_control_flow_runs_end_to_end_on_cpu():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["steps"] == 2 and j["config"]["ranks_seen_by_rccl"] == 2
     assert "512x512" in j["config"]["workload"] and j["weak_side"]["steps"] >= 3 and j["value"] > 0
+    # what the first hardware run is read by: per-rank encode and gather times, their imbalance, K
+    c = j["config"]
+    assert len(c["per_rank_encode_ms"]) == 2 and len(c["per_rank_gather_ms"]) == 2 and all(v > 0 for v in c["per_rank_gather_ms"])
+    assert c["max_over_mean"] >= 1.0 and c["sub_bands_per_rank"] in (1, 2, 4) and "rccl_version" in c
     assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]          # only rank 0 prints
 
 
@@ -337,3 +341,39 @@ def test_sub_band_geometry_is_the_band_rule_on_k_times_n_parts():
             assert (y0, rows, off, nbytes) == shard.band_of(w, h, fmt, piece * world + r, k * world)
             seen.append((y0, rows))
     assert sorted(seen) == [(64 * j, 64) for j in range(16)]
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dry_run_plan_is_the_band_rule_and_tiles_the_stream(world):
+    """`bench.py --dry-run-plan N`: every rank's sub-bands, offsets and message sizes for the 16384^2 surface, without a
+    GPU.  Each sub-band must be itwBandForPart(j, K * N)'s, the sub-bands must tile the block stream exactly once, and the collectives'
+    buffers must be the K groups of N equal pieces the in-place all-gather needs."""
+    import json
+    import subprocess
+    import itw_amd
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-plan", str(world)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    K, size = j["sub_bands_per_rank"], j["size"]
+    assert size == 16384 and j["ranks"] == world and K == 4 and j["total_out_bytes"] == (size // 4) ** 2 * 16
+    covered = []
+    for rk in j["per_rank"]:
+        assert len(rk["sub_bands"]) == K and rk["device"] == rk["rank"]
+        for sb in rk["sub_bands"]:
+            assert sb["sub_band"] % world == rk["rank"] and sb["sub_band"] // world == sb["piece"]
+            y0, rows, off = itw_amd.band_for_part(size, size, "bc7", sb["sub_band"], K * world)
+            assert (sb["first_texel_row"], sb["texel_rows"], sb["out_offset"]) == (y0, rows, off)
+            assert sb["out_bytes"] == (rows // 4) * (size // 4) * 16 and sb["input_bytes"] == rows * size * 4
+            covered.append((sb["out_offset"], sb["out_bytes"]))
+        assert rk["out_bytes"] * world == j["total_out_bytes"]                    # equal load in bytes
+    covered.sort()
+    assert covered[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(covered, covered[1:])) and sum(c[1] for c in covered) == j["total_out_bytes"]
+    piece = j["per_rank"][0]["sub_bands"][0]["out_bytes"]
+    for k, c in enumerate(j["python_job_collectives"]):
+        assert c["group"] == k and c["send_bytes_per_rank"] == piece and c["buffer_offset"] == k * world * piece and c["buffer_bytes"] == world * piece
+        # group k's buffer is exactly sub-bands k*N .. k*N+N-1, in rank order: the in-place all-gather's layout
+        for rk in j["per_rank"]:
+            assert rk["sub_bands"][k]["out_offset"] == c["buffer_offset"] + rk["rank"] * piece
+    assert j["cpp_job_gather"]["owner_recv_bytes_total"] == j["total_out_bytes"] - K * piece
