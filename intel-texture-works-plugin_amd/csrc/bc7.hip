@@ -1833,7 +1833,12 @@ bc7_wide_phase1(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_
 // SINGLES = false: the refine tasks (modes 0,2,1,3,7; need phase 1).  SINGLES = true: the single-subset tasks (mode 4/5
 // candidates, mode 6), which depend on nothing and run on a second stream beside phase 1 when the caller provides one.
 template <bool VEC16, bool SINGLES>
-__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// SINGLES (one mode 4/5 candidate group or mode 6 per wave, nothing else live): 168 VGPRs hold it with 10 cold spills, and 44 KiB of LDS let
+// three workgroups share a CU: 3 waves per SIMD run modes 4/5 of a call 14 % faster than 2 (profiles/r06_modes45_mapping_probe.txt)
+#ifndef WIDE_SINGLES_WAVES
+#define WIDE_SINGLES_WAVES 3
+#endif
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(SINGLES ? WIDE_SINGLES_WAVES : 2, SINGLES ? WIDE_SINGLES_WAVES : 2)))
 bc7_wide_phase2(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, const uint4* __restrict__ wins,
                 int32_t* __restrict__ cerr, uint4* __restrict__ cblk, const bc7_enc_settings S, const WideModes modes, const int pstride)
 {

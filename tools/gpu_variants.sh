@@ -8,6 +8,6 @@ cp $L /tmp/orig.so
 for v in orig $(ls gpurun_variants | sed 's/lib_//;s/\.so//'); do
   if [ $v = orig ]; then cp /tmp/orig.so $L; else cp gpurun_variants/lib_$v.so $L; fi
   echo "== $v"
-  timeout 300 python tools/profile_table.py 2>&1 | grep -E "^bc7 +(basic|slow|alpha_slow|fast) "
+  timeout 900 ${VARIANT_CMD:-python tools/variant_table.py ${VARIANT_FILTER:-}} 2>&1 | grep -E "${VARIANT_GREP:- ms }"
 done | tee gpurun_out/variants/table.txt
 cp /tmp/orig.so $L
