@@ -514,13 +514,21 @@ bc13_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
     }
 }
 
-// Persistent workgroups: at most 2048 (two per resident slot at 4 waves per SIMD), each walking chunks of 256 blocks (measured
-// round 3, tools/gpu_probe_bc1.sh: 1024 / 1536 / 2048 workgroups 29.4 / 28.7 / 28.9 us BC1 and 32.8 / 30.9 / 31.1 us BC3 at 4096^2).
-constexpr int64_t BC13_GRID = 2048;
+// Persistent workgroups, each walking chunks of 256 blocks.  How many: 1 024 are resident at once (4 waves per SIMD); fewer, longer-lived
+// workgroups stage the 9 KiB table image less often, more of them balance the tail better.  Round 6 sweep (tools/bc13_timing.py over
+// tools/build_variant.sh builds, profiles/r06_bc13_grid_sweep.txt; us per launch BC1 / BC3):
+//     workgroups     1024          2048 (round 3-5)   3072          6144          8192          one per chunk
+//     4096^2         29.3 / 33.0   28.1-28.6 / 31.4-31.5   27.8 / 30.4   27.7 / 30.7   28.5 / 30.8   28.2-28.4 / 30.8
+//     16384^2        393 / 461     378-380 / 439-441       375 / 437     371 / 428     370 / 432     387 / 442
+// -> 3 072 up to 8 192 chunks (a 4096^2 surface has 4 096), 6 144 above: 0.340 / 0.345 of the HBM peak at 4096^2, 0.407 / 0.392 at 16384^2.
+#ifndef BC13_GRID_WGS
+#define BC13_GRID_WGS 0                       // 0 = the rule above; a number fixes the bound (tools/build_variant.sh sweeps)
+#endif
 static unsigned bc13_grid(int64_t n)
 {
     const int64_t chunks = (n + 255) / 256;
-    return (unsigned)(chunks < BC13_GRID ? chunks : BC13_GRID);
+    const int64_t bound = BC13_GRID_WGS > 0 ? (int64_t)BC13_GRID_WGS : (chunks <= 8192 ? 3072 : 6144);
+    return (unsigned)(chunks < bound ? chunks : bound);
 }
 
 // SMALL: positive stride and every texel row below 2 GiB from the base (16384^2 RGBA8 is 1 GiB): 32-bit offsets.  The output offset is
