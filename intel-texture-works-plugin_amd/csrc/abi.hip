@@ -290,6 +290,7 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
 }
 
 bool coalesce_small_call(const Job& j, const rgba_surface* src, uint8_t* dst, int64_t blocks);
+bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user, int fixed_window = 0);
 
 // texel rows of a host surface into the tight staging image
 void upload_rows(uint8_t* d_rows, size_t pitch, const uint8_t* hs, int64_t stride, size_t row_bytes, size_t nrows, hipStream_t copy)
@@ -329,6 +330,21 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     }
     // small host-pointer calls made concurrently by several host threads are joined into one (below)
     if (may_coalesce && !src_dev && !dst_dev && coalesce_small_call(j, src, dst, (int64_t)bx * by)) return;
+
+    // Round 6: a large BC6H call, and a large BC7 call of a profile without an order verdict (everything but `slow`), takes the WINDOW pipeline
+    // of the slice loop (compress_sliced below) with no callback: windows of ~131 072 blocks alternate between two kernel streams with the
+    // neighbours' copies on the third -- measured against the runs below at 4096^2: BC6H `slow` 4.81 -> 4.36 ms, BC7 `alpha_basic` 3.31 -> 3.11,
+    // `alpha_veryfast` 2.46 -> 2.26, `basic` 3.93 -> 3.86 (profiles/r06a_sliced_timing.jsonl).  The tuning knobs of the runs keep the runs.
+    if (!src_dev && !dst_dev && !keep_partial && !std::getenv("ITW_HOST_CHUNKS") && !std::getenv("ITW_HOST_RUNS") && !std::getenv("ITW_HOST_WINDOWS_OFF")) {
+        const int64_t blocks = (int64_t)bx * by;
+        const bool bc7w = j.fmt == Fmt::BC7 && blocks >= 524288 && !itw::bc7_has_order_verdict(*j.s7) && itw::bc7_staged_bands_ok();
+        const bool bc6w = j.fmt == Fmt::BC6H && blocks >= 262144 && j.s6->slow_mode;    // (the other BC6H profiles are PCIe-bound: 2.98 vs 3.02 ms, fewer copies win)
+        if (bc7w || bc6w) {
+            int64_t windows = (blocks + 65536) / 131072;
+            if (windows > by) windows = by;
+            if (windows >= 2) { (void)compress_sliced(j, src, dst, (int)windows, nullptr, nullptr, 1); return; }
+        }
+    }
 
     ensure_device_ctx();
     hipStream_t st = tls.own_stream, cs = tls.copy_stream;
@@ -541,9 +557,9 @@ SliceRows slice_rows(int i, int slices, int height, bool keep_partial)
 }
 
 // returns true when every slice was encoded, false when `progress` stopped the job
-bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user)
+// `fixed_window` > 0 fixes W (compress() passes 1: its "slices" are the windows).
+bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user, int fixed_window)
 {
-    itw::clear_failure();
     if (!src) itw::fail_msg("null surface");
     const int w = src->width, h = src->height;
     const bool keep_partial = (j.fmt == Fmt::BC4 || j.fmt == Fmt::BC5);
@@ -563,7 +579,7 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
     const size_t out_bytes = (size_t)bx * by * bpb;
     const bool src_dev = is_device_pointer(src->ptr), dst_dev = is_device_pointer(dst);
 
-    const int W = slice_window(j.fmt, (int64_t)bx * by / slices, slices);
+    const int W = fixed_window > 0 ? (fixed_window < slices ? fixed_window : slices) : slice_window(j.fmt, (int64_t)bx * by / slices, slices);
     const int nwin = (slices + W - 1) / W;
 
     ensure_device_ctx();
@@ -924,6 +940,7 @@ bool itwCompressImageSlicedEx(const rgba_surface* source, uint8_t* target, int64
                               int64_t slice_pixels, ItwProgressFunc* progress, void* user)
 {
     bool done = false;
+    itw::clear_failure();
     const bool ok = itw::guarded([&] {
         if (!source) itw::fail_msg("null surface");
         Job j;
