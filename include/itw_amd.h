@@ -59,13 +59,16 @@ const char* itwDeviceInfo(void);
 enum { ITW_BC7_PATH_AUTO = 0, ITW_BC7_PATH_DEEP = 1, ITW_BC7_PATH_WIDE = 2 };
 void itwSetBc7Path(int path);
 
-/* Tuning / test knob of the BC7 `slow` profile's mode order on whole surfaces (csrc/bc7.hip): the library runs modes 1/3 last and only
- * for the blocks an exact lower bound cannot exclude ("bounded order"), which pays on content where few blocks need them and costs 4-6 %
- * where nearly all do.  A pilot -- 1/16 of the surface, spread over it, encoded first on a second stream -- decides per call, on the
- * device: `percent` = the share of the pilot's blocks that may still need modes 1/3 for the rest of the surface to take the bounded
- * order (default 90; env ITW_BC7_PILOT_THR presets it); 0 = the rest always takes the reference's order, 100 = always the bounded
- * order, -1 = no pilot (the whole call in the bounded order), any value below -1 = back to the preset (the environment's, else 90).  The
- * emitted bytes are the same whatever the value. */
+/* Tuning / test knob of the BC7 `slow` profile's mode order on whole surfaces (csrc/bc7.hip): the library can run modes 1/3 last and only
+ * for the blocks an exact lower bound cannot exclude ("bounded order"), which pays on content where few blocks need them and costs a few
+ * percent where nearly all do.  A pilot decides per call, on the device: behind the first band's {0,2} scan -- common to both orders -- an
+ * estimate kernel (bc7_pilot_estimate) evaluates the bound against the scan's winners on 1/16 of the surface (every eighth chunk of that
+ * band) and leaves a device word; both continuations of each band are enqueued behind it, each launch gated on that word, and the one not
+ * chosen returns at once (no host round trip).  `percent` = the share of the sampled blocks the estimate may list for modes 1/3 for the
+ * call to take the bounded order (default 90; env ITW_BC7_PILOT_THR presets it).  0 = the reference's order unless the estimate lists no
+ * block at all (then the bounded order, which skips modes 1/3 everywhere), 100 = always the bounded order, -1 = no pilot (the whole call in
+ * the bounded order, ungated), any value below -1 = back to the preset (the environment's, else 90).  The emitted bytes are the same
+ * whatever the value. */
 void itwSetBc7Pilot(int percent);
 
 /* Library build identification: arithmetic model and arch, e.g.

@@ -108,9 +108,10 @@ struct ThreadCtx {
     void*  d_ws = nullptr;  size_t ws_cap = 0;      // BC7 inter-family workspace
     hipStream_t ws_stream = nullptr; bool ws_used = false;
     hipEvent_t  ws_event = nullptr;                 // recorded after each BC7 call: orders the workspace across streams
-    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr, false, nullptr, false};
-    itw::Bc7Verdict verdict = {nullptr, nullptr, false};
-    bool staged_wide = false;                       // what the last staged BC7 call's estimate said (used when this call's is not in yet)  // second stream + fork/join events for the parallel parts of small BC7 calls
+    itw::Bc7Aux aux = {nullptr, nullptr, nullptr, 0, nullptr, false, nullptr, false};   // second stream + fork / join / mid events: the parallel parts of small
+                                                    // BC7 calls, the second band of large ones, the second kernel stream of the window pipeline
+    itw::Bc7Verdict verdict = {nullptr, nullptr, false, nullptr};   // the pilot's estimate of a staged host-pointer call's first run, left for the host (kernels.hpp)
+    bool staged_wide = false;                       // what the last staged BC7 call's estimate said (the shape of this call's first run, until its own is in)
     int    device = -1;
     char   info[256] = {0};
     ~ThreadCtx() {
@@ -128,6 +129,7 @@ struct ThreadCtx {
         if (aux.join) (void)hipEventDestroy(aux.join);
         if (aux.mid) (void)hipEventDestroy(aux.mid);
         if (verdict.event) (void)hipEventDestroy(verdict.event);
+        if (verdict.host_counts) (void)hipHostFree((void*)verdict.host_counts);
     }
 };
 thread_local ThreadCtx tls;
@@ -152,6 +154,7 @@ void bind_thread_to_current_device()
     if (tls.aux.join) { (void)hipEventDestroy(tls.aux.join); tls.aux.join = nullptr; }
     if (tls.aux.mid) { (void)hipEventDestroy(tls.aux.mid); tls.aux.mid = nullptr; }
     if (tls.verdict.event) { (void)hipEventDestroy(tls.verdict.event); tls.verdict.event = nullptr; }
+    if (tls.verdict.host_counts) { (void)hipHostFree((void*)tls.verdict.host_counts); tls.verdict.host_counts = nullptr; tls.verdict.host_counts_dev = nullptr; }
     tls.device = dev;
 }
 
@@ -189,12 +192,12 @@ struct Job {
 // of stream makes the new stream wait for a library-owned event recorded behind the previous call (never for the
 // caller's old stream handle, which may have been destroyed since -- ADVICE r01); calls on one stream are ordered by
 // the stream itself.  Growing the workspace frees it first, and hipFree waits for the device.
-float* bc7_workspace(int w, int h, hipStream_t st, int64_t wide_max_blocks = 0)
+float* bc7_workspace(int w, int h, hipStream_t st, int64_t wide_max_blocks, const bc7_enc_settings* settings)
 {
     bind_thread_to_current_device();
     if (!tls.ws_event) ITW_CHECK(hipEventCreateWithFlags(&tls.ws_event, hipEventDisableTiming));
     if (tls.ws_used && tls.ws_stream != st) ITW_CHECK(hipStreamWaitEvent(st, tls.ws_event, 0));
-    float* ws = (float*)grow(tls.d_ws, tls.ws_cap, itw::bc7_workspace_bytes(w, h, wide_max_blocks));
+    float* ws = (float*)grow(tls.d_ws, tls.ws_cap, itw::bc7_workspace_bytes(w, h, wide_max_blocks, settings));
     tls.ws_stream = st; tls.ws_used = true;
     return ws;
 }
@@ -237,6 +240,13 @@ void ensure_bc7_aux()
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.join, hipEventDisableTiming));
     ITW_CHECK(hipEventCreateWithFlags(&tls.aux.mid, hipEventDisableTiming));
     ITW_CHECK(hipEventCreateWithFlags(&tls.verdict.event, hipEventDisableTiming));
+    // two pinned, device-visible words the pilot's estimate kernel writes for the host (no copy, no stream: ADVICE r05)
+    void* h = nullptr;
+    ITW_CHECK(hipHostMalloc(&h, 2 * sizeof(int32_t), hipHostMallocMapped));
+    void* d = nullptr;
+    ITW_CHECK(hipHostGetDevicePointer(&d, h, 0));
+    tls.verdict.host_counts = static_cast<volatile int32_t*>(h);
+    tls.verdict.host_counts_dev = static_cast<int32_t*>(d);
 }
 
 // `band` >= 0: a staged run of a host-pointer BC7 call that compress() overlaps with its neighbours on two streams; it runs in the deep
@@ -262,7 +272,7 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
                 if (tls.aux.verdict) tls.verdict.valid = false;
                 itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(static_cast<uint8_t*>(tls.d_ws) + ws_off), st, &tls.aux);
             } else {
-                float* ws = bc7_workspace(w, h, st, tls.aux.wide_max_blocks);         // (sized and ordered already when ws_off != 0)
+                float* ws = bc7_workspace(w, h, st, tls.aux.wide_max_blocks, j.s7);         // (sized and ordered already when ws_off != 0)
                 itw::launch_bc7(d_src, stride, w, h, d_dst, *j.s7, reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(ws) + ws_off), st, &tls.aux);
                 ITW_CHECK(hipEventRecord(tls.ws_event, st));
             }
@@ -403,15 +413,15 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         for (int c = 0; c < nch; c++) {
             const int run_rows = (cut[c + 1] - cut[c]) * 4;
             if (run_rows <= 0) continue;
-            const size_t b = (itw::bc7_workspace_bytes(w, run_rows, staged_wide_max_blocks()) + 255) & ~(size_t)255;
+            const size_t b = (itw::bc7_workspace_bytes(w, run_rows, staged_wide_max_blocks(), j.s7) + 255) & ~(size_t)255;
             if (b > total) total = b;
         }
         probe_off = total;
-        total += (itw::bc7_workspace_bytes(w, (cut[1] - cut[0]) * 4, 1) + 255) & ~(size_t)255;
+        total += (itw::bc7_workspace_bytes(w, (cut[1] - cut[0]) * 4, 1, j.s7) + 255) & ~(size_t)255;
         for (int c = 0; c < nch; c++) {
             band_off[c] = total;
             const int run_rows = (cut[c + 1] - cut[c]) * 4;
-            if (run_rows > 0) total += (itw::bc7_workspace_bytes(w, run_rows, 1) + 255) & ~(size_t)255;
+            if (run_rows > 0) total += (itw::bc7_workspace_bytes(w, run_rows, 1, j.s7) + 255) & ~(size_t)255;
         }
         reserve_workspace(total, st);
         ITW_CHECK(hipEventRecord(tls.aux.fork, st));          // the other streams start behind whatever ordered the workspace on the first
@@ -426,23 +436,32 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         for (int c = 0; c < nch; c++) {
             const int run_rows = (cut[c + 1] - cut[c]) * 4;
             if (run_rows <= 0) continue;
-            const size_t b = (j.fmt == Fmt::BC7) ? itw::bc7_workspace_bytes(w, run_rows, wide_max) : itw::bc6h_workspace_bytes(w, run_rows, *j.s6);
+            const size_t b = (j.fmt == Fmt::BC7) ? itw::bc7_workspace_bytes(w, run_rows, wide_max, j.s7) : itw::bc6h_workspace_bytes(w, run_rows, *j.s6);
             if (b > need) need = b;
         }
         if (need) reserve_workspace(need, st);
     }
+    // A failure below is a C++ exception (and under ITW_ON_ERROR_RETURN the thread lives on): whatever this call has queued by then on the
+    // thread's streams is drained and the workspace's event recorded, so the next call finds d_in / d_out / d_ws free of work in flight.
+    struct Unwind {
+        bool done; hipStream_t a, b, c;
+        ~Unwind() {
+            if (done) return;
+            (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
+            if (c) (void)hipStreamSynchronize(c);
+            if (tls.ws_event && tls.ws_used) (void)hipEventRecord(tls.ws_event, a);
+            (void)hipGetLastError();
+        }
+    } unwind{false, st, cs, tls.aux.stream};
     hipStream_t copy = (nch > 1) ? cs : st;
     bool shape_wide = bands && tls.staged_wide && itw::bc7_has_order_verdict(*j.s7);   // the shape of the next run (profiles without a verdict: bands)
     bool verdict_pending = false;
     auto poll_verdict = [&](bool wait) {                      // this call's estimate, if it is in (or, `wait`: now that everything is done)
         if (!verdict_pending || !tls.verdict.valid) return;
         if (!wait && hipEventQuery(tls.verdict.event) != hipSuccess) { (void)hipGetLastError(); return; }
-        int32_t counts[2] = {0, 0};
         if (wait) ITW_CHECK(hipEventSynchronize(tls.verdict.event));
-        // a synchronous 8-byte copy: the event has fired, and the library's streams are non-blocking, so the null stream waits for nothing
-        // (not the copy stream: it has this call's downloads queued behind kernels; and no stream of its own: a process has four hardware
-        // queues, a fifth stream shares one with a neighbour and serialises with it -- measured: +0.8 ms per call)
-        ITW_CHECK(hipMemcpy(counts, tls.verdict.counts, sizeof counts, hipMemcpyDeviceToHost));
+        // the event has fired: the estimate kernel's last workgroup wrote the two counts into this thread's pinned words before it ended
+        const int32_t counts[2] = {tls.verdict.host_counts[0], tls.verdict.host_counts[1]};
         if (counts[1] > 0) tls.staged_wide = (int64_t)counts[0] * 100 > (int64_t)staged_verdict_percent() * counts[1];
         verdict_pending = false;
     };
@@ -495,6 +514,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         ITW_CHECK(hipEventRecord(tls.ws_event, st));
     }
     ITW_CHECK(hipStreamSynchronize(st));
+    unwind.done = true;
     if (bands) poll_verdict(true);                            // for the next call, if it was not in before
 }
 
@@ -602,7 +622,7 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
             const int64_t r = slice_rows(s1 - 1, slices, h, false).y1 - slice_rows(k * W, slices, h, false).y0;
             if (r > tallest) tallest = r;
         }
-        const size_t b = (itw::bc7_workspace_bytes(w, (int)tallest, 1) + 255) & ~(size_t)255;
+        const size_t b = (itw::bc7_workspace_bytes(w, (int)tallest, 1, j.s7) + 255) & ~(size_t)255;
         ws_off[1] = b;
         reserve_workspace(2 * b, k0);
     }

@@ -1680,7 +1680,7 @@ template <bool VEC16>
 __global__ void __launch_bounds__(TPB)
 bc7_pilot_estimate(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, const uint32_t* __restrict__ wins4,
                    const int skip_mode2, const ChunkSel sel, int32_t* __restrict__ counters /* listed, sampled, done */, const int32_t thr256,
-                   int32_t* __restrict__ flag)
+                   int32_t* __restrict__ flag, int32_t* __restrict__ host_counts /* optional: pinned host memory, {listed, sampled} for the host */)
 {
     const int32_t chunk = sel_chunk(sel, (int32_t)blockIdx.x * 8 + 3);
     if (chunk * TPB < nblocks) {                                     // workgroup-uniform
@@ -1713,6 +1713,7 @@ bc7_pilot_estimate(const uint8_t* __restrict__ src, int64_t stride, int32_t bloc
             __threadfence();
             const int64_t listed = atomicAdd(counters + 0, 0), sampled = atomicAdd(counters + 1, 0);
             *flag = (listed * 256 <= (int64_t)thr256 * sampled) ? 1 : 0;
+            if (host_counts) { host_counts[0] = (int32_t)listed; host_counts[1] = (int32_t)sampled; __threadfence_system(); }
         }
     }
 }
@@ -2083,14 +2084,32 @@ static size_t wide_workspace_bytes(size_t n)
 // (rows 2, 3 used: list_scan_parts x listed <= cap), the listed blocks' texels [cap] x 64 B in list order
 struct ListRegion { size_t list, wins, compact, cap; };
 struct FusedLayout { size_t inc, list0, list1, list2, counts, words; ListRegion band[2]; };
-static FusedLayout fused_layout(size_t n)
+// Which regions a call's settings can touch (a `basic` call was sized like a `slow` one, 124 B per block instead of 36):
+//   lists    the three block lists of the RGBA profiles' alpha-first order (and list13 of an RGB bounded call that runs as one band);
+//   bands    the per-band lists and share winners of the bounded order (modes 1/3, mode 7 scanned over lists);
+//   compact  the listed blocks' texels in list order (the RGB bounded order only).
+struct FusedNeeds { bool lists, bands, compact; };
+static FusedNeeds fused_needs(const bc7_enc_settings* s)
+{
+    if (!s) return FusedNeeds{true, true, true};                  // unknown settings: everything
+    bc7_enc_settings S = *s;
+    S.channels = (s->channels == 4) ? 4 : 3;
+    auto ranked = [](int t) { return t > 0 && t < 64; };
+    const bool on02 = S.mode_selection[0];
+    const bool on13 = S.mode_selection[1] && (S.fastSkipTreshold_mode1 > 0 || S.fastSkipTreshold_mode3 > 0);
+    const bool r13 = on13 && (ranked(S.fastSkipTreshold_mode1) || ranked(S.fastSkipTreshold_mode3));
+    const bool bounded = bc7_bounded_order() && on02 && on13 && !r13;
+    const bool alpha = bc7_alpha_first(S);
+    return FusedNeeds{alpha || bounded, bounded, bounded && !alpha && bc7_compact_lists()};
+}
+static FusedLayout fused_layout(size_t n, const FusedNeeds& need)
 {
     auto up4 = [](size_t w) { return (w + 3) & ~(size_t)3; };
     const size_t nchunks = (n + TPB - 1) / TPB;
     FusedLayout W;
     size_t o = up4(5 * n);                                         // 5 winner rows
     W.inc = o;      o = up4(o + n);                                // a phase's error / incumbent
-    const size_t lcap = 2 * (nchunks / 2 + 65) * TPB;              // three block lists (RGBA profiles), each with room for two bands' shares
+    const size_t lcap = need.lists ? 2 * (nchunks / 2 + 65) * TPB : 0;   // three block lists (RGBA profiles), each with room for two bands' shares
     W.list0 = o;    o = up4(o + lcap);
     W.list1 = o;    o = up4(o + lcap);
     W.list2 = o;    o = up4(o + lcap);
@@ -2098,19 +2117,19 @@ static FusedLayout fused_layout(size_t n)
     for (int k = 0; k < 2; k++) {                                  // the two bands: lists and share winners ...
         ListRegion& r = W.band[k];
         r.cap = (nchunks / 2 + 65) * TPB;                          // (a band is whole stripes of up to 64 chunks)
-        r.list = o;    o = up4(o + r.cap);
-        r.wins = o;    o = up4(o + 5 * r.cap);
+        r.list = o;    o = up4(o + (need.bands ? r.cap : 0));
+        r.wins = o;    o = up4(o + (need.bands ? 5 * r.cap : 0));
     }
-    W.band[0].compact = o; o += 16 * W.band[0].cap;                // ... and their texels, contiguous: a call without bands uses both as one
-    W.band[1].compact = o; o += 16 * W.band[1].cap;
+    W.band[0].compact = o; o += need.compact ? 16 * W.band[0].cap : 0;   // ... and their texels, contiguous: a call without bands uses both as one
+    W.band[1].compact = o; o += need.compact ? 16 * W.band[1].cap : 0;
     W.words = o;
     return W;
 }
-size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks)
+size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks, const bc7_enc_settings* settings)
 {
     const size_t n = (size_t)(width / 4) * (size_t)(height / 4);
     size_t deep = ((n * sizeof(int32_t) + 15) & ~(size_t)15) + 2 * n * sizeof(uint4);
-    const size_t fused = fused_layout(n).words * sizeof(uint32_t);
+    const size_t fused = fused_layout(n, fused_needs(settings)).words * sizeof(uint32_t);
     if (fused > deep) deep = fused;
     const size_t limit = bc7_path_override() == 2 ? ((size_t)1 << 20) : (wide_max_blocks > 0 ? (size_t)wide_max_blocks : (size_t)ITW_BC7_WIDE_MAX_BLOCKS);
     const bool may_wide = bc7_path_override() != 1 && n <= limit && n <= ((size_t)1 << 20);
@@ -2261,7 +2280,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
             // alternate on every CU: instruction cache), 256 chunks 5.36 ms / 76 MB, 1024 chunks 5.38 ms / 166 MB (L2 no longer
             // holds the first family's texels), family-major 5.39 ms / 154 MB; two separate launches 5.45 ms.
             const int a13 = r13 ? 1 : 0, a7 = r7 ? 1 : 0;
-            const FusedLayout W = fused_layout((size_t)n);
+            const FusedLayout W = fused_layout((size_t)n, fused_needs(&S));
             int32_t* alpha_err = reinterpret_cast<int32_t*>(wins4 + W.inc);                    // [n] x 4 B behind the winner rows: a phase's error / incumbent
             int32_t* rgb_list = reinterpret_cast<int32_t*>(wins4 + W.list0);                   // [n] block ids (RGBA profiles: where an RGB mode can win; RGB: where modes 1/3 can)
             int32_t* list13 = reinterpret_cast<int32_t*>(wins4 + W.list1);                     // [n] block ids (RGBA profiles, bounded order)
@@ -2426,10 +2445,10 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                         // a staged run of a host-pointer call (abi.hip): the same estimate, left for the HOST to read under the next
                         // run's upload -- it picks the launch shape of the remaining runs
                         const dim3 grid((unsigned)((B.cnt + 7) / 8));
-                        if (L.vec) hipLaunchKernelGGL((bc7_pilot_estimate<true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S.skip_mode2 ? 1 : 0, B.sel, pilot_ctr, 256, pilot_flag);
-                        else       hipLaunchKernelGGL((bc7_pilot_estimate<false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S.skip_mode2 ? 1 : 0, B.sel, pilot_ctr, 256, pilot_flag);
+                        if (L.vec) hipLaunchKernelGGL((bc7_pilot_estimate<true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S.skip_mode2 ? 1 : 0, B.sel, pilot_ctr, 256, pilot_flag, aux->verdict->host_counts_dev);
+                        else       hipLaunchKernelGGL((bc7_pilot_estimate<false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S.skip_mode2 ? 1 : 0, B.sel, pilot_ctr, 256, pilot_flag, aux->verdict->host_counts_dev);
                         ITW_CHECK(hipEventRecord(aux->verdict->event, st));
-                        aux->verdict->counts = pilot_ctr; aux->verdict->valid = true;
+                        aux->verdict->valid = true;
                     }
                     if (probe) return;
                     tail(B);
@@ -2441,8 +2460,8 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                     head(Bb); head(A);
                     if (pilot) {
                         const dim3 grid((unsigned)((A.cnt + 7) / 8));
-                        if (L.vec) hipLaunchKernelGGL((bc7_pilot_estimate<true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S.skip_mode2 ? 1 : 0, A.sel, pilot_ctr, bc7_pilot_threshold(), pilot_flag);
-                        else       hipLaunchKernelGGL((bc7_pilot_estimate<false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S.skip_mode2 ? 1 : 0, A.sel, pilot_ctr, bc7_pilot_threshold(), pilot_flag);
+                        if (L.vec) hipLaunchKernelGGL((bc7_pilot_estimate<true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S.skip_mode2 ? 1 : 0, A.sel, pilot_ctr, bc7_pilot_threshold(), pilot_flag, (int32_t*)nullptr);
+                        else       hipLaunchKernelGGL((bc7_pilot_estimate<false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, wins4, S.skip_mode2 ? 1 : 0, A.sel, pilot_ctr, bc7_pilot_threshold(), pilot_flag, (int32_t*)nullptr);
                         ITW_CHECK(hipEventRecord(aux->mid, st));
                         ITW_CHECK(hipStreamWaitEvent(s2, aux->mid, 0));        // band 1's continuations start behind the verdict
                     }

@@ -3,7 +3,9 @@
 // :291-366 ConvertToBC6From8/16/32Bit; helpers IntelPlugin.h:31-96).  One pixel per lane, 1-16 B in, 4 / 8 B out:
 // a stream, HBM bound.
 //   8 -> 8  : copy                                   16 -> 8 : v > 32768 ? 255 : (v*255) >> 15   (= FloatToByte(v/32768.0))
-//   32 -> 8 : FloatToByte(pow(v, 1/2.2)) in double   (pow is not bit-pinned across platforms: +-1 code vs the CPU)
+//   32 -> 8 : FloatToByte(v) in double; with gamma FloatToByte(pow(v, 1/2.2)) -- evaluated as "how many of the 255 code thresholds are <= v"
+//             (gamma_thresholds.h: the thresholds of the reference's own function compiled in the build container), eight comparisons, no
+//             pow: bit-exact with that function, where a device-library pow was +-1 code
 //   8 -> 16F: half(v / 255.f)    16 -> 16F: half((float)(v / 32768.0))    32 -> 16F: half(v)   (round to nearest even)
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -11,8 +13,19 @@
 #include <cstdlib>
 #include "../../include/itw_dispatch.h"
 #include "../../include/itw_amd.h"
+#include "gamma_thresholds.h"
 
 namespace {
+
+__device__ const uint32_t GAMMA_THR[256] = {
+#define ITW_T(i) itw::GAMMA_THR_BITS[i]
+#define ITW_T8(i) ITW_T(i), ITW_T(i + 1), ITW_T(i + 2), ITW_T(i + 3), ITW_T(i + 4), ITW_T(i + 5), ITW_T(i + 6), ITW_T(i + 7)
+#define ITW_T64(i) ITW_T8(i), ITW_T8(i + 8), ITW_T8(i + 16), ITW_T8(i + 24), ITW_T8(i + 32), ITW_T8(i + 40), ITW_T8(i + 48), ITW_T8(i + 56)
+    ITW_T64(0), ITW_T64(64), ITW_T64(128), ITW_T64(192)
+#undef ITW_T64
+#undef ITW_T8
+#undef ITW_T
+};
 
 __device__ __forceinline__ uint32_t float_to_byte(double v)                 // IntelPlugin.h:41-48
 {
@@ -31,9 +44,17 @@ __device__ __forceinline__ uint32_t to8(const void* src, int64_t idx, bool gamma
 {
     if (DEPTH == 8) return ((const uint8_t*)src)[idx];
     if (DEPTH == 16) { const uint32_t v = ((const uint16_t*)src)[idx]; return v > 32768u ? 255u : (v * 255u) >> 15; }
-    double v = (double)((const float*)src)[idx];
-    if (gamma) v = pow(v, 1 / 2.2);
-    return float_to_byte(v);
+    const float f = ((const float*)src)[idx];
+    if (gamma) {
+        // ConvertTo8Bit(v, true) is non-decreasing in v: its value is the number of code thresholds <= v.  NaN and negative v compare below
+        // every threshold -> 0, like (unsigned char)(NaN * 255) of the reference's x86 code; v > 1 passes all 255.
+        uint32_t lo = 0;
+#pragma unroll
+        for (uint32_t step = 128; step >= 1; step >>= 1)
+            if (f >= __uint_as_float(GAMMA_THR[lo + step])) lo += step;           // lo + step <= 255
+        return lo;
+    }
+    return float_to_byte((double)f);
 }
 
 template <int DEPTH>

@@ -19,7 +19,9 @@ void copy_bc45_index_table(uint32_t* host_out, hipStream_t st);   // test hook: 
 // BC7 runs as up to seven kernels (search + finish per multi-subset mode family, one for modes 4/5/6) that hand
 // "best error so far" and the search winners to each other through
 // `workspace`: device memory, bc7_workspace_bytes(width, height) bytes, 16 B aligned, contents irrelevant on entry.
-size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks = 0);   // wide_max_blocks as in Bc7Aux
+// `settings` (optional): size for what a call with these settings can touch -- the lists, band regions and compact texel copy belong to the
+// alpha-first and bounded mode orders (36 B per block without them, ~124 with); nullptr sizes for any settings.
+size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks = 0, const bc7_enc_settings* settings = nullptr);   // wide_max_blocks as in Bc7Aux
 // BC7 launch shape: 0 = by call size (default), 1 = deep (one lane per block, a launch pair per mode family: fills the
 // chip on whole surfaces), 2 = wide (split scans + ordered argmin: small calls).  Same blocks either way.
 void set_bc7_path(int path);
@@ -33,11 +35,12 @@ void set_bc7_pilot(int percent);
 // `mid` (may be null: no pilot): a third event, for the pilot of the bounded mode order (bc7.hip).  `single`: the call is one band of a
 // larger job whose bands the CALLER overlaps on two streams (the staged runs of a host-pointer call, abi.hip): deep shape whatever the
 // size, everything on `st`, no pilot, no inner bands.
-// `verdict` (optional, `single` calls): where a call that runs the bounded order leaves the pilot's estimate for the HOST -- `counts` =
-// {blocks some two-subset shape can still improve, blocks looked at} in device memory, complete once `event` (recorded behind the kernel
-// that counts) has fired.  The caller of the first staged run polls it under the upload of the next run and picks the launch shape of the
-// remaining runs (abi.hip).
-struct Bc7Verdict { hipEvent_t event; const int32_t* counts; bool valid; };
+// `verdict` (optional, `single` calls): where a call that runs the bounded order leaves the pilot's estimate for the HOST -- {blocks some
+// two-subset shape can still improve, blocks looked at}, written by the estimate kernel's last workgroup straight into PINNED HOST memory
+// (`host_counts_dev` = the device-side address of the caller's two pinned words, `host_counts` = their host address), complete once `event`
+// (recorded behind that kernel) has fired: the host reads two words, no copy on any stream.  The caller of the first staged run polls it
+// under the upload of the next run and picks the launch shape of the remaining runs (abi.hip).
+struct Bc7Verdict { hipEvent_t event; volatile int32_t* host_counts; bool valid; int32_t* host_counts_dev; };
 // `probe` (with `single` and `verdict`): only the pilot's estimate is computed -- the {0,2} scan of every eighth chunk and the count -- nothing
 // is encoded (a staged call whose runs take the wide shape keeps its verdict fresh this way).
 struct Bc7Aux { hipStream_t stream; hipEvent_t fork, join; int64_t wide_max_blocks; hipEvent_t mid; bool single; Bc7Verdict* verdict; bool probe; };   // wide_max_blocks: 0 = the library default

@@ -368,9 +368,16 @@ void run_rank(RankCtx& c, const Call& k)
     if (idle) { c.posted_ms.store(ms_since(g.t0)); c.stage.store(2); return; }
 
     // ---- TRANSFER + ENCODE ----
-    // Posting order: upload 0, encode 0 | upload s on the transfer stream (runs under encode s-1), encode s | ... | the gathers on the
-    // transfer stream (gather s runs under encode s+1).  The gathers are posted last because a download into pageable host memory
-    // blocks the posting thread until the copy is done: posted earlier it would hold back the next encode's launch.
+    // Posting order (host side): upload 0, encode 0 | upload s on the transfer stream, encode s | ... | then every gather on the transfer stream,
+    // gather s behind encode s's event.  What overlaps ON THE DEVICE:
+    //   * the encodes are launches (asynchronous: posting all of them takes well under a millisecond against tens of milliseconds of work), so
+    //     with device-side destinations every gather is queued long before its encode ends and gather s runs under encode s+1;
+    //   * the transfer stream is ONE stream: gather 0 sits behind upload K-1 in it.  Uploads from pageable host memory are done when their call
+    //     returns (they block the posting thread, which is why encode s is not launched before upload s is in), peer-copy uploads from another
+    //     GPU finish under encode 0..s-1 -- either way no gather waits for an upload that is still needed by a later encode;
+    //   * a download into pageable host memory blocks the posting thread until the copy is done: posted between the encodes it would hold back
+    //     the next launch, hence "gathers last".  With host memory on both sides the K pieces cost K blocking uploads + K blocking downloads;
+    //     each still overlaps its neighbour's encode on the device.
     try {
         itwSetStream(c.enc);
         uint8_t* o[MAX_PIECES] = {nullptr};

@@ -7,8 +7,10 @@
  * denormals for everything a half can hold -- restated below.  What it returns above 65504 differs between DirectXMath
  * releases (0x7FFF in the 2012-2015 ones, +-inf later); this restatement saturates to +-inf like the hardware conversion
  * and the fixtures' generator, and the parity tests stay inside the finite range ("parity unpinned" beyond it).
- * The 32-bit -> 8-bit path applies pow(v, 1/2.2) in double precision: the C library's pow is not bit-pinned across
- * platforms, so that path is compared with a +-1 code tolerance.
+ * The 32-bit -> 8-bit path applies pow(v, 1/2.2) in double precision with the C library's pow -- the same call the reference's own
+ * ConvertTo8Bit makes where it is compiled here (tests/test_reference_pins.py).  The kernel does not call pow: it counts the code thresholds
+ * of that function (csrc/gamma_thresholds.h, tools/gen_gamma_thresholds.py) and is compared bit for bit.  (On another platform's C library the
+ * thresholds could sit one float further: the pin is "the reference's function under this image's libm".)
  */
 #include <math.h>
 #include <stdint.h>

@@ -12,6 +12,7 @@ kernel.ispc itself is covered by tests/test_reference_kernel_source.py (built as
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -242,3 +243,13 @@ def test_prepass_oracle_equals_the_reference_scalar_conversions(oracle):
         assert np.array_equal(via_oracle8(src, 32, gamma), np.array([L.ref_convert8_from32(float(v), gamma) for v in src], np.uint8)), gamma
     fin = f[np.abs(f) <= 65504.0]                                       # beyond: DirectXMath releases disagree (oracle/prepass.c header)
     assert np.array_equal(via_oracle16(fin, 32), np.array([L.ref_convert16_from32(float(v)) for v in fin], np.uint16))
+
+
+def test_committed_gamma_thresholds_are_what_the_reference_function_gives_now():
+    """csrc/gamma_thresholds.h is generated from the reference's own ConvertTo8Bit(double, true) compiled where it lies
+    (tools/gen_gamma_thresholds.py); where that build exists the committed table must be what the generator produces."""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libintelplugin_convert_ref.so")):
+        pytest.skip("oracle/_ref not built here")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_gamma_thresholds.py"), "--check"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, "csrc/gamma_thresholds.h differs from what tools/gen_gamma_thresholds.py generates: " + r.stderr[-500:]
