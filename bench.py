@@ -404,7 +404,7 @@ def issue_block(per_kernel, insts, kernel_ms, cur_sha):
             "model_matches_source": model.get("_source_sha256") == cur_sha,
             "unit": "SIMD issue cycles per C-ABI call (1 024 SIMDs x 2.4 GHz nominal; a wave64 VALU instruction holds its SIMD for 2, 4 or 8 cycles)",
             "note": "1 - frac = issue slots the call leaves empty (dependency stalls, s_nop, LDS / memory waits, launch ramp and tail) -- at the "
-                    "NOMINAL clock: measured shader clocks under these kernels (s_memtime against the 100 MHz clock, profiles/r04_clock_probe.txt) "
+                    "NOMINAL clock: measured shader clocks under these kernels (s_memtime against the 100 MHz clock, profiles/history/r05/r04_clock_probe.txt) "
                     "are 2.31 GHz in the BC7 scans and 2.04 GHz in the BC1 / BC3 kernels, i.e. frac / 0.96 and frac / 0.85 of the cycles the chip really had"}
 
 

@@ -46,8 +46,9 @@ __device__ __forceinline__ uint32_t to8(const void* src, int64_t idx, bool gamma
     if (DEPTH == 16) { const uint32_t v = ((const uint16_t*)src)[idx]; return v > 32768u ? 255u : (v * 255u) >> 15; }
     const float f = ((const float*)src)[idx];
     if (gamma) {
-        // ConvertTo8Bit(v, true) is non-decreasing in v: its value is the number of code thresholds <= v.  NaN and negative v compare below
+        // ConvertTo8Bit(v, true) is non-decreasing in v: its value is the number of code thresholds <= v.  NaN and negative finite v compare below
         // every threshold -> 0, like (unsigned char)(NaN * 255) of the reference's x86 code; v > 1 passes all 255.
+        if (f == -__builtin_inff()) return 255u;      // pow(-inf, y > 0, not an odd integer) = +inf (C99 F.9.4.4): the one negative input above 1
         uint32_t lo = 0;
 #pragma unroll
         for (uint32_t step = 128; step >= 1; step >>= 1)

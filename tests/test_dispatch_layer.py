@@ -81,8 +81,11 @@ PLUGIN_TRAMPOLINES = [("bc1", None), ("bc3", None), ("bc7", "veryfast"), ("bc7",
                       ("bc6h", "fast"), ("bc6h", "slow"), ("bc7", "slow"), ("bc7", "alpha_slow"), ("bc4", None), ("bc5", None)]
 
 
-def _slice_bounds(i, slices, h):
-    return (i * h // slices) & ~3
+def _default_window_rule():
+    """False when the environment presets the window (tools/gpu_env_matrix.sh runs this file under ITW_SLICE_WINDOW / ITW_SLICED_PIPELINE):
+    the asserts on the DEFAULT rule's values are then skipped; bytes and progress calls must hold either way."""
+    import os
+    return "ITW_SLICE_WINDOW" not in os.environ and os.environ.get("ITW_SLICED_PIPELINE", "1") != "0"
 
 
 @pytest.fixture
@@ -107,7 +110,8 @@ def test_sliced_pipeline_every_plugin_trampoline_vs_oracle(itw, gpu, oracle, res
         img = hdr if fmt == "bc6h" else (odd if fmt in ("bc4", "bc5") else ldr)
         h, w = img.shape[:2]
         slice_pixels = w * h // 64
-        assert itw.lib().itwSliceWindow(itw.DXGI_FORMAT[fmt], w, h, slice_pixels) == (8 if fmt in ("bc7", "bc6h") else 16)
+        if _default_window_rule():
+            assert itw.lib().itwSliceWindow(itw.DXGI_FORMAT[fmt], w, h, slice_pixels) == (8 if fmt in ("bc7", "bc6h") else 16)
         want = oracle.encode(fmt, img, prof).reshape(-1)
         calls = []
         src = torch.from_numpy(img.view(np.int16) if fmt == "bc6h" else img).to(gpu) if resident else img
@@ -138,7 +142,10 @@ def test_sliced_pipeline_abort_contract(itw, gpu, oracle, k, slice_window):
     for W in (0, 1):                                          # default (8 slices per window here) and the reference's granularity
         slice_window(W)
         win = itw.lib().itwSliceWindow(98, 256, 512, 2048)
-        assert win == (8 if W == 0 else 1)
+        if W == 1 or _default_window_rule():
+            assert win == (8 if W == 0 else 1)
+        if win == 0:                                          # ITW_SLICED_PIPELINE=0: the literal loop -- the reference's granularity
+            win = 1
         for resident in (False, True):
             calls = []
             src = torch.from_numpy(img).to(gpu) if resident else img

@@ -1,8 +1,8 @@
 """Round 5: BC7 `slow` (and `alpha_slow`) at 4096^2 by content and by mode-order policy, device resident (HIP events) and through host
-pointers (wall clock of the synchronous call).  One process per environment setting (the knobs are read once): tools/round5/gpu_r05a.sh.
+pointers (wall clock of the synchronous call).  One process per environment setting (the knobs are read once): tools/evidence.sh.
   argv: list of content names (default: I3 I2 baboon test_a)"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "intel-texture-works-plugin_amd"))
 import numpy as np, torch
 import itw_amd

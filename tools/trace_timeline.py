@@ -1,5 +1,5 @@
 """Timeline of the last BC7 call in a rocprofv3 --kernel-trace CSV: every kernel's queue, grid, start and end relative to the call's first
-kernel.  usage: python tools/round5/trace_timeline.py <kernel_trace.csv> [anchor kernel substring, default bc7_pilot_decide]"""
+kernel.  usage: python tools/trace_timeline.py <kernel_trace.csv> [anchor kernel substring, default bc7_pilot_decide]"""
 import csv, re, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "bc7" in r["Kernel_Name"]]
 anchor = sys.argv[2] if len(sys.argv) > 2 else "bc7_pilot_decide"
