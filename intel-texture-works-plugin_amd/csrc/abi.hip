@@ -347,7 +347,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     // `alpha_veryfast` 2.46 -> 2.26, `basic` 3.93 -> 3.86 (profiles/r06a_sliced_timing.jsonl).  The tuning knobs of the runs keep the runs.
     if (!src_dev && !dst_dev && !keep_partial && !std::getenv("ITW_HOST_CHUNKS") && !std::getenv("ITW_HOST_RUNS") && !std::getenv("ITW_HOST_WINDOWS_OFF")) {
         const int64_t blocks = (int64_t)bx * by;
-        const bool bc7w = j.fmt == Fmt::BC7 && blocks >= 524288 && !itw::bc7_has_order_verdict(*j.s7) && itw::bc7_staged_bands_ok();
+        const bool bc7w = j.fmt == Fmt::BC7 && blocks >= 524288 && !itw::bc7_has_order_verdict(*j.s7) && itw::bc7_staged_bands_ok();   // (`slow` keeps its runs: their host-side verdict picks the wide shape on photographs, 7.4 vs 8.6 ms as windows)
         const bool bc6w = j.fmt == Fmt::BC6H && blocks >= 262144 && j.s6->slow_mode;    // (the other BC6H profiles are PCIe-bound: 2.98 vs 3.02 ms, fewer copies win)
         if (bc7w || bc6w) {
             int64_t windows = (blocks + 65536) / 131072;
@@ -671,13 +671,16 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
         ITW_CHECK(hipMemcpyAsync(dst + off, d_dst + off, len, hipMemcpyDeviceToHost, cs));
         ITW_CHECK(hipStreamSynchronize(cs));
     };
-    for (int k = 0; k <= nwin; k++) {
-        if (k < nwin) issue(k);
-        if (k > 0) {
-            retire(k - 1);
-            const Window v = window(k - 1);
-            if (!poll(v.s0 + 1, v.s1)) return false;     // window k (if any) is in flight: ~Drain waits for it, its bytes are not copied back
-        }
+    // Two windows AHEAD of the one being retired are issued: when window k-1's kernels end, window k is running on the other stream and window
+    // k+1 -- same stream as k-1, behind it in stream order -- already has its texels on the device.  (With one window of lookahead the upload of
+    // k+1 only started after k-1 had been retired, and for its 0.16 ms the chip ran window k alone: `basic` 3.86 -> 3.5 ms per 4096^2 call.)
+    static const int depth = [] { const char* e = std::getenv("ITW_SLICE_LOOKAHEAD"); const int v = e ? std::atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
+    for (int k = 0; k < depth && k < nwin; k++) issue(k);
+    for (int k = 0; k < nwin; k++) {
+        if (k + depth < nwin) issue(k + depth);
+        retire(k);
+        const Window v = window(k);
+        if (!poll(v.s0 + 1, v.s1)) return false;         // the windows behind k are in flight: ~Drain waits for them, their bytes are not copied back
     }
     return true;
 }
