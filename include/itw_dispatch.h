@@ -80,15 +80,18 @@ void CompressImageBC6H_veryslow(const rgba_surface* input, uint8_t* output);
  * DDS image's rowPitch); slice_pixels <= 0 selects the reference's 0x40000.
  *
  * The reference encodes slice i between progress(i) and progress(i+1), one synchronous CompressImageMT/ST call each.  Here, when
- * `cmpFunc` is one of THIS library's CompressImage* trampolines and one GPU serves the call, the slices run as a PIPELINE instead:
+ * `cmpFunc` is one of THIS library's CompressImage* trampolines, the slices run as a PIPELINE instead:
  * W consecutive slices form a window (upload, kernels and download of neighbouring windows overlap on three streams; W =
  * itwSliceWindow(...), at most slices/8 -- slices/4 for BC1/BC3/BC4/BC5 -- so a progress bar keeps real steps), and progress(i) is called once slice i-1 -- and
  * every slice before it -- is in `target`.  What a caller can observe of the difference:
  *   * when progress(i) returns false, slices < i are written like in the reference, and so may be up to W-1 slices after them (the
  *     rest of slice i-1's window); the window being encoded at that moment is drained and NOT copied back;
  *   * progress calls of one window arrive back to back.
- * Any other `cmpFunc` (a caller's own function: opaque), several GPUs with host memory, itwSetSliceWindow(-1) or a single slice:
- * the literal loop.  Host or device pointers; synchronous either way. */
+ * Several GPUs (`multithreaded` and GetProcessorCount() > 1, host memory): one pipeline PER GPU -- window k runs on worker k % n, each worker
+ * on its own device, and the calling thread calls progress(i) once every window up to slice i-1's has arrived, i.e. still in order; on an
+ * abort windows other GPUs had already finished further down the image stay written too.
+ * Any other `cmpFunc` (a caller's own function: opaque), itwSetSliceWindow(-1) or a single slice: the literal loop.  Host or device
+ * pointers; synchronous either way. */
 typedef bool (ItwProgressFunc)(int done, int total, void* user);
 bool itwCompressImageSliced(const rgba_surface* source, uint8_t* target, int64_t block_row_pitch, CompressionFunc* cmpFunc,
                             int dxgi_format, bool multithreaded, int64_t slice_pixels, ItwProgressFunc* progress, void* user);

@@ -300,7 +300,8 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
 }
 
 bool coalesce_small_call(const Job& j, const rgba_surface* src, uint8_t* dst, int64_t blocks);
-bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user, int fixed_window = 0);
+bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user, int fixed_window = 0,
+                     const itw::SlicedPart* share = nullptr);
 
 // texel rows of a host surface into the tight staging image
 void upload_rows(uint8_t* d_rows, size_t pitch, const uint8_t* hs, int64_t stride, size_t row_bytes, size_t nrows, hipStream_t copy)
@@ -578,7 +579,10 @@ SliceRows slice_rows(int i, int slices, int height, bool keep_partial)
 
 // returns true when every slice was encoded, false when `progress` stopped the job
 // `fixed_window` > 0 fixes W (compress() passes 1: its "slices" are the windows).
-bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user, int fixed_window)
+// `share`: this thread runs only the windows share->part, + share->parts, ... (one pipeline per GPU of the pool, dispatch.hip) and reports them
+// through share->retired instead of polling `progress`.
+bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user, int fixed_window,
+                     const itw::SlicedPart* share)
 {
     if (!src) itw::fail_msg("null surface");
     const int w = src->width, h = src->height;
@@ -590,7 +594,7 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
             if (i > 0 && progress && !progress(i, slices, user)) return false;
         return true;
     };
-    if (bx <= 0 || by <= 0) return poll(1, slices - 1);   // nothing to encode: the reference's loop still polls
+    if (bx <= 0 || by <= 0) return share ? true : poll(1, slices - 1);   // nothing to encode: the reference's loop still polls
     if (!src->ptr || !dst) itw::fail_msg("null texel or destination pointer");
     const int bpb = (j.fmt == Fmt::BC1 || j.fmt == Fmt::BC4) ? 8 : 16;
     const int texel_bytes = (j.fmt == Fmt::BC6H) ? 8 : 4;
@@ -601,6 +605,9 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
 
     const int W = fixed_window > 0 ? (fixed_window < slices ? fixed_window : slices) : slice_window(j.fmt, (int64_t)bx * by / slices, slices);
     const int nwin = (slices + W - 1) / W;
+    const int part = share ? share->part : 0, parts = share ? (share->parts < 1 ? 1 : share->parts) : 1;
+    const int nlocal = part < nwin ? (nwin - part + parts - 1) / parts : 0;       // this thread's windows: part, part + parts, ...
+    if (nlocal == 0) return true;
 
     ensure_device_ctx();
     ensure_bc7_aux();
@@ -649,8 +656,10 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
         v.nb = (int)((v.y1 - v.y0 + 3) / 4);
         return v;
     };
-    auto issue = [&](int k) {
-        const Window v = window(k);
+    // (issue / retire take the LOCAL index i of this thread's window part + i * parts: streams, workspace slices and events alternate by it)
+    auto issue = [&](int i) {
+        const int k = i;
+        const Window v = window(part + i * parts);
         if (v.y1 <= v.y0) return;
         hipStream_t ks = (k & 1) ? k1 : k0;
         const size_t nrows = (size_t)(v.y1 - v.y0);
@@ -662,8 +671,9 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
         launch(j, d_src + v.y0 * d_stride, d_stride, w, (int)nrows, d_dst + (size_t)v.row0 * bx * bpb, ks, true, j.fmt == Fmt::BC7 ? 1 : -1, ws_off[k & 1]);
         ITW_CHECK(hipEventRecord(tls.ev_done[k & 7], ks));
     };
-    auto retire = [&](int k) {                            // window k's bytes into `dst`; returns when they are there
-        const Window v = window(k);
+    auto retire = [&](int i) {                            // the window's bytes into `dst`; returns when they are there
+        const int k = i;
+        const Window v = window(part + i * parts);
         if (v.y1 <= v.y0) return;
         if (dst_dev) { ITW_CHECK(hipEventSynchronize(tls.ev_done[k & 7])); return; }
         const size_t off = (size_t)v.row0 * bx * bpb, len = (size_t)v.nb * bx * bpb;
@@ -675,14 +685,43 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
     // k+1 -- same stream as k-1, behind it in stream order -- already has its texels on the device.  (With one window of lookahead the upload of
     // k+1 only started after k-1 had been retired, and for its 0.16 ms the chip ran window k alone: `basic` 3.86 -> 3.5 ms per 4096^2 call.)
     static const int depth = [] { const char* e = std::getenv("ITW_SLICE_LOOKAHEAD"); const int v = e ? std::atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
-    for (int k = 0; k < depth && k < nwin; k++) issue(k);
-    for (int k = 0; k < nwin; k++) {
-        if (k + depth < nwin) issue(k + depth);
-        retire(k);
-        const Window v = window(k);
-        if (!poll(v.s0 + 1, v.s1)) return false;         // the windows behind k are in flight: ~Drain waits for them, their bytes are not copied back
+    auto stopped = [&] { return share && share->stop && share->stop->load(std::memory_order_acquire); };
+    for (int i = 0; i < depth && i < nlocal; i++) issue(i);
+    for (int i = 0; i < nlocal; i++) {
+        if (stopped()) return false;
+        if (i + depth < nlocal) issue(i + depth);
+        retire(i);
+        const Window v = window(part + i * parts);
+        if (share) { if (share->retired) share->retired(v.s0, v.s1, share->ctx); }
+        else if (!poll(v.s0 + 1, v.s1)) return false;    // the windows behind it are in flight: ~Drain waits for them, their bytes are not copied back
     }
     return true;
+}
+
+// format code + settings pointer of the dispatch layer -> Job (the settings struct must outlive the job)
+Job job_of(int dxgi_format, const void* settings)
+{
+    Job j;
+    switch (dxgi_format) {
+    case ITW_DXGI_FORMAT_BC1_UNORM: case ITW_DXGI_FORMAT_BC1_UNORM_SRGB: j.fmt = Fmt::BC1; break;
+    case ITW_DXGI_FORMAT_BC3_UNORM: case ITW_DXGI_FORMAT_BC3_UNORM_SRGB: j.fmt = Fmt::BC3; break;
+    case ITW_DXGI_FORMAT_BC4_UNORM: j.fmt = Fmt::BC4; break;
+    case ITW_DXGI_FORMAT_BC5_UNORM: j.fmt = Fmt::BC5; break;
+    case ITW_DXGI_FORMAT_BC6H_UF16: case ITW_DXGI_FORMAT_BC6H_SF16: j.fmt = Fmt::BC6H; j.s6 = static_cast<const bc6h_enc_settings*>(settings); break;
+    case ITW_DXGI_FORMAT_BC7_UNORM: case ITW_DXGI_FORMAT_BC7_UNORM_SRGB: j.fmt = Fmt::BC7; j.s7 = static_cast<const bc7_enc_settings*>(settings); break;
+    default: itw::fail_msg("DXGI format %d is not one this library encodes", dxgi_format);
+    }
+    if ((j.fmt == Fmt::BC7 || j.fmt == Fmt::BC6H) && !settings) itw::fail_msg("null settings for a BC7 / BC6H job");
+    return j;
+}
+
+int slices_of(const rgba_surface* s, int64_t slice_pixels)
+{
+    if (slice_pixels <= 0) slice_pixels = 0x40000;                               // IntelPlugin.cpp:851
+    int64_t slices = ((int64_t)s->width * s->height) / slice_pixels;
+    if (slices < 1) slices = 1;
+    if (slices > (1 << 24)) itw::fail_msg("%lld slices", (long long)slices);
+    return (int)slices;
 }
 
 // ---- joining concurrent small calls ----------------------------------------------------------------------------------
@@ -908,6 +947,33 @@ __global__ void k_test_f2i(const float* in, int32_t* out, int64_t n)
 
 } // namespace
 
+namespace itw {
+
+bool sliced_part(const rgba_surface* source, uint8_t* target, int dxgi_format, const void* settings, int64_t slice_pixels, const SlicedPart& part)
+{
+    bool done = false;
+    clear_failure();
+    const bool ok = guarded([&] {
+        if (!source) fail_msg("null surface");
+        const Job j = job_of(dxgi_format, settings);
+        done = compress_sliced(j, source, target, slices_of(source, slice_pixels), nullptr, nullptr, 0, &part);
+    });
+    return ok && done;
+}
+
+int sliced_windows(int dxgi_format, int width, int height, int64_t slice_pixels, int* window_slices)
+{
+    const int W = itwSliceWindow(dxgi_format, width, height, slice_pixels);
+    if (window_slices) *window_slices = W;
+    if (W <= 0) return 0;
+    if (slice_pixels <= 0) slice_pixels = 0x40000;
+    int64_t slices = ((int64_t)width * height) / slice_pixels;
+    if (slices < 1) slices = 1;
+    return (int)((slices + W - 1) / W);
+}
+
+} // namespace itw
+
 extern "C" {
 
 void GetProfile_ultrafast(bc7_enc_settings* s) { apply(kUltrafast, s); }
@@ -966,25 +1032,11 @@ bool itwCompressImageSlicedEx(const rgba_surface* source, uint8_t* target, int64
     itw::clear_failure();
     const bool ok = itw::guarded([&] {
         if (!source) itw::fail_msg("null surface");
-        Job j;
-        switch (dxgi_format) {
-        case ITW_DXGI_FORMAT_BC1_UNORM: case ITW_DXGI_FORMAT_BC1_UNORM_SRGB: j.fmt = Fmt::BC1; break;
-        case ITW_DXGI_FORMAT_BC3_UNORM: case ITW_DXGI_FORMAT_BC3_UNORM_SRGB: j.fmt = Fmt::BC3; break;
-        case ITW_DXGI_FORMAT_BC4_UNORM: j.fmt = Fmt::BC4; break;
-        case ITW_DXGI_FORMAT_BC5_UNORM: j.fmt = Fmt::BC5; break;
-        case ITW_DXGI_FORMAT_BC6H_UF16: case ITW_DXGI_FORMAT_BC6H_SF16: j.fmt = Fmt::BC6H; j.s6 = static_cast<const bc6h_enc_settings*>(settings); break;
-        case ITW_DXGI_FORMAT_BC7_UNORM: case ITW_DXGI_FORMAT_BC7_UNORM_SRGB: j.fmt = Fmt::BC7; j.s7 = static_cast<const bc7_enc_settings*>(settings); break;
-        default: itw::fail_msg("itwCompressImageSlicedEx: DXGI format %d is not one this library encodes", dxgi_format);
-        }
-        if ((j.fmt == Fmt::BC7 || j.fmt == Fmt::BC6H) && !settings) itw::fail_msg("itwCompressImageSlicedEx: null settings");
+        const Job j = job_of(dxgi_format, settings);
         const bool keep = j.fmt == Fmt::BC4 || j.fmt == Fmt::BC5;
         const int64_t tight = (int64_t)(keep ? (source->width + 3) / 4 : source->width / 4) * ((j.fmt == Fmt::BC1 || j.fmt == Fmt::BC4) ? 8 : 16);
         if (block_row_pitch != tight) itw::fail_msg("itwCompressImageSlicedEx: block_row_pitch %lld != %lld (tight)", (long long)block_row_pitch, (long long)tight);
-        if (slice_pixels <= 0) slice_pixels = 0x40000;                               // IntelPlugin.cpp:851
-        int64_t slices = ((int64_t)source->width * source->height) / slice_pixels;
-        if (slices < 1) slices = 1;
-        if (slices > (1 << 24)) itw::fail_msg("itwCompressImageSlicedEx: %lld slices", (long long)slices);
-        done = compress_sliced(j, source, target, (int)slices, progress, user);
+        done = compress_sliced(j, source, target, slices_of(source, slice_pixels), progress, user);
     });
     return ok && done;
 }

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -29,6 +30,7 @@ struct Job {
     CompressionFunc* fn = nullptr;
     int min_height = 4;         // bands without a whole block row are not handed out (the reference calls them anyway,
                                 // win32Threads.cpp:264, and its kernel loops over height/4 = 0 rows); 1 for BC4/BC5
+    std::function<void(int)> task;   // instead of a band: something the worker runs on its device (its share of a pipelined slice loop)
     bool pending = false;
 };
 
@@ -55,7 +57,11 @@ struct Pool {
             Job j = jobs[idx];
             lk.unlock();
             const char* err = nullptr;
-            if (j.input.height >= j.min_height) {
+            if (j.task) {
+                itwClearError();
+                j.task(idx);
+                err = itwLastError();
+            } else if (j.input.height >= j.min_height) {
                 itwClearError();
                 j.fn(&j.input, j.output);
                 // The resident path of CompressBlocks* is asynchronous on this worker's stream; a band handed to a
@@ -189,6 +195,7 @@ bool CompressImageMT(const rgba_surface* input, uint8_t* output, CompressionFunc
             j.input.height = y1 - y0;
             j.output = output + (int64_t)(y0 / 4) * blocks_across(input->width, dxgi_format) * bpb;
             j.fn = cmpFunc;
+            j.task = nullptr;
             j.min_height = keeps_partial_blocks(dxgi_format) ? 1 : 4;
             j.pending = true;
         }
@@ -263,6 +270,80 @@ static bool resolve_trampoline(CompressionFunc* fn, int dxgi_format, bc7_enc_set
     return false;
 }
 
+// Several GPUs, host memory: one PIPELINE PER GPU.  The windows of the slice loop are dealt round-robin to the pool's workers (window k to
+// worker k % n; every worker runs its share through its own device, streams and staging: itw::sliced_part), a worker reports a window once
+// its bytes are in `target`, and the submitting thread -- this one -- calls `progress` for the window's slices as soon as every window
+// before it has arrived, i.e. in the reference's order.  A false return raises the stop flag: no worker issues another window, what is in
+// flight is drained (windows other GPUs had already finished further down the image stay written, like the rest of the aborting window).
+static bool sliced_on_pool(const rgba_surface* source, uint8_t* target, int dxgi_format, const void* settings, int64_t slice_pixels, int slices,
+                           ItwProgressFunc* progress, void* user)
+{
+    Pool* p = pool();
+    const int n = (int)p->threads.size();
+    int W = 1;
+    const int nwin = itw::sliced_windows(dxgi_format, source->width, source->height, slice_pixels, &W);
+    struct Shared {
+        std::mutex m; std::condition_variable cv;
+        std::vector<char> arrived;
+        std::atomic<bool> stop{false};
+        int running = 0, W = 1;
+    } sh;
+    sh.arrived.assign((size_t)(nwin > 0 ? nwin : 1), 0);
+    sh.running = n; sh.W = W;
+    auto retired = [](int s0, int, void* ctx) {
+        Shared* s = static_cast<Shared*>(ctx);
+        { std::lock_guard<std::mutex> lk(s->m); s->arrived[(size_t)(s0 / s->W)] = 1; }
+        s->cv.notify_all();
+    };
+    std::lock_guard<std::mutex> one(p->submit);
+    {
+        std::lock_guard<std::mutex> lk(p->m);
+        for (int i = 0; i < n; i++) {
+            Job& j = p->jobs[i];
+            j.fn = nullptr;
+            j.task = [&, n](int idx) {
+                itw::SlicedPart part;
+                part.part = idx; part.parts = n; part.retired = retired; part.stop = &sh.stop; part.ctx = &sh;
+                const bool ok = itw::sliced_part(source, target, dxgi_format, settings, slice_pixels, part);
+                if (!ok) sh.stop.store(true, std::memory_order_release);          // a failed worker ends the job for everybody
+                { std::lock_guard<std::mutex> l2(sh.m); sh.running--; }
+                sh.cv.notify_all();
+            };
+            j.pending = true;
+        }
+        p->outstanding = n;
+        p->failed = false;
+    }
+    p->work.notify_all();
+    bool aborted = false;
+    {
+        std::unique_lock<std::mutex> lk(sh.m);
+        for (int k = 0; k < nwin && !aborted; k++) {
+            sh.cv.wait(lk, [&] { return sh.arrived[(size_t)k] || sh.running == 0; });
+            if (!sh.arrived[(size_t)k]) break;                                      // the workers are gone without it: stopped or failed
+            lk.unlock();
+            const int s1 = (k + 1) * W < slices ? (k + 1) * W : slices;
+            for (int i = k * W + 1; i <= s1 && i < slices; i++)
+                if (progress && !progress(i, slices, user)) { aborted = true; sh.stop.store(true, std::memory_order_release); break; }
+            lk.lock();
+        }
+    }
+    bool failed = false;
+    {
+        std::unique_lock<std::mutex> lk(p->m);
+        p->done.wait(lk, [&] { return p->outstanding == 0; });
+        failed = p->failed;
+        if (failed) {
+            itw::Failure f;
+            std::snprintf(f.msg, sizeof f.msg, "%s", p->fail_msg);
+            lk.unlock();
+            itw::report_failure(f);
+        }
+        for (int i = 0; i < n; i++) p->jobs[i].task = nullptr;                      // (the closures point into this frame)
+    }
+    return !aborted && !failed && !sh.stop.load();
+}
+
 bool itwCompressImageSliced(const rgba_surface* source, uint8_t* target, int64_t block_row_pitch, CompressionFunc* cmpFunc,
                             int dxgi_format, bool multithreaded, int64_t slice_pixels, ItwProgressFunc* progress, void* user)
 {
@@ -276,14 +357,17 @@ bool itwCompressImageSliced(const rgba_surface* source, uint8_t* target, int64_t
         std::fprintf(stderr, "itwCompressImageSliced: block_row_pitch %lld != %lld (tight)\n", (long long)block_row_pitch, (long long)tight);
         return false;
     }
-    // One GPU behind the call (one worker, or a surface that lives on a device): the slices run as a pipeline.  With several GPUs
-    // CompressImageMT hands every slice's bands to all of them, as the reference's pool does with its threads.
+    // The library's own trampolines: the slices run as a pipeline -- on the calling thread when one GPU is behind the call (one worker, or a
+    // surface that lives on a device), else one pipeline per GPU of the pool with the windows dealt round-robin.
     bc7_enc_settings s7;
     bc6h_enc_settings s6;
     const void* settings = nullptr;
-    if (slices > 1 && itwSliceWindow(dxgi_format, source->width, source->height, slice_pixels) > 0 && resolve_trampoline(cmpFunc, dxgi_format, &s7, &s6, &settings) &&
-        (!multithreaded || worker_count() == 1 || is_device_pointer(source->ptr) || is_device_pointer(target)))
-        return itwCompressImageSlicedEx(source, target, block_row_pitch, dxgi_format, settings, slice_pixels, progress, user);
+    if (slices > 1 && itwSliceWindow(dxgi_format, source->width, source->height, slice_pixels) > 0 && resolve_trampoline(cmpFunc, dxgi_format, &s7, &s6, &settings)) {
+        if (!multithreaded || worker_count() == 1 || is_device_pointer(source->ptr) || is_device_pointer(target))
+            return itwCompressImageSlicedEx(source, target, block_row_pitch, dxgi_format, settings, slice_pixels, progress, user);
+        itwClearError();
+        return sliced_on_pool(source, target, dxgi_format, settings, slice_pixels, slices, progress, user);
+    }
     for (int i = 0; i < slices; i++) {
         if (i > 0 && progress && !progress(i, slices, user)) return false;          // allow an early out
         int ylo = (int)((int64_t)i * source->height / slices) & ~0x3;

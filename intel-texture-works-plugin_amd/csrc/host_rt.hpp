@@ -10,8 +10,11 @@
 // Inside the library a failure is a C++ exception (itw::Failure) that every extern "C" entry point catches.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
+#include "../../include/ispc_texcomp.h"
 
 namespace itw {
 
@@ -33,6 +36,21 @@ inline bool guarded(F&& body) noexcept
     catch (...) { Failure f; std::snprintf(f.msg, sizeof f.msg, "unexpected C++ exception inside libispc_texcomp"); report_failure(f); }
     return false;
 }
+
+// One worker's share of a pipelined slice loop (abi.hip compress_sliced; dispatch.hip deals the windows of itwCompressImageSliced to the pool's
+// GPUs): the worker runs windows part, part + parts, ... on ITS device and streams, calls `retired(first_slice, end_slice, ctx)` when a window's
+// bytes are in the target instead of polling the caller's progress function (the submitting thread does that, in order), and stops issuing
+// once `*stop` is set.
+struct SlicedPart {
+    int part = 0, parts = 1;
+    void (*retired)(int first_slice, int end_slice, void* ctx) = nullptr;
+    const std::atomic<bool>* stop = nullptr;
+    void* ctx = nullptr;
+};
+// the share `part` of the slice loop over `source` (format, settings and slice size as itwCompressImageSlicedEx takes them); false: stopped or failed
+bool sliced_part(const rgba_surface* source, uint8_t* target, int dxgi_format, const void* settings, int64_t slice_pixels, const SlicedPart& part);
+// windows a call is cut into, and W (slices per window); 0 windows: the pipeline is off
+int sliced_windows(int dxgi_format, int width, int height, int64_t slice_pixels, int* window_slices);
 
 // One predicate for "the kernels can dereference this pointer": device AND managed allocations (abi.hip and
 // dispatch.hip/decode.hip used to disagree on managed memory).  Unregistered host memory -> false.

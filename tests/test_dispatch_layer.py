@@ -304,7 +304,57 @@ itw_amd.lib().DestroyThreads()
 print("ok")
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, ITW_WORKERS="64")
+    env = dict(os.environ, ITW_WORKERS="64", ITW_SLICED_PIPELINE="0")     # the literal loop: one CompressImageMT per slice, 64 bands each
     r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "intel-texture-works-plugin_amd"))],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workers", [2, 3, 8])
+def test_sliced_pipeline_one_pipeline_per_worker(gpu, oracle, workers):
+    """Several GPUs behind itwCompressImageSliced (here: ITW_WORKERS workers sharing device 0): the windows are dealt round-robin to the
+    pool's workers, each runs its share as its own pipeline, and the submitting thread calls progress in the reference's order.  Bytes of the
+    oracle; one call per slice boundary, ascending; an abort stops every worker, returns false and leaves slices < k written."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import itw_amd
+from itw_amd import surfaces
+from oracle import pyoracle
+L = itw_amd.lib()
+n = L.GetProcessorCount()
+ldr = surfaces.ldr_smooth(512, 256)                       # 64 slices of 2048 px (8 texel rows)
+hdr = surfaces.hdr_smooth(256, 128)
+for fmt, img, prof, px in (("bc7", ldr, "basic", 2048), ("bc7", ldr, "alpha_basic", 2048), ("bc1", ldr, None, 2048), ("bc6h", hdr, "slow", 512),
+                           ("bc5", np.ascontiguousarray(ldr[:509, :253]), None, 2012)):
+    h, w = img.shape[:2]
+    assert w * h // px == 64
+    want = pyoracle.encode(fmt, img, prof).reshape(-1)
+    calls = []
+    ok, out = itw_amd.compress_image(fmt, img, prof, multithreaded=True, slice_pixels=px, progress=lambda i, t, u: calls.append(i) or True)
+    assert ok and calls == list(range(1, 64)), (fmt, prof, calls[:8])
+    assert np.array_equal(out, want), (fmt, prof)
+for k in (1, 9, 40, 63):
+    want = pyoracle.encode("bc7", ldr, "veryfast").reshape(-1)
+    calls = []
+    ok, out = itw_amd.compress_image("bc7", ldr, "veryfast", multithreaded=True, slice_pixels=2048, progress=lambda i, t, u: calls.append(i) or i != k)
+    done = k * 2 * 64 * 16
+    assert not ok and calls == list(range(1, k + 1)) and np.array_equal(out[:done], want[:done]), (k, calls[-3:])
+    assert itw_amd.lib().itwLastError() is None
+    written = out.reshape(-1, 2048).any(axis=1)            # per slice: anything written?
+    assert all(np.array_equal(out[s * 2048:(s + 1) * 2048], want[s * 2048:(s + 1) * 2048]) for s in np.nonzero(written)[0])   # whatever arrived is right
+ok, out = itw_amd.compress_image("bc7", ldr, "veryfast", multithreaded=True, slice_pixels=2048)      # and the pool is fine afterwards
+assert ok and np.array_equal(out, pyoracle.encode("bc7", ldr, "veryfast").reshape(-1))
+L.DestroyThreads()
+print("ok", n)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ITW_WORKERS=str(workers))
+    env.pop("ITW_SLICED_PIPELINE", None); env.pop("ITW_SLICE_WINDOW", None)
+    r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "intel-texture-works-plugin_amd"))],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and ("ok %d" % workers) in r.stdout, r.stdout + r.stderr
