@@ -344,8 +344,8 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
 
     // Round 6: a large BC6H call, and a large BC7 call of a profile without an order verdict (everything but `slow`), takes the WINDOW pipeline
     // of the slice loop (compress_sliced below) with no callback: windows of ~131 072 blocks alternate between two kernel streams with the
-    // neighbours' copies on the third -- measured against the runs below at 4096^2: BC6H `slow` 4.81 -> 4.36 ms, BC7 `alpha_basic` 3.31 -> 3.11,
-    // `alpha_veryfast` 2.46 -> 2.26, `basic` 3.93 -> 3.86 (profiles/r06a_sliced_timing.jsonl).  The tuning knobs of the runs keep the runs.
+    // neighbours' copies on the third -- measured against the runs below at 4096^2: BC6H `slow` 4.83 -> 4.3 ms, BC7 `alpha_basic` 3.31 -> 2.9,
+    // `alpha_veryfast` 2.46 -> 2.0, `basic` 3.93 -> 3.6 (profiles/r06_host_pointer_path.txt, r06_sliced_timing.jsonl).  The tuning knobs of the runs keep the runs.
     if (!src_dev && !dst_dev && !keep_partial && !std::getenv("ITW_HOST_CHUNKS") && !std::getenv("ITW_HOST_RUNS") && !std::getenv("ITW_HOST_WINDOWS_OFF")) {
         const int64_t blocks = (int64_t)bx * by;
         const bool bc7w = j.fmt == Fmt::BC7 && blocks >= 524288 && !itw::bc7_has_order_verdict(*j.s7) && itw::bc7_staged_bands_ok();   // (`slow` keeps its runs: their host-side verdict picks the wide shape on photographs, 7.4 vs 8.6 ms as windows)
@@ -683,7 +683,8 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
     };
     // Two windows AHEAD of the one being retired are issued: when window k-1's kernels end, window k is running on the other stream and window
     // k+1 -- same stream as k-1, behind it in stream order -- already has its texels on the device.  (With one window of lookahead the upload of
-    // k+1 only started after k-1 had been retired, and for its 0.16 ms the chip ran window k alone: `basic` 3.86 -> 3.5 ms per 4096^2 call.)
+    // k+1 only started after k-1 had been retired, and for its 0.16 ms the chip ran window k alone.  4096^2, 64 slices, ms per call with a lookahead of
+    // 1 / 2 / 3: `basic` 3.81 / 3.58 / 3.59, `alpha_basic` 3.20 / 2.86 / 2.94, `slow` 6.50 / 5.96 / 5.96, BC6H `slow` 4.35 / 4.29 / 4.27, BC1 1.48 / 1.50 / 1.49.)
     static const int depth = [] { const char* e = std::getenv("ITW_SLICE_LOOKAHEAD"); const int v = e ? std::atoi(e) : 2; return v < 1 ? 1 : (v > 4 ? 4 : v); }();
     auto stopped = [&] { return share && share->stop && share->stop->load(std::memory_order_acquire); };
     for (int i = 0; i < depth && i < nlocal; i++) issue(i);

@@ -34,6 +34,28 @@ def test_host_pad_respects_stride(itw):
     assert np.array_equal(itw.pad_to_multiple_of_4(view), np.pad(view, ((0, 3), (0, 1), (0, 0)), mode="edge"))
 
 
+def test_slice_window_rule(itw):
+    """itwSliceWindow (no GPU needed): W = slices per window of the pipelined slice loop -- about 131 072 blocks for BC7 / BC6H, 262 144 for the
+    PCIe-bound formats, never more than 1/8 resp. 1/4 of the slices; itwSetSliceWindow fixes it, -1 turns the pipeline off (0)."""
+    import os
+    if "ITW_SLICE_WINDOW" in os.environ or os.environ.get("ITW_SLICED_PIPELINE") == "0":
+        pytest.skip("the environment presets the window")
+    L = itw.lib()
+    try:
+        assert [L.itwSliceWindow(f, 4096, 4096, 0) for f in (98, 99, 95, 96)] == [8, 8, 8, 8]          # 64 slices of 16 384 blocks
+        assert [L.itwSliceWindow(f, 4096, 4096, 0) for f in (71, 77, 80, 83)] == [16, 16, 16, 16]
+        assert L.itwSliceWindow(98, 16384, 16384, 0) == 8 and L.itwSliceWindow(71, 16384, 16384, 0) == 16   # 1024 slices: the block target binds
+        assert L.itwSliceWindow(98, 1024, 1024, 0) == 1 and L.itwSliceWindow(98, 2048, 2048, 0) == 2      # 4 / 16 slices: the 1/8 cap binds
+        assert L.itwSliceWindow(98, 4096, 4096, 1 << 20) == 2                                            # 16 slices of 65 536 blocks
+        assert L.itwSliceWindow(98, 64, 64, 0) == 1                                                      # one slice
+        L.itwSetSliceWindow(5)
+        assert L.itwSliceWindow(98, 4096, 4096, 0) == 5 and L.itwSliceWindow(98, 1024, 1024, 0) == 4     # clamped to the slice count
+        L.itwSetSliceWindow(-1)
+        assert L.itwSliceWindow(98, 4096, 4096, 0) == 0
+    finally:
+        L.itwSetSliceWindow(0)
+
+
 # ---- GPU ------------------------------------------------------------------------------------------
 @pytest.mark.gpu
 def test_trampolines_equal_direct_calls_and_oracle(itw, gpu, oracle):
