@@ -132,7 +132,12 @@ struct ThreadCtx {
         if (verdict.host_counts) (void)hipHostFree((void*)verdict.host_counts);
     }
 };
-thread_local ThreadCtx tls;
+thread_local ThreadCtx tls_own;
+// A combiner leader (below) works in its DEVICE's shared context instead of its own: whichever of the caller's 8 or 64 pool threads happens to
+// lead a burst would otherwise bring its own staging buffers, workspace, streams and pinned words -- tens of milliseconds of hipMalloc the first
+// time each thread leads, and 64 copies of the buffers (round 6: BC7 `basic`, one whole-surface CompressImageMT from 64 pool threads: 14.0 -> 4 ms).
+thread_local ThreadCtx* tls_lent = nullptr;
+#define tls (*(tls_lent ? tls_lent : &tls_own))
 
 // Per-thread resources belong to the device they were created on: a host thread that switches devices (hipSetDevice)
 // drops them and starts over.
@@ -745,11 +750,29 @@ struct Pending {
     char msg[384] = {0};
 };
 
+// ITW_COALESCE_DEBUG=1: per device, at process exit: bursts, batches (leader rounds), requests, merged calls, microseconds leaders waited
+struct CombinerStats { std::atomic<long long> bursts{0}, batches{0}, requests{0}, calls{0}, wait_us{0}; };
+CombinerStats g_cstats;
+bool combiner_debug()
+{
+    static const bool on = [] {
+        const char* e = std::getenv("ITW_COALESCE_DEBUG");
+        const bool v = e && e[0] == '1';
+        if (v) std::atexit([] {
+            std::fprintf(stderr, "itw combiner: %lld bursts, %lld batches, %lld requests, %lld merged calls, leaders waited %lld us\n", g_cstats.bursts.load(),
+                         g_cstats.batches.load(), g_cstats.requests.load(), g_cstats.calls.load(), g_cstats.wait_us.load());
+        });
+        return v;
+    }();
+    return on;
+}
+
 struct Combiner {
     std::mutex m;
     std::condition_variable cv;
     std::vector<Pending*> queue;
     bool leader = false;
+    ThreadCtx* ctx = nullptr;          // the device's shared context: used by whoever leads (one thread at a time), created by the first leader, never freed
     int burst = 0;                     // requests served since the queue was last idle
     int expected = 1;                  // size of the previous burst: the reference's pool submits the same number of bands
                                        // for every slice (win32Threads.cpp:217-231), so the next burst will be this large too
@@ -811,6 +834,7 @@ void run_batch(std::vector<Pending*>& batch)
         }
         Job j = batch[i]->job;
         j.s7 = &batch[i]->s7; j.s6 = &batch[i]->s6;
+        if (combiner_debug()) g_cstats.calls++;
         try { compress(j, &merged, batch[i]->dst, false); }
         catch (const itw::Failure& f) {
             for (size_t t = i; t < k; t++) { batch[t]->failed = true; std::snprintf(batch[t]->msg, sizeof batch[t]->msg, "%s", f.msg); }
@@ -853,16 +877,21 @@ bool coalesce_small_call(const Job& j, const rgba_surface* src, uint8_t* dst, in
                 if (c.queue.size() != seen) { seen = c.queue.size(); grown = now; }
                 if (now - grown > std::chrono::microseconds(80) || now - t0 > std::chrono::microseconds(600)) break;
             }
+            if (combiner_debug()) g_cstats.wait_us += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
         }
         std::vector<Pending*> batch;
         batch.swap(c.queue);
+        if (combiner_debug()) { g_cstats.batches++; g_cstats.requests += (long long)batch.size(); if (c.burst == 0) g_cstats.bursts++; }
         c.burst += (int)batch.size();
         lk.unlock();
+        if (!c.ctx) c.ctx = new ThreadCtx;                // (only the leader touches c.ctx, and there is one leader at a time)
+        tls_lent = c.ctx;
         try { run_batch(batch); }
         catch (...) {                                     // anything but an itw::Failure (those are caught per merged call):
             for (Pending* p : batch)                      // the requests must still be released and leadership handed on
                 if (!p->failed) { p->failed = true; std::snprintf(p->msg, sizeof p->msg, "unexpected C++ exception while running a combined call"); }
         }
+        tls_lent = nullptr;
         lk.lock();
         for (Pending* p : batch) p->done = true;
         if (c.queue.empty()) { c.expected = c.burst; c.burst = 0; }      // burst over

@@ -33,6 +33,7 @@ tables)
   timeout 900 python tools/sliced_timing.py 4096 5 0,4,16 2>/dev/null > $OUT/sliced_timing.jsonl
   timeout 600 python tools/sliced_timing.py 16384 2 0 bc7_basic,bc1,bc6h_slow 2>/dev/null > $OUT/sliced_timing_16384.jsonl
   timeout 900 python tools/ref_caller_timing.py 4096 8,64 > $OUT/reference_caller_timing.jsonl 2>&1
+  timeout 600 bash tools/combiner_probe.sh 2>&1 | nog > $OUT/combiner_probe.txt
   timeout 600 python tools/bc13_timing.py 2>&1 | nog > $OUT/bc13_timing.txt
   ORDER_PROFILES=slow,alpha_slow timeout 600 python tools/order_timing.py I3 I2 baboon test_a mixed monkey landscape 2>&1 | nog > $OUT/bc7_order_policy_by_content.txt
   ITW_BC7_PILOT_DEBUG=1 ORDER_HOST=0 timeout 300 python tools/order_timing.py I3 I2 baboon test_a mixed monkey landscape 2>&1 | grep "^bc7 pilot\|^==" | uniq -c > $OUT/bc7_pilot_verdicts_by_content.txt
