@@ -37,6 +37,10 @@ def main():
     only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
     L = itw_amd.lib()
     ldr = surfaces.ldr_smooth(size, size)
+    if os.environ.get("SLICED_CONTENT") == "baboon":      # the reference's baboon.png tiled (opaque): the natural-image end of BC7 `slow`
+        z = np.load(os.path.join(ROOT, "tests", "golden", "inputs.npz"))
+        reps = -(-size // z["baboon"].shape[0])
+        ldr = np.ascontiguousarray(np.tile(z["baboon"], (reps, reps, 1))[:size, :size])
     rgba = ldr                          # the generator's alpha channel is a second field (translucent)
     hdr = surfaces.hdr_smooth(size, size)
     for fmt, prof in PLUGIN:
