@@ -378,7 +378,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     // BC7 / BC6H spend milliseconds per surface: cut the call into runs of block rows so that the upload of run c+1 and
     // the download of run c-1 (copy stream; a pageable copy blocks only this host thread) overlap the kernels of run c.
     // A run must still fill the chip several times over (one block per lane: 1024 workgroups = one round of the BC7
-    // scans), or the kernels' tails cost more than the copies save -- measured at 4096^2 (tools/host_chunks_probe.py):
+    // scans), or the kernels' tails cost more than the copies save -- measured at 4096^2 (tools/history/misc/host_chunks_probe.py):
     // BC7 slow 9.58 / 9.19 / 9.60 / 11.6 ms for 1 / 2 / 4 / 8 runs, BC6H slow 7.61 / 6.15 / 5.64 / 5.57 ms.
     // BC1/3/4/5 are PCIe-bound: one run.
     // Runs need not be equal: a SHORT FIRST run starts the kernels after an eighth of the upload instead of half of it,
@@ -405,7 +405,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     // each run in the deep shape with its own slice of the workspace, so that one run's launch tails are filled by its neighbour's work as
     // soon as that neighbour's texels have arrived (the device-resident path does the same with the two halves of a surface, bc7.hip).
     // Content where nearly every block still needs modes 1/3 (photographs) gains nothing from the bounded order, and for it the WIDE shape,
-    // one run after the other, overlaps staged runs better (8.1 against 7.4 ms per 4096^2 call, profiles/r05c_*).  Which it is comes
+    // one run after the other, overlaps staged runs better (8.1 against 7.4 ms per 4096^2 call, profiles/history/r05/r05c_*).  Which it is comes
     // from the pilot's estimate (bc7.hip bc7_pilot_estimate): counted behind the first run's {0,2} scan when that run is a band, by a
     // probe on the second stream when it is wide.  The host never waits for it: the first run takes the shape the PREVIOUS call's
     // estimate asked for (successive calls of a save -- mip levels, slices -- hold similar content), later runs this call's as soon as

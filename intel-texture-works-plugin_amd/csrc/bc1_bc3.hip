@@ -19,7 +19,7 @@
 
 // Register allocation target: four waves per SIMD (measured round 3: 5 waves = 96 VGPRs + spills is 16 % slower, 3 and 2 waves
 // change nothing -- the kernel is bound by the issue cycles of its own instruction stream).  The A/B switches and
-// probe builds that measured this live in tools/variants/bc1_bc3_r03_probes.hip.
+// probe builds that measured this live in tools/history/variants_r03_r04/bc1_bc3_r03_probes.hip.
 constexpr int BC13_WAVES = 4;
 
 namespace itw {
@@ -64,7 +64,7 @@ static_assert(sizeof(Bc1Image) == 4096 + 4096 + 1024, "Bc1Image layout");
 
 // Round 3: the image is 9 KiB (was 21): the seeds stay packed to 16 bit and a lookup expands its word with one v_lshl_or.
 // At launch every workgroup of the chip copies the image at the same time and nothing overlaps that copy but the first
-// texel loads: measured 2.4 us of a 29 us BC1 launch for 21 KiB x 2048 workgroups (tools/gpu_probe_bc1.sh).
+// texel loads: measured 2.4 us of a 29 us BC1 launch for 21 KiB x 2048 workgroups (tools/history/misc/gpu_probe_bc1.sh).
 struct Bc1Tables {
     const unsigned short* rsq16;
     const unsigned short* rcp16;

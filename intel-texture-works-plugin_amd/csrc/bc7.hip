@@ -1518,7 +1518,7 @@ __device__ __forceinline__ int32_t append_to_list(int32_t* __restrict__ list, in
 // so its error is >= (sqrt(R) - sqrt(3)/2 sqrt(16))_+^2 with R the block's residual about its best line (subset_residual_bound: the same
 // number the two-subset bound is built from, for the whole block), and it replaces the block only on a strict `<`.  Where that bound has
 // already been reached by the modes before it for all 64 blocks of the wave, mode 6 is not run (per-lane skipping saves nothing on a SIMT
-// machine).  profiles/r05_bc7_bound456_study.txt: 100 % of the bench surface's blocks (noise in every block: three subsets beat one line),
+// machine).  profiles/history/r05/r05_bc7_bound456_study.txt: 100 % of the bench surface's blocks (noise in every block: three subsets beat one line),
 // 56-64 % of a photograph's; modes 4/5 cannot be bounded out this way (15 % / 1 %: their scalar channel absorbs the noise).
 __device__ __forceinline__ bool mode6_cannot_win(Lane& ln)
 {
@@ -1999,9 +1999,9 @@ static bool bc7_bounded_order()
 }
 // Round 5.  ITW_BC7_PILOT_THR: the pilot's threshold in percent of the blocks it looks at that its estimate lists for modes 1/3 -- at or below it the rest of
 // the surface takes the bounded order, above it the reference's; -1 = no pilot (always bounded), 0 = pilot, always the reference's order for the
-// rest, 100 = pilot, always bounded (tools/round5/order_timing.py under each setting: profiles/r05e_*).  Returned in 1/256.
+// rest, 100 = pilot, always bounded (tools/order_timing.py under each setting: profiles/history/r05/r05e_*).  Returned in 1/256.
 #ifndef ITW_BC7_PILOT_THR_DEFAULT
-#define ITW_BC7_PILOT_THR_DEFAULT 90     // forced either way by content (profiles/r05l_*): 74 % estimated -> bounded wins by 11 %, 91 % -> equal, 98 % -> reference order by 0.6 %
+#define ITW_BC7_PILOT_THR_DEFAULT 90     // forced either way by content (profiles/history/r05/r05l_*): 74 % estimated -> bounded wins by 11 %, 91 % -> equal, 98 % -> reference order by 0.6 %
 #endif
 static std::atomic<int> g_bc7_pilot{-2};           // percent; -2 = not read yet
 static int bc7_pilot_threshold()
@@ -2409,7 +2409,7 @@ void launch_bc7(const uint8_t* src, int64_t stride, int width, int height, uint8
                 //    device word; BOTH continuations of each band are enqueued behind it, each gated on that word (ChunkSel.gate): the one
                 //    the pilot did not choose returns at once.  No host round trip, no block treated differently from its neighbours.
                 //    (A sample encoded ahead on a third stream was measured first: its chain of small launches could not get its share of a
-                //    chip the bands' scans fill, and the verdict arrived late: profiles/r05d_bc7_pilot_timeline.txt.)
+                //    chip the bands' scans fill, and the verdict arrived late: profiles/history/r05/r05d_bc7_pilot_timeline.txt.)
                 ITW_CHECK(hipMemsetAsync(rgb_count, 0, 16 * sizeof(int32_t), st));
                 const bool two = bc7_bands() > 1 && aux && !aux->single && aux->stream && nchunks >= 32;
                 const bool pilot = two && bc7_pilot_threshold() >= 0 && aux->mid;

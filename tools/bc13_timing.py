@@ -1,4 +1,4 @@
-"""BC1 / BC3 kernel time at 4096^2 and 16384^2 (HIP events around back-to-back launches); used by tools/gpu_probe_bc1.sh."""
+"""BC1 / BC3 kernel time at 4096^2 and 16384^2 (HIP events around back-to-back launches); used by tools/evidence.sh and the grid sweeps (tools/build_variant.sh + tools/gpu_variants.sh)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "intel-texture-works-plugin_amd"))
