@@ -77,11 +77,20 @@ def test_trampolines_equal_direct_calls_and_oracle(itw, gpu, oracle):
         assert np.array_equal(out, oracle.encode(fmt, img, prof).reshape(-1)), (fmt, prof)
 
 
+@pytest.fixture
+def slice_window(itw):
+    """itwSetSliceWindow for one test, back to the default afterwards."""
+    yield itw.lib().itwSetSliceWindow
+    itw.lib().itwSetSliceWindow(0)
+
+
 @pytest.mark.gpu
-def test_slice_loop_progress_and_abort(itw, gpu, oracle):
+def test_slice_loop_progress_and_abort(itw, gpu, oracle, slice_window):
     """IntelPlugin.cpp:851-879: `slices = w*h / slice_pixels`, progress polled before every slice but the first, a false
-    return stops the job and leaves the slices already written."""
+    return stops the job and leaves the slices already written -- with a window of one slice exactly those (the default window of so small
+    a job is one slice too; the environment matrix presets others, hence the explicit 1)."""
     from itw_amd import surfaces
+    slice_window(1)
     img = surfaces.ldr_smooth(128, 64)                        # 8192 px
     want = oracle.encode("bc7", img, "veryfast").reshape(-1)
     calls = []
@@ -108,13 +117,6 @@ def _default_window_rule():
     the asserts on the DEFAULT rule's values are then skipped; bytes and progress calls must hold either way."""
     import os
     return "ITW_SLICE_WINDOW" not in os.environ and os.environ.get("ITW_SLICED_PIPELINE", "1") != "0"
-
-
-@pytest.fixture
-def slice_window(itw):
-    """itwSetSliceWindow for one test, back to the default afterwards."""
-    yield itw.lib().itwSetSliceWindow
-    itw.lib().itwSetSliceWindow(0)
 
 
 @pytest.mark.gpu
