@@ -18,7 +18,8 @@ for o in $CS/build/*.o; do
   [ $skip = 0 ] && OBJS="$OBJS $o"
 done
 for s in $STEMS; do
-  /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $CS/$s.hip -o /tmp/variant_$NAME/$s.o &
+  PER=""; [ "$s" = bc7 ] && [ -z "${NO_PER_SOURCE:-}" ] && PER="-mllvm -amdgpu-sched-strategy=max-ilp"     # the Makefile's EXTRA_bc7 (NO_PER_SOURCE=1: without)
+  /opt/rocm/bin/hipcc $FLAGS $PER $EXTRA -c $CS/$s.hip -o /tmp/variant_$NAME/$s.o &
 done
 wait
 for s in $STEMS; do OBJS="$OBJS /tmp/variant_$NAME/$s.o"; done

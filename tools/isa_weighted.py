@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "intel-texture-works-plugin_amd", "csrc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-gpu-flush-denormals-to-zero",
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-slp-vectorize", "--cuda-device-only", "-S"]
+PER_SOURCE = {"bc7.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}      # csrc/Makefile EXTRA_<stem>
 TWO = {"v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_mov_b32", "v_mov_b64",
        "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_ashrrev_i32", "v_cndmask_b32", "v_add_u16", "v_sub_u16",
        "v_mul_lo_u16", "v_ashrrev_i16", "v_mul_f16", "v_mul_legacy_f32"}
@@ -54,7 +55,7 @@ def assembly(src, cache_dir="/tmp/isa_weighted"):
     key = hashlib.sha256((source_sha256() + src).encode()).hexdigest()[:16]
     out = os.path.join(cache_dir, f"{os.path.basename(src)}.{key}.s")
     if not os.path.exists(out):
-        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + FLAGS + ["-o", out, os.path.join(CSRC, src)], check=True,
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + FLAGS + PER_SOURCE.get(src, []) + ["-o", out, os.path.join(CSRC, src)], check=True,
                        stderr=subprocess.DEVNULL, cwd=CSRC)
     return open(out).read().split("\n")
 
