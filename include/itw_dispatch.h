@@ -86,7 +86,9 @@ void CompressImageBC6H_veryslow(const rgba_surface* input, uint8_t* output);
  * every slice before it -- is in `target`.  What a caller can observe of the difference:
  *   * when progress(i) returns false, slices < i are written like in the reference, and so may be up to W-1 slices after them (the
  *     rest of slice i-1's window); the window being encoded at that moment is drained and NOT copied back;
- *   * progress calls of one window arrive back to back.
+ *   * progress calls of one window arrive back to back;
+ *   * `progress` runs on the calling thread while later windows are in flight on that thread's streams and staging buffers: it must not
+ *     call back into this library on the same thread (Photoshop's SetProgress does not).
  * Several GPUs (`multithreaded` and GetProcessorCount() > 1, host memory): one pipeline PER GPU -- window k runs on worker k % n, each worker
  * on its own device, and the calling thread calls progress(i) once every window up to slice i-1's has arrived, i.e. still in order; on an
  * abort windows other GPUs had already finished further down the image stay written too.
