@@ -630,7 +630,8 @@ def sliced_side(itw_amd, size, make_surface):
                 row[key + "_Mpixels/s"] = round(w * h / ms / 1e3, 1)
                 row[key + "_bytes_equal_one_call"] = bool(np.array_equal(got, want))
                 if W == 0:
-                    row["window_slices"] = int(L.itwSliceWindow(code, w, h, 0))
+                    st7 = itw_amd.bc7_profile(prof) if fmt == "bc7" else None
+                    row["window_slices"] = int(L.itwSliceWindowFor(code, C.cast(C.byref(st7), C.c_void_p) if st7 is not None else None, w, h, 0))
                     row["progress_calls_per_run"] = len(calls) // 6
             L.itwSetSliceWindow(0)
             row["pipeline_over_one_call"] = round(one / row["pipeline_ms"], 3)

@@ -106,6 +106,9 @@ bool itwCompressImageSlicedEx(const rgba_surface* source, uint8_t* target, int64
  * (also env ITW_SLICED_PIPELINE=0).  itwSliceWindow reports what a call would use (0: the literal loop). */
 void itwSetSliceWindow(int slices);
 int  itwSliceWindow(int dxgi_format, int width, int height, int64_t slice_pixels);
+/* ... for given settings (bc7_enc_settings* / bc6h_enc_settings* / NULL): BC7 settings whose modes 1/3 scan every two-subset shape (`slow`, `alpha_slow`:
+ * twice the work per block) take windows twice as large, at most slices/4; itwSliceWindow is this with NULL (every preset the plugin selects). */
+int  itwSliceWindowFor(int dxgi_format, const void* settings, int width, int height, int64_t slice_pixels);
 
 /* Pad to multiples of 4 by edge replication (IntelPlugin.cpp:893-928): the step immediately before the ABI.
  * pixel_size = 4 (RGBA8) or 8 (RGBA16F).  Host version: returns a surface whose ptr was allocated with malloc()

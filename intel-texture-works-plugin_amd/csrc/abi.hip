@@ -305,6 +305,7 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
 }
 
 bool coalesce_small_call(const Job& j, const rgba_surface* src, uint8_t* dst, int64_t blocks);
+bool heavy_job(const Job& j);
 bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user, int fixed_window = 0,
                      const itw::SlicedPart* share = nullptr);
 
@@ -356,7 +357,8 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         const bool bc7w = j.fmt == Fmt::BC7 && blocks >= 524288 && !itw::bc7_has_order_verdict(*j.s7) && itw::bc7_staged_bands_ok();   // (`slow` keeps its runs: their host-side verdict picks the wide shape on photographs, 7.4 vs 8.6 ms as windows)
         const bool bc6w = j.fmt == Fmt::BC6H && blocks >= 262144 && j.s6->slow_mode;    // (the other BC6H profiles are PCIe-bound: 2.98 vs 3.02 ms, fewer copies win)
         if (bc7w || bc6w) {
-            int64_t windows = (blocks + 65536) / 131072;
+            const int64_t per_window = heavy_job(j) ? 262144 : 131072;
+            int64_t windows = (blocks + per_window / 2) / per_window;
             if (windows > by) windows = by;
             if (windows >= 2) { (void)compress_sliced(j, src, dst, (int)windows, nullptr, nullptr, 1); return; }
         }
@@ -551,24 +553,29 @@ int slice_window_setting()
     return W;
 }
 
-int slice_window(Fmt fmt, int64_t slice_blocks, int slices)
+// `heavy`: BC7 settings that scan every two-subset shape (`slow`, `alpha_slow`: bc7_scans_every_shape) -- twice the work per block and dependent
+// launch chains twice as long: windows twice as large, a quarter of the slices at most (4096^2 `slow`, ms per sliced call with 8 / 16 / 32 slices per
+// window: bench surface 5.91 / 5.57 / 5.86, photograph 8.18 / 7.62 / 7.73)
+int slice_window(Fmt fmt, int64_t slice_blocks, int slices, bool heavy)
 {
     int W = slice_window_setting();
     if (W <= 0) {
-        // BC7 / BC6H: a window must fill the chip (131 072 blocks = one block per lane of 2 waves per SIMD; two windows are in flight);
+        // BC7 / BC6H: a window must fill the chip (131 072 blocks = one block per lane of 2 waves per SIMD; up to three windows are in flight);
         // BC1 / BC3 / BC4 / BC5 are PCIe-bound: fewer, larger copies
-        const int64_t target = (fmt == Fmt::BC7 || fmt == Fmt::BC6H) ? 131072 : 262144;
+        const bool compute = fmt == Fmt::BC7 || fmt == Fmt::BC6H;
+        const int64_t target = (compute && !heavy) ? 131072 : 262144;
         const int64_t per = slice_blocks < 1 ? 1 : slice_blocks;
         W = (int)((target + per / 2) / per);
         // the caller's progress bar keeps >= 8 real steps (>= 4 for the PCIe-bound formats, where a window is two pageable copies of ~40 us
-        // fixed cost each: 4096^2 BC1 runs at 8 200 Mpix/s with 8 windows, 11 200 with 4, 12 100 as one call; profiles/r06a_sliced_timing.jsonl)
-        const int cap = slices / ((fmt == Fmt::BC7 || fmt == Fmt::BC6H) ? 8 : 4);
+        // fixed cost each: 4096^2 BC1 runs at 8 200 Mpix/s with 8 windows, 11 200 with 4, 12 100 as one call; and for the heavy BC7 profiles)
+        const int cap = slices / ((compute && !heavy) ? 8 : 4);
         if (W > cap) W = cap;
     }
     if (W < 1) W = 1;
     if (W > slices) W = slices;
     return W;
 }
+bool heavy_job(const Job& j) { return j.fmt == Fmt::BC7 && j.s7 && itw::bc7_scans_every_shape(*j.s7); }
 
 struct SliceRows { int64_t y0, y1; };
 // rows of slice i of `slices` (IntelPlugin.cpp:861-865); the formats that keep partial blocks end the last slice at `height`
@@ -608,7 +615,7 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
     const size_t out_bytes = (size_t)bx * by * bpb;
     const bool src_dev = is_device_pointer(src->ptr), dst_dev = is_device_pointer(dst);
 
-    const int W = fixed_window > 0 ? (fixed_window < slices ? fixed_window : slices) : slice_window(j.fmt, (int64_t)bx * by / slices, slices);
+    const int W = fixed_window > 0 ? (fixed_window < slices ? fixed_window : slices) : slice_window(j.fmt, (int64_t)bx * by / slices, slices, heavy_job(j));
     const int nwin = (slices + W - 1) / W;
     const int part = share ? share->part : 0, parts = share ? (share->parts < 1 ? 1 : share->parts) : 1;
     const int nlocal = part < nwin ? (nwin - part + parts - 1) / parts : 0;       // this thread's windows: part, part + parts, ...
@@ -991,9 +998,9 @@ bool sliced_part(const rgba_surface* source, uint8_t* target, int dxgi_format, c
     return ok && done;
 }
 
-int sliced_windows(int dxgi_format, int width, int height, int64_t slice_pixels, int* window_slices)
+int sliced_windows(int dxgi_format, const void* settings, int width, int height, int64_t slice_pixels, int* window_slices)
 {
-    const int W = itwSliceWindow(dxgi_format, width, height, slice_pixels);
+    const int W = itwSliceWindowFor(dxgi_format, settings, width, height, slice_pixels);
     if (window_slices) *window_slices = W;
     if (W <= 0) return 0;
     if (slice_pixels <= 0) slice_pixels = 0x40000;
@@ -1073,7 +1080,9 @@ bool itwCompressImageSlicedEx(const rgba_surface* source, uint8_t* target, int64
 
 void itwSetSliceWindow(int slices) { g_slice_window.store(slices < 0 ? -1 : slices, std::memory_order_relaxed); }
 
-int itwSliceWindow(int dxgi_format, int width, int height, int64_t slice_pixels)
+int itwSliceWindow(int dxgi_format, int width, int height, int64_t slice_pixels) { return itwSliceWindowFor(dxgi_format, nullptr, width, height, slice_pixels); }
+
+int itwSliceWindowFor(int dxgi_format, const void* settings, int width, int height, int64_t slice_pixels)
 {
     if (slice_window_setting() < 0) return 0;
     if (slice_pixels <= 0) slice_pixels = 0x40000;
@@ -1084,7 +1093,9 @@ int itwSliceWindow(int dxgi_format, int width, int height, int64_t slice_pixels)
     const int64_t blocks = keep ? (int64_t)((width + 3) / 4) * ((height + 3) / 4) : (int64_t)(width / 4) * (height / 4);
     const bool heavy = dxgi_format == ITW_DXGI_FORMAT_BC7_UNORM || dxgi_format == ITW_DXGI_FORMAT_BC7_UNORM_SRGB ||
                        dxgi_format == ITW_DXGI_FORMAT_BC6H_UF16 || dxgi_format == ITW_DXGI_FORMAT_BC6H_SF16;
-    return slice_window(heavy ? Fmt::BC7 : Fmt::BC1, blocks / slices, (int)slices);
+    const bool bc7 = dxgi_format == ITW_DXGI_FORMAT_BC7_UNORM || dxgi_format == ITW_DXGI_FORMAT_BC7_UNORM_SRGB;
+    const bool every_shape = bc7 && settings && itw::bc7_scans_every_shape(*static_cast<const bc7_enc_settings*>(settings));
+    return slice_window(heavy ? Fmt::BC7 : Fmt::BC1, blocks / slices, (int)slices, every_shape);
 }
 
 void  itwSetStream(void* s) { tls.user_stream = (hipStream_t)s; }

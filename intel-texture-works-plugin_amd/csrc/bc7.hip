@@ -2125,6 +2125,8 @@ static FusedLayout fused_layout(size_t n, const FusedNeeds& need)
     W.words = o;
     return W;
 }
+bool bc7_scans_every_shape(const bc7_enc_settings& s) { return fused_needs(&s).bands; }
+
 size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks, const bc7_enc_settings* settings)
 {
     const size_t n = (size_t)(width / 4) * (size_t)(height / 4);

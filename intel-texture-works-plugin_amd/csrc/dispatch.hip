@@ -281,7 +281,7 @@ static bool sliced_on_pool(const rgba_surface* source, uint8_t* target, int dxgi
     Pool* p = pool();
     const int n = (int)p->threads.size();
     int W = 1;
-    const int nwin = itw::sliced_windows(dxgi_format, source->width, source->height, slice_pixels, &W);
+    const int nwin = itw::sliced_windows(dxgi_format, settings, source->width, source->height, slice_pixels, &W);
     struct Shared {
         std::mutex m; std::condition_variable cv;
         std::vector<char> arrived;

@@ -50,7 +50,7 @@ struct SlicedPart {
 // the share `part` of the slice loop over `source` (format, settings and slice size as itwCompressImageSlicedEx takes them); false: stopped or failed
 bool sliced_part(const rgba_surface* source, uint8_t* target, int dxgi_format, const void* settings, int64_t slice_pixels, const SlicedPart& part);
 // windows a call is cut into, and W (slices per window); 0 windows: the pipeline is off
-int sliced_windows(int dxgi_format, int width, int height, int64_t slice_pixels, int* window_slices);
+int sliced_windows(int dxgi_format, const void* settings, int width, int height, int64_t slice_pixels, int* window_slices);
 
 // One predicate for "the kernels can dereference this pointer": device AND managed allocations (abi.hip and
 // dispatch.hip/decode.hip used to disagree on managed memory).  Unregistered host memory -> false.

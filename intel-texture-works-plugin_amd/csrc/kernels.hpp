@@ -25,6 +25,7 @@ size_t bc7_workspace_bytes(int width, int height, int64_t wide_max_blocks = 0, c
 // BC7 launch shape: 0 = by call size (default), 1 = deep (one lane per block, a launch pair per mode family: fills the
 // chip on whole surfaces), 2 = wide (split scans + ordered argmin: small calls).  Same blocks either way.
 void set_bc7_path(int path);
+bool bc7_scans_every_shape(const bc7_enc_settings& s);  // the settings take the bounded mode order (modes 1/3 -- and 7 -- scan all 64 shapes: `slow`, `alpha_slow`): about twice the work per block
 bool bc7_has_order_verdict(const bc7_enc_settings& s);   // the settings run the bounded order of the RGB profiles (the one with a pilot's estimate)
 bool bc7_staged_bands_ok();      // the staged runs of a host-pointer call may run as overlapped deep bands (not when the wide shape is forced / ITW_STAGED_BANDS=0)
 // The pilot of the bounded BC7 mode order (bc7.hip, launch_bc7): percent of the blocks the pilot looks at that its estimate may list for modes 1/3 for the rest of

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = tuple(
     + ["GetProcessorCount", "InitWin32Threads", "DestroyThreads", "GetBytesPerBlock", "CompressImageMT", "CompressImageST",
        "CompressImageBC1", "CompressImageBC3", "CompressImageBC4", "CompressImageBC5"]
     + ["CompressImageBC7_" + p for p in BC7_PROFILES] + ["CompressImageBC6H_" + p for p in BC6H_PROFILES]
-    + ["itwCompressImageSliced", "itwCompressImageSlicedEx", "itwSetSliceWindow", "itwSliceWindow", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
+    + ["itwCompressImageSliced", "itwCompressImageSlicedEx", "itwSetSliceWindow", "itwSliceWindow", "itwSliceWindowFor", "itwPadToMultipleOf4", "itwFreeSurface", "itwPadToMultipleOf4Device",
        "itwConvertToRGBA8Device", "itwConvertToRGBA16FDevice"]
     # include/itw_multigpu.h: one surface over all GPUs, one process
     + ["itwMultiGpuRanks", "itwMultiGpuTransport", "itwMultiGpuPeerLinks", "itwCompressImageMultiGPU", "itwCompressImageMultiGPUEx", "itwCompressImageMultiGPUBands",
@@ -188,6 +188,8 @@ def _load(path, hooks):
         L.itwSetSliceWindow.restype = None
         L.itwSliceWindow.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int64]
         L.itwSliceWindow.restype = C.c_int
+        L.itwSliceWindowFor.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64]
+        L.itwSliceWindowFor.restype = C.c_int
         L.itwMultiGpuRanks.restype = C.c_int
         L.itwMultiGpuSetInterleave.argtypes = [C.c_int]
         L.itwMultiGpuSetInterleave.restype = None

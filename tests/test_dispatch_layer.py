@@ -48,6 +48,13 @@ def test_slice_window_rule(itw):
         assert L.itwSliceWindow(98, 1024, 1024, 0) == 1 and L.itwSliceWindow(98, 2048, 2048, 0) == 2      # 4 / 16 slices: the 1/8 cap binds
         assert L.itwSliceWindow(98, 4096, 4096, 1 << 20) == 2                                            # 16 slices of 65 536 blocks
         assert L.itwSliceWindow(98, 64, 64, 0) == 1                                                      # one slice
+        # BC7 settings whose modes 1/3 scan every two-subset shape (twice the work per block): windows twice as large, <= slices / 4
+        for name, want in (("slow", 16), ("alpha_slow", 16), ("basic", 8), ("veryfast", 8), ("alpha_basic", 8)):
+            st = itw.bc7_profile(name)
+            assert L.itwSliceWindowFor(98, C.cast(C.byref(st), C.c_void_p), 4096, 4096, 0) == want, name
+        st = itw.bc7_profile("slow")
+        assert L.itwSliceWindowFor(98, C.cast(C.byref(st), C.c_void_p), 2048, 2048, 0) == 4               # 16 slices: the 1/4 cap
+        assert L.itwSliceWindowFor(71, None, 4096, 4096, 0) == L.itwSliceWindow(71, 4096, 4096, 0) == 16
         L.itwSetSliceWindow(5)
         assert L.itwSliceWindow(98, 4096, 4096, 0) == 5 and L.itwSliceWindow(98, 1024, 1024, 0) == 4     # clamped to the slice count
         L.itwSetSliceWindow(-1)

@@ -30,6 +30,14 @@ def time_call(fn, reps):
     return best * 1e3
 
 
+def _window(L, fmt, prof, fcode, w, h):
+    """W of the call (BC7 settings that scan every two-subset shape take larger windows: itwSliceWindowFor)"""
+    if fmt == "bc7":
+        st = itw_amd.bc7_profile(prof)
+        return L.itwSliceWindowFor(fcode, C.cast(C.byref(st), C.c_void_p), w, h, 0)
+    return L.itwSliceWindow(fcode, w, h, 0)
+
+
 def main():
     size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
@@ -69,7 +77,7 @@ def main():
             ms = time_call(run, reps)
             slices = max(1, w * h // 0x40000)
             per_run = len(calls) // (reps + 1)
-            print(json.dumps({"trampoline": name, "shape": "literal loop" if W < 0 else "pipeline", "window": L.itwSliceWindow(fcode, w, h, 0),
+            print(json.dumps({"trampoline": name, "shape": "literal loop" if W < 0 else "pipeline", "window": _window(L, fmt, prof, fcode, w, h),
                               "slices": slices, "progress_calls": per_run, "ms": round(ms, 3), "mpix_s": round(mpix / ms * 1e3, 1),
                               "bytes_equal_one_call": bool(np.array_equal(out, want))}), flush=True)
         L.itwSetSliceWindow(0)
