@@ -307,7 +307,7 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
 bool coalesce_small_call(const Job& j, const rgba_surface* src, uint8_t* dst, int64_t blocks);
 bool heavy_job(const Job& j);
 bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user, int fixed_window = 0,
-                     const itw::SlicedPart* share = nullptr);
+                     const itw::SlicedPart* share = nullptr, bool leave_verdict = false);
 
 // texel rows of a host surface into the tight staging image
 void upload_rows(uint8_t* d_rows, size_t pitch, const uint8_t* hs, int64_t stride, size_t row_bytes, size_t nrows, hipStream_t copy)
@@ -354,13 +354,17 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
     // `alpha_veryfast` 2.46 -> 2.0, `basic` 3.93 -> 3.6 (profiles/r06_host_pointer_path.txt, r06_sliced_timing.jsonl).  The tuning knobs of the runs keep the runs.
     if (!src_dev && !dst_dev && !keep_partial && !std::getenv("ITW_HOST_CHUNKS") && !std::getenv("ITW_HOST_RUNS") && !std::getenv("ITW_HOST_WINDOWS_OFF")) {
         const int64_t blocks = (int64_t)bx * by;
-        const bool bc7w = j.fmt == Fmt::BC7 && blocks >= 524288 && !itw::bc7_has_order_verdict(*j.s7) && itw::bc7_staged_bands_ok();   // (`slow` keeps its runs: their host-side verdict picks the wide shape on photographs, 7.4 vs 8.6 ms as windows)
+        // A profile WITH an order verdict (`slow`) takes the windows while the last estimate says the bounded order pays (each window runs it on one
+        // stream: 5.6 against 6.05 ms for the staged runs below on the bench surface) and the staged runs -- whose remaining runs go wide -- while it
+        // says nearly every block needs modes 1/3 (photographs: 7.3 against 7.6 ms as windows).  Either way the call leaves a fresh estimate.
+        const bool verdict_profile = j.fmt == Fmt::BC7 && itw::bc7_has_order_verdict(*j.s7);
+        const bool bc7w = j.fmt == Fmt::BC7 && blocks >= 524288 && itw::bc7_staged_bands_ok() && (!verdict_profile || !tls.staged_wide);
         const bool bc6w = j.fmt == Fmt::BC6H && blocks >= 262144 && j.s6->slow_mode;    // (the other BC6H profiles are PCIe-bound: 2.98 vs 3.02 ms, fewer copies win)
         if (bc7w || bc6w) {
             const int64_t per_window = heavy_job(j) ? 262144 : 131072;
             int64_t windows = (blocks + per_window / 2) / per_window;
             if (windows > by) windows = by;
-            if (windows >= 2) { (void)compress_sliced(j, src, dst, (int)windows, nullptr, nullptr, 1); return; }
+            if (windows >= 2) { (void)compress_sliced(j, src, dst, (int)windows, nullptr, nullptr, 1, nullptr, bc7w && verdict_profile); return; }
         }
     }
 
@@ -593,8 +597,10 @@ SliceRows slice_rows(int i, int slices, int height, bool keep_partial)
 // `fixed_window` > 0 fixes W (compress() passes 1: its "slices" are the windows).
 // `share`: this thread runs only the windows share->part, + share->parts, ... (one pipeline per GPU of the pool, dispatch.hip) and reports them
 // through share->retired instead of polling `progress`.
+// `leave_verdict` (BC7 profiles with an order verdict, whole-surface host-pointer calls): the first window also counts the pilot's estimate, and the
+// call ends by reading it into tls.staged_wide -- what the NEXT such call's shape goes by (compress()).
 bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user, int fixed_window,
-                     const itw::SlicedPart* share)
+                     const itw::SlicedPart* share, bool leave_verdict)
 {
     if (!src) itw::fail_msg("null surface");
     const int w = src->width, h = src->height;
@@ -680,7 +686,8 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
             ITW_CHECK(hipEventRecord(tls.ev_in[k & 7], cs));
             ITW_CHECK(hipStreamWaitEvent(ks, tls.ev_in[k & 7], 0));
         }
-        launch(j, d_src + v.y0 * d_stride, d_stride, w, (int)nrows, d_dst + (size_t)v.row0 * bx * bpb, ks, true, j.fmt == Fmt::BC7 ? 1 : -1, ws_off[k & 1]);
+        launch(j, d_src + v.y0 * d_stride, d_stride, w, (int)nrows, d_dst + (size_t)v.row0 * bx * bpb, ks, true, j.fmt == Fmt::BC7 ? ((leave_verdict && i == 0) ? 0 : 1) : -1,
+               ws_off[k & 1]);
         ITW_CHECK(hipEventRecord(tls.ev_done[k & 7], ks));
     };
     auto retire = [&](int i) {                            // the window's bytes into `dst`; returns when they are there
@@ -707,6 +714,11 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
         const Window v = window(part + i * parts);
         if (share) { if (share->retired) share->retired(v.s0, v.s1, share->ctx); }
         else if (!poll(v.s0 + 1, v.s1)) return false;    // the windows behind it are in flight: ~Drain waits for them, their bytes are not copied back
+    }
+    if (leave_verdict && tls.verdict.valid) {            // the first window's estimate, for the next call (its kernel is long done: every window has been retired)
+        ITW_CHECK(hipEventSynchronize(tls.verdict.event));
+        const int32_t listed = tls.verdict.host_counts[0], sampled = tls.verdict.host_counts[1];
+        if (sampled > 0) tls.staged_wide = (int64_t)listed * 100 > (int64_t)staged_verdict_percent() * sampled;
     }
     return true;
 }
