@@ -734,15 +734,20 @@ __device__ __forceinline__ void search_two_subset(Lane& ln, const bc7_enc_settin
         int32_t top[16];
         #pragma unroll
         for (int i = 0; i < 16; i++) top[i] = 0x7fffffff;
+        const int nlist = min(max(na, nb), 16);                   // entries of the ranked list that will be read (wave-uniform)
         for (int part = 0; part < 64; part++) {
             ln.tx.fence();
             const int32_t key = rank_key<RANK_CH>(part, ln.tx, rfull, ln.T);
             if (RANKED == 1) {
                 ln.keys[part * TPB] = key;
             } else {
-                int32_t x = key;                                 // sorted insertion, 16 compare-exchanges
-                #pragma unroll
-                for (int i = 0; i < 16; i++) { const int32_t lo = min(top[i], x); x = max(top[i], x); top[i] = lo; }
+                // sorted insertion into the `nlist` smallest keys seen so far: a chain of compare-exchanges as long as the list the settings ask
+                // for, in steps of four (wave-uniform: three scalar branches; `veryfast` keeps 3 keys, not 16: 24 of 32 VALU per shape saved)
+                int32_t x = key;
+#define ITW_INS4(b) { _Pragma("unroll") for (int i = (b); i < (b) + 4; i++) { const int32_t lo = min(top[i], x); x = max(top[i], x); top[i] = lo; } }
+                ITW_INS4(0)
+                if (nlist > 4) { ITW_INS4(4) if (nlist > 8) { ITW_INS4(8) if (nlist > 12) ITW_INS4(12) } }
+#undef ITW_INS4
             }
         }
         const int n = min(max(na, nb), RANKED == 1 ? 64 : 16);
