@@ -798,7 +798,10 @@ struct Combiner {
 };
 constexpr int kMaxDevices = 64;
 Combiner g_combiner[kMaxDevices];
-constexpr int64_t kCoalesceMaxBlocks = 65536;     // larger calls fill the chip on their own
+// Calls up to this size are combined.  65 536 until round 6 ("larger calls fill the chip on their own") -- but eight pool threads handing over a 4096^2
+// surface make eight concurrent calls of 131 072 blocks, each staging through its own thread's buffers and streams: BC7 `slow` 7.8 ms against 5.8 for one
+// call, `basic` 4.06 against 3.72 (profiles/r06_reference_caller_timing.jsonl before the change).  Merged they are one call, which takes the windows.
+constexpr int64_t kCoalesceMaxBlocks = 524288;       // (two pool threads halve a 4096^2 surface into calls of this size)
 
 bool coalescing_enabled()
 {
