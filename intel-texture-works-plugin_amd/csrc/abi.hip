@@ -306,6 +306,7 @@ void launch(const Job& j, const uint8_t* d_src, int64_t stride, int w, int h, ui
 
 bool coalesce_small_call(const Job& j, const rgba_surface* src, uint8_t* dst, int64_t blocks);
 bool heavy_job(const Job& j);
+static int64_t bc7_window_min_blocks() { static const int64_t v = [] { const char* e = std::getenv("ITW_BC7_WINDOW_MIN"); return e ? (int64_t)std::atoll(e) : (int64_t)262144; }(); return v; }   // BC7 host-pointer calls from this size take windows (2048^2 `basic` 1.28 -> 1.17 ms, 2896^2 2.46 -> 1.97, `slow` 4.24 -> 3.13)
 bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int slices, ItwProgressFunc* progress, void* user, int fixed_window = 0,
                      const itw::SlicedPart* share = nullptr, bool leave_verdict = false);
 
@@ -358,7 +359,7 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
         // stream: 5.6 against 6.05 ms for the staged runs below on the bench surface) and the staged runs -- whose remaining runs go wide -- while it
         // says nearly every block needs modes 1/3 (photographs: 7.3 against 7.6 ms as windows).  Either way the call leaves a fresh estimate.
         const bool verdict_profile = j.fmt == Fmt::BC7 && itw::bc7_has_order_verdict(*j.s7);
-        const bool bc7w = j.fmt == Fmt::BC7 && blocks >= 524288 && itw::bc7_staged_bands_ok() && (!verdict_profile || !tls.staged_wide);
+        const bool bc7w = j.fmt == Fmt::BC7 && blocks >= bc7_window_min_blocks() && itw::bc7_staged_bands_ok() && (!verdict_profile || !tls.staged_wide);
         const bool bc6w = j.fmt == Fmt::BC6H && blocks >= 262144 && j.s6->slow_mode;    // (the other BC6H profiles are PCIe-bound: 2.98 vs 3.02 ms, fewer copies win)
         if (bc7w || bc6w) {
             const int64_t per_window = heavy_job(j) ? 262144 : 131072;
