@@ -82,7 +82,8 @@ void CompressImageBC6H_veryslow(const rgba_surface* input, uint8_t* output);
  * The reference encodes slice i between progress(i) and progress(i+1), one synchronous CompressImageMT/ST call each.  Here, when
  * `cmpFunc` is one of THIS library's CompressImage* trampolines, the slices run as a PIPELINE instead:
  * W consecutive slices form a window (upload, kernels and download of neighbouring windows overlap on three streams; W =
- * itwSliceWindow(...), at most slices/8 -- slices/4 for BC1/BC3/BC4/BC5 -- so a progress bar keeps real steps), and progress(i) is called once slice i-1 -- and
+ * itwSliceWindow(...): about 131 072 blocks, 262 144 for BC1/BC3/BC4/BC5 -- 0.3-1 ms of work, so any job long enough to show a progress bar
+ * has many windows), and progress(i) is called once slice i-1 -- and
  * every slice before it -- is in `target`.  What a caller can observe of the difference:
  *   * when progress(i) returns false, slices < i are written like in the reference, and so may be up to W-1 slices after them (the
  *     rest of slice i-1's window); the window being encoded at that moment is drained and NOT copied back;
@@ -107,7 +108,7 @@ bool itwCompressImageSlicedEx(const rgba_surface* source, uint8_t* target, int64
 void itwSetSliceWindow(int slices);
 int  itwSliceWindow(int dxgi_format, int width, int height, int64_t slice_pixels);
 /* ... for given settings (bc7_enc_settings* / bc6h_enc_settings* / NULL): BC7 settings whose modes 1/3 scan every two-subset shape (`slow`, `alpha_slow`:
- * twice the work per block) take windows twice as large, at most slices/4; itwSliceWindow is this with NULL (every preset the plugin selects). */
+ * twice the work per block) take windows twice as large; itwSliceWindow is this with NULL (every preset the plugin selects). */
 int  itwSliceWindowFor(int dxgi_format, const void* settings, int width, int height, int64_t slice_pixels);
 
 /* Pad to multiples of 4 by edge replication (IntelPlugin.cpp:893-928): the step immediately before the ABI.

@@ -535,8 +535,8 @@ void compress(const Job& j, const rgba_surface* src, uint8_t* dst, bool may_coal
 // IntelPlugin.cpp:851-879 cuts a save into 0x40000-pixel slices and makes one synchronous CompressImageMT/ST call per slice, polling
 // SetProgress between them.  Restated literally on a GPU every slice is upload -> a latency-bound launch chain over 1/64 of the
 // chip-filling work -> download -> synchronise (BC7 `basic`: 1 274 Mpix/s against 4 175 for one call over the surface).  Here the same
-// slices, progress calls and early out run as a PIPELINE: consecutive slices form a WINDOW (the unit of upload / launch / download; at
-// most an eighth of the slices -- a quarter for the PCIe-bound formats --, so the progress bar keeps real steps), window k's kernels run on stream k % 2 with its
+// slices, progress calls and early out run as a PIPELINE: consecutive slices form a WINDOW (the unit of upload / launch / download: about 131 072 blocks, 262 144 for the PCIe-bound formats and the heavy BC7 settings),
+// window k's kernels run on stream k % 2 with its
 // upload and the previous window's download on the copy stream, and `progress(i, slices)` is called for every slice i of a window -- in
 // order, each call only after the slices before it are in `target` -- once that window's bytes have arrived.  A false return stops the
 // job: nothing further is issued or copied back, the one window in flight is drained, and every slice below i (and the rest of i's own
@@ -559,7 +559,7 @@ int slice_window_setting()
 }
 
 // `heavy`: BC7 settings that scan every two-subset shape (`slow`, `alpha_slow`: bc7_scans_every_shape) -- twice the work per block and dependent
-// launch chains twice as long: windows twice as large, a quarter of the slices at most (4096^2 `slow`, ms per sliced call with 8 / 16 / 32 slices per
+// launch chains twice as long: windows twice as large (4096^2 `slow`, ms per sliced call with 8 / 16 / 32 slices per
 // window: bench surface 5.91 / 5.57 / 5.86, photograph 8.18 / 7.62 / 7.73)
 int slice_window(Fmt fmt, int64_t slice_blocks, int slices, bool heavy)
 {
@@ -571,10 +571,9 @@ int slice_window(Fmt fmt, int64_t slice_blocks, int slices, bool heavy)
         const int64_t target = (compute && !heavy) ? 131072 : 262144;
         const int64_t per = slice_blocks < 1 ? 1 : slice_blocks;
         W = (int)((target + per / 2) / per);
-        // the caller's progress bar keeps >= 8 real steps (>= 4 for the PCIe-bound formats, where a window is two pageable copies of ~40 us
-        // fixed cost each: 4096^2 BC1 runs at 8 200 Mpix/s with 8 windows, 11 200 with 4, 12 100 as one call; and for the heavy BC7 profiles)
-        const int cap = slices / ((compute && !heavy) ? 8 : 4);
-        if (W > cap) W = cap;
+        // No cap by slice count (the first version kept >= 8 windows per job): a window is 0.3-1 ms of work, so a job long enough to show a
+        // progress bar has many; and windows SMALLER than the target run the deep launch shape on a fraction of the chip -- 2048^2 `basic` with 8
+        // windows of 32 768 blocks 1.79 ms, with 2 of 131 072 1.13 (one call 1.16); 1024^2 with 4 windows 1.12 ms, as one 0.48 (literal loop 0.85).
     }
     if (W < 1) W = 1;
     if (W > slices) W = slices;
@@ -627,6 +626,12 @@ bool compress_sliced(const Job& j, const rgba_surface* src, uint8_t* dst, int sl
     const int part = share ? share->part : 0, parts = share ? (share->parts < 1 ? 1 : share->parts) : 1;
     const int nlocal = part < nwin ? (nwin - part + parts - 1) / parts : 0;       // this thread's windows: part, part + parts, ...
     if (nlocal == 0) return true;
+    if (nwin == 1 && !share && fixed_window == 0) {
+        // one window = the whole surface: the ordinary call (which picks its launch shape by size: the wide one for small surfaces), then the polls
+        compress(j, src, dst, false);
+        if (src_dev && dst_dev) ITW_CHECK(hipStreamSynchronize(tls.user_stream));
+        return poll(1, slices - 1);
+    }
 
     ensure_device_ctx();
     ensure_bc7_aux();
