@@ -1171,7 +1171,8 @@ __device__ __forceinline__ void load_win(Win& w, const uint4* __restrict__ wins,
 }
 
 // Register budgets (waves per SIMD) were picked by measurement on MI355X: the scans are bound by dependent-issue
-// and LDS latency at 2 waves, and tolerate a few spilled cold values to reach 3-4.
+// and LDS latency at 2 waves, and tolerate a few spilled cold values to reach 3-4.  Re-swept in round 6 under the max-ILP schedule
+// (profiles/r06_rejected_experiments.txt, item 10): only the unranked mode 7 scan moved, 3 -> 4 (alpha_slow -3...-5 %).
 #ifndef SW02
 #define SW02 4
 #endif
@@ -1182,7 +1183,7 @@ __device__ __forceinline__ void load_win(Win& w, const uint4* __restrict__ wins,
 #define SWALL 4
 #endif
 #ifndef SW7
-#define SW7 3
+#define SW7 4
 #endif
 #ifndef SWR
 #define SWR 2
@@ -1396,7 +1397,8 @@ __device__ __forceinline__ int32_t sel_chunk(const ChunkSel& s, int32_t i)
 }
 
 // FAM7 = false: the three-channel families {0,2} and {1,3} (4 waves per SIMD; ranked lists 3); FAM7 = true: the mode 7 scan
-// alone (four-channel fits need the registers of 3 waves per SIMD; sharing a kernel with the others made those spill).
+// alone (four-channel fits need more registers; sharing a kernel with the others made those spill.  Unranked 4 waves since the
+// max-ILP schedule, ranked lists 2).
 __host__ __device__ constexpr int scan_all_waves(bool ranked, bool fam7) { return fam7 ? (ranked ? SWR27 : SW7) : (ranked ? SWR2 : SWALL); }
 template <bool VEC16, bool RANKED_LISTS, bool FAM7>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(scan_all_waves(RANKED_LISTS, FAM7), scan_all_waves(RANKED_LISTS, FAM7))))
