@@ -6,6 +6,8 @@
 #              the reference's own win32Threads.cpp driving the library, mode-order policy by content, one call's kernel timeline
 #     bench    python bench.py (default flags) and the 16384^2 geometry on one GPU
 #     profile  tools/profile_gpu.sh <tag>: rocprofv3 kernel stats, PMC traffic, SQ counters (every plugin preset included)
+#     long     the long campaigns: 16 Mpix of every format and preset, 64 Mpix per BC7 slow profile (4 M blocks per call), 1 200 + 1 200 random
+#              settings structs, and a second seed of the 4 Mpix campaign against the reference's own kernel source
 #     matrix   tools/gpu_env_matrix.sh: the BC7 / BC6H / dispatch / host-pointer suites under every environment switch
 # Afterwards, in the build container:  python tools/summarize_profiles.py <tag>  &&  python tools/collect_evidence.py <tag>
 # copy the summaries into profiles/<tag>_* (counter files into profiles/<tag>_counters/).  Lab scripts of earlier rounds: tools/history/.
@@ -52,6 +54,12 @@ bench)
   ;;
 profile)
   bash tools/profile_gpu.sh $TAG > gpurun_out/profile_gpu_$TAG.log 2>&1; tail -3 gpurun_out/profile_gpu_$TAG.log
+  ;;
+long)
+  timeout 2400 python tools/parity_campaign.py 16 > $OUT/parity_campaign_16Mpix_all_formats.txt 2>&1; tail -n 1 $OUT/parity_campaign_16Mpix_all_formats.txt
+  timeout 1500 python tools/parity_campaign.py 64 oracle bc7 slow,alpha_slow > $OUT/parity_campaign_64Mpix_bc7_slow_profiles.txt 2>&1; tail -n 1 $OUT/parity_campaign_64Mpix_bc7_slow_profiles.txt
+  timeout 1500 python tools/gpu_settings_fuzz.py 1200 6 > $OUT/gpu_settings_fuzz_1200.txt 2>&1; tail -n 1 $OUT/gpu_settings_fuzz_1200.txt
+  CAMPAIGN_SEED=7 timeout 1500 python tools/parity_campaign.py 4 ref bc7,bc1,bc3,bc6h > $OUT/parity_campaign_4Mpix_vs_reference_kernel_seed7.txt 2>&1; tail -n 1 $OUT/parity_campaign_4Mpix_vs_reference_kernel_seed7.txt
   ;;
 matrix)
   bash tools/gpu_env_matrix.sh > /dev/null 2>&1; cp gpurun_out/env_matrix/result.txt $OUT/env_matrix.txt; grep -c passed $OUT/env_matrix.txt

@@ -3,7 +3,8 @@ content -- smooth + noise, uniform random bytes, posterised (tie-heavy), real al
 bit for bit with the multi-threaded scalar oracle.  Prints one line per case and a summary; exit code 1 on any mismatch.
 Usage: python tools/parity_campaign.py [megapixels_per_case] [oracle|ref] [fmt,fmt,...] [profile,...]   (default 2, oracle, every format; the oracle needs ~1 s per
 Mpix of BC7 slow on 16 cores).  `ref`: the checker is the reference's own kernel.ispc built as a scalar program
-(oracle/_ref/libispc_texcomp_ref_full.so) instead of the oracle's restatement; BC4/BC5, which kernel.ispc does not have, stay on the oracle."""
+(oracle/_ref/libispc_texcomp_ref_full.so) instead of the oracle's restatement; BC4/BC5, which kernel.ispc does not have, stay on the oracle.
+CAMPAIGN_SEED=<n> (default 2026) reseeds the random parts of the content."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "intel-texture-works-plugin_amd"))
@@ -18,10 +19,12 @@ if CHECKER == "ref":
     from oracle import pyref
 W = 2048
 H = max(4, int(mp * 1e6 / W) // 4 * 4)
-rng = np.random.default_rng(2026)
+CSEED = int(os.environ.get("CAMPAIGN_SEED", "2026"))           # another seed = other smooth fields, random bytes, alpha mixes
+rng = np.random.default_rng(CSEED)
+OFF = CSEED - 2026
 
 def posterised(h, w, levels):
-    img = surfaces.ldr_smooth(h, w, seed=surfaces.SEED + 17)
+    img = surfaces.ldr_smooth(h, w, seed=surfaces.SEED + 17 + OFF)
     step = 256 // levels
     return ((img // step) * step + step // 2).astype(np.uint8)
 
@@ -41,7 +44,7 @@ def mixed_ldr(h, w):
             col = np.tile(t[:, :tw], (-(-q // t.shape[0]), 1, 1))[:q]
             nat[:, x:x + tw] = col
             x += tw
-    parts = [surfaces.ldr_smooth(q, w, seed=surfaces.SEED + 31).copy(), rng.integers(0, 256, size=(q, w, 4), dtype=np.uint8),
+    parts = [surfaces.ldr_smooth(q, w, seed=surfaces.SEED + 31 + OFF).copy(), rng.integers(0, 256, size=(q, w, 4), dtype=np.uint8),
              posterised(q, w, 4), nat, posterised(h - 4 * q, w, 2)]
     # alpha of the smooth quarter: real alpha | opaque | 254/255 speckles | per-block mix -- the RGBA profiles' order of
     # mode groups and the skipped RGB scans (bc7_finish_all) see whole waves of each kind and mixed ones
@@ -54,7 +57,7 @@ def mixed_ldr(h, w):
 
 def mixed_hdr(h, w):
     q = h // 2 // 4 * 4
-    a = surfaces.hdr_smooth(q, w, seed=surfaces.SEED + 41)
+    a = surfaces.hdr_smooth(q, w, seed=surfaces.SEED + 41 + OFF)
     b = rng.integers(0, 65536, size=(h - q, w, 4), dtype=np.uint16)     # NaN / inf / negative halves included
     return np.ascontiguousarray(np.concatenate([a, b], axis=0))
 
