@@ -59,6 +59,8 @@ long)
   timeout 2400 python tools/parity_campaign.py 16 > $OUT/parity_campaign_16Mpix_all_formats.txt 2>&1; tail -n 1 $OUT/parity_campaign_16Mpix_all_formats.txt
   timeout 1500 python tools/parity_campaign.py 64 oracle bc7 slow,alpha_slow > $OUT/parity_campaign_64Mpix_bc7_slow_profiles.txt 2>&1; tail -n 1 $OUT/parity_campaign_64Mpix_bc7_slow_profiles.txt
   timeout 1500 python tools/gpu_settings_fuzz.py 1200 6 > $OUT/gpu_settings_fuzz_1200.txt 2>&1; tail -n 1 $OUT/gpu_settings_fuzz_1200.txt
+  timeout 1500 python tools/gpu_settings_fuzz.py 2400 11 > $OUT/gpu_settings_fuzz_2400_seed11.txt 2>&1; tail -n 1 $OUT/gpu_settings_fuzz_2400_seed11.txt
+  CAMPAIGN_SEED=13 timeout 1500 python tools/parity_campaign.py 16 oracle bc7 slow,alpha_slow,basic,alpha_basic,veryfast,alpha_veryfast > $OUT/parity_campaign_16Mpix_bc7_fused_seed13.txt 2>&1; tail -n 1 $OUT/parity_campaign_16Mpix_bc7_fused_seed13.txt
   CAMPAIGN_SEED=7 timeout 1500 python tools/parity_campaign.py 4 ref bc7,bc1,bc3,bc6h > $OUT/parity_campaign_4Mpix_vs_reference_kernel_seed7.txt 2>&1; tail -n 1 $OUT/parity_campaign_4Mpix_vs_reference_kernel_seed7.txt
   ;;
 matrix)
