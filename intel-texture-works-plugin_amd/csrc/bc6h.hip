@@ -51,6 +51,7 @@ struct HLane {
     SeedTables T;
     int32_t* keys;            // LDS column, 32 entries: keys[i * TPB6]
     uint32_t* wins;           // LDS column, 6 winners x {err bits, shape, -, -}: wins[(4 * m + f) * TPB6]
+    uint8_t* order;           // LDS column (slow profiles of the one-kernel path): the ranked list written out, order[c * TPB6] = shape of entry c
 };
 
 // ---- format data (kernel.ispc:2080-2125) -----------------------------------
@@ -339,6 +340,16 @@ __device__ __forceinline__ int32_t next_key32(const HLane& ln, int32_t prev, boo
     return cur;
 }
 
+// The first `count` entries of the ranked list, written out: after this the key column is dead (bc6h_kernel<true> reuses it for the winners).
+__device__ __forceinline__ void order_shapes32(HLane& ln, int count)
+{
+    int32_t prev = 0;
+    for (int c = 0; c < count; c++) {
+        prev = next_key32(ln, prev, c == 0);
+        ln.order[c * TPB6] = (uint8_t)(prev & 31);
+    }
+}
+
 // The two-region modes a profile encodes, in the reference's order.  Slow profiles: 0,1,2,5,6,9 (never gated out:
 // margin 0).  Other profiles: the mode the gate sequence left in the lane (`gated`), then mode 1 unless fast_mode.
 __device__ __forceinline__ int two_region_mode(bool slow, int m, int gated)
@@ -352,7 +363,7 @@ __device__ __forceinline__ int two_region_mode(bool slow, int m, int gated)
 // the slow profiles); otherwise the scan stores the indices with the winner.
 // `first`/`step`: the share of a split scan (wide path): list entries first, first + step, ... ; a winner also records
 // its position in the ranked list (the reference's strict `<` keeps the earliest entry among equal errors).
-template <bool LEAN>
+template <bool LEAN, bool ORDERED = false>
 __device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes, int gated, int count, int first = 0, int step = 1)
 {
     for (int m = 0; m < nmodes; m++) {
@@ -363,7 +374,7 @@ __device__ __forceinline__ void scan_two_region(HLane& ln, bool slow, int nmodes
     }
     int32_t prev = 0;
     for (int c = 0; c < count; c++) {
-        prev = next_key32(ln, prev, c == 0);
+        prev = ORDERED ? (int32_t)ln.order[c * TPB6] : next_key32(ln, prev, c == 0);      // only the shape (low 5 bits) is used below
         if (step > 1 && (c % step) != first) continue;           // another wave's share of the list
         ln.tex.fence();
         const int shape = prev & 31;
@@ -541,15 +552,35 @@ __device__ __forceinline__ void load_and_setup(HLane& ln, const uint8_t* __restr
     for (int c = 0; c < 3; c++) { ln.qlo[c] = 0; ln.qhi[c] = 0; }
 }
 
+// Register / LDS budgets (per 256-lane workgroup; a CU has 160 KiB, so 53 KiB is what a third workgroup = a third wave per SIMD needs).
+//   slow profiles     seed tables 12 KiB + 32 keys 32 KiB + the ranked list written out 8 KiB; the 6 winners (24 KiB) live in the key column, dead
+//                     once the list is written: 52 KiB
+//   other profiles    seed tables + 32 keys + at most 2 winners (8 KiB): 52 KiB
+//   no two-region search (`veryfast`): bc6h_one_region_kernel, seed tables only
+// BC6H_*_WAVES = the occupancy an instantiation is compiled for; measured on MI355X (profiles/r06_waves_sweep.txt): the kernels are bound by
+// dependent issue and LDS latency, a third wave with 140 spilled registers beats two waves without by 9-15 %.
+#ifndef BC6H_SLOW_WAVES
+#define BC6H_SLOW_WAVES 3
+#endif
+#ifndef BC6H_WIDE_WAVES
+#define BC6H_WIDE_WAVES 3
+#endif
+#ifndef BC6H_FAST_WAVES
+#define BC6H_FAST_WAVES 3
+#endif
+#ifndef BC6H_ONE_WAVES
+#define BC6H_ONE_WAVES 4
+#endif
+constexpr int bc6h_waves(bool slow) { return slow ? BC6H_SLOW_WAVES : BC6H_FAST_WAVES; }
 template <bool SLOW, bool VEC16>
-__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(2, 2)))   // measured: 2 waves with a little scratch beat 1 wave with AGPR spills by 35 %
+__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(bc6h_waves(SLOW), bc6h_waves(SLOW))))
 bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
             uint8_t* __restrict__ dst, const bc6h_enc_settings S)
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
     __shared__ int32_t s_keys[32 * TPB6];
-    __shared__ uint32_t s_wins[24 * TPB6];
+    __shared__ uint32_t s_tail[8 * TPB6];            // slow: the ranked list (bytes, 32 rows); otherwise the winners' columns (2 winners x 4 words)
     HLane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB6);
     __syncthreads();
@@ -558,7 +589,8 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
     const int32_t b = live ? gid : nblocks - 1;    // idle lanes of the last workgroup redo its last block, store nothing
     const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
     ln.keys = s_keys + threadIdx.x;
-    ln.wins = s_wins + threadIdx.x;
+    ln.wins = SLOW ? reinterpret_cast<uint32_t*>(s_keys) + threadIdx.x : s_tail + threadIdx.x;
+    ln.order = reinterpret_cast<uint8_t*>(s_tail) + threadIdx.x;
 
     load_and_setup<VEC16>(ln, src, stride, xx, yy);
 
@@ -567,7 +599,8 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
         rank_shapes32(ln);
         const int count = min(max(S.fastSkipTreshold, 0), 32);
         if (count > 0) {
-            scan_two_region<true>(ln, true, 6, 0, count);
+            order_shapes32(ln, count);              // the keys are dead from here: the winners' columns take their place
+            scan_two_region<true, true>(ln, true, 6, 0, count);
             finish_two_region<true>(ln, true, 6, 0, S.refineIterations_2p);
         }
         encode_one_region(ln, true, S.refineIterations_1p);
@@ -605,6 +638,42 @@ bc6h_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, i
     }
 }
 
+// Profiles without a two-region search (fastSkipTreshold <= 0 and not slow_mode: `veryfast`): gated modes 10..13 only.  No ranking, no winners:
+// the seed tables are all the LDS it needs, and it keeps the register budget of two waves per SIMD (at three it spills and loses 24 %).
+template <bool VEC16>
+__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(BC6H_ONE_WAVES, BC6H_ONE_WAVES)))
+bc6h_one_region_kernel(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks,
+                       uint8_t* __restrict__ dst, const bc6h_enc_settings S)
+{
+    __shared__ unsigned short s_seed16[2048];
+    __shared__ uint32_t s_seed32[2048];
+    HLane ln;
+    ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB6);
+    __syncthreads();
+    const int32_t gid = blockIdx.x * TPB6 + threadIdx.x;
+    const bool live = gid < nblocks;
+    const int32_t b = live ? gid : nblocks - 1;
+    const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
+    ln.keys = nullptr;
+    ln.wins = nullptr;
+    ln.order = nullptr;
+
+    load_and_setup<VEC16>(ln, src, stride, xx, yy);
+    enter_mode(ln, 10, 0.f);                                                            // [kernel.ispc:3100-3106]
+    enter_mode(ln, 11, 1.f);
+    enter_mode(ln, 12, 1.f);
+    enter_mode(ln, 13, 1.f);
+    encode_one_region(ln, false, S.refineIterations_1p);
+
+    uint32_t out[4];
+    emit_one_region(out, ln.best_q[0], ln.best_qb, ln.best_mode);
+    if (live) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(dst + (int64_t)b * 16);
+        if (VEC16) *reinterpret_cast<uint4*>(d) = make_uint4(out[0], out[1], out[2], out[3]);
+        else { d[0] = out[0]; d[1] = out[1]; d[2] = out[2]; d[3] = out[3]; }
+    }
+}
+
 // ---- WIDE path for the slow profiles: calls too small to fill the chip (see bc7.hip, same idea) ---------------------------
 //   phase A  blockIdx.y = task: `parts` strided shares of the ranked two-region list (every share ranks the 32 shapes
 //            itself: the ranking is a tenth of the scan), each leaving one winner {error, shape, list position} per mode;
@@ -618,14 +687,14 @@ constexpr int W6_MAX_PARTS = 8;
 constexpr int W6_SLOTS = 10;              // 6 two-region modes + 4 one-region modes
 
 template <bool VEC16>
-__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(BC6H_WIDE_WAVES, BC6H_WIDE_WAVES)))
 bc6h_wide_phaseA(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, uint4* __restrict__ wins,
                  float* __restrict__ cerr, uint4* __restrict__ cblk, const bc6h_enc_settings S, const int parts, const int count)
 {
     __shared__ unsigned short s_seed16[2048];
     __shared__ uint32_t s_seed32[2048];
-    __shared__ int32_t s_keys[32 * TPB6];
-    __shared__ uint32_t s_wins[24 * TPB6];
+    __shared__ int32_t s_keys[32 * TPB6];           // the winners' columns take the keys' place once the list is written out (bc6h_kernel<true>)
+    __shared__ uint8_t s_order[32 * TPB6];
     HLane ln;
     ln.T = stage_seed_tables_fast(s_seed16, s_seed32, threadIdx.x, TPB6);
     __syncthreads();
@@ -634,12 +703,14 @@ bc6h_wide_phaseA(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks
     const int32_t b = live ? gid : nblocks - 1;
     const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
     ln.keys = s_keys + threadIdx.x;
-    ln.wins = s_wins + threadIdx.x;
+    ln.wins = reinterpret_cast<uint32_t*>(s_keys) + threadIdx.x;
+    ln.order = s_order + threadIdx.x;
     load_and_setup<VEC16>(ln, src, stride, xx, yy);
     const int task = blockIdx.y;                                   // wave-uniform
     if (task < parts) {                                            // a share of the two-region scan
         rank_shapes32(ln);
-        scan_two_region<true>(ln, true, 6, 0, count, task, parts);
+        order_shapes32(ln, count);
+        scan_two_region<true, true>(ln, true, 6, 0, count, task, parts);
         if (live)
             for (int m = 0; m < 6; m++)
                 wins[((int64_t)m * parts + task) * nblocks + b] = make_uint4(ln.wins[(4 * m + 0) * TPB6], ln.wins[(4 * m + 1) * TPB6], ln.wins[(4 * m + 2) * TPB6], 0u);
@@ -653,7 +724,7 @@ bc6h_wide_phaseA(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks
 }
 
 template <bool VEC16>
-__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(TPB6) __attribute__((amdgpu_waves_per_eu(BC6H_WIDE_WAVES, BC6H_WIDE_WAVES)))
 bc6h_wide_phaseB(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks_x, int32_t nblocks, const uint4* __restrict__ wins,
                  float* __restrict__ cerr, uint4* __restrict__ cblk, const bc6h_enc_settings S, const int parts)
 {
@@ -669,6 +740,7 @@ bc6h_wide_phaseB(const uint8_t* __restrict__ src, int64_t stride, int32_t blocks
     const int32_t yy = b / blocks_x, xx = b - yy * blocks_x;
     ln.keys = nullptr;
     ln.wins = s_wins + threadIdx.x;
+    ln.order = nullptr;
     load_and_setup<VEC16>(ln, src, stride, xx, yy);
     const int m = blockIdx.y;                                      // wave-uniform: index into 0,1,2,5,6,9
     // ordered argmin over the shares: lowest error, then earliest list position (errors compare as floats, like the scan)
@@ -749,10 +821,10 @@ static void launch_bc6h_wide(const uint8_t* src, int64_t stride, int bx, int64_t
     uint4* cblk = reinterpret_cast<uint4*>(reinterpret_cast<uint8_t*>(cerr) + (((size_t)W6_SLOTS * n * sizeof(float) + 15) & ~(size_t)15));
     const bool vec = ((reinterpret_cast<uintptr_t>(src) | (uintptr_t)stride | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
     const int count = s.fastSkipTreshold > 32 ? 32 : s.fastSkipTreshold;
-    // shares of the ranked list: while all waves (2 per SIMD) stay resident at once; every share repeats the ranking
+    // shares of the ranked list: while all waves (BC6H_WIDE_WAVES per SIMD) stay resident at once; every share repeats the ranking
     const int64_t waves = (n + 63) / 64;
     int parts = 1;
-    while (parts < W6_MAX_PARTS && parts * 2 <= count && waves * (parts * 2 + 4) <= 2048) parts *= 2;
+    while (parts < W6_MAX_PARTS && parts * 2 <= count && waves * (parts * 2 + 4) <= 1024 * BC6H_WIDE_WAVES) parts *= 2;
     const unsigned gx = (unsigned)((n + TPB6 - 1) / TPB6);
     const dim3 blk(TPB6);
     if (vec) hipLaunchKernelGGL((bc6h_wide_phaseA<true>),  dim3(gx, (unsigned)(parts + 4)), blk, 0, st, src, stride, bx, (int32_t)n, wins, cerr, cblk, s, parts, count);
@@ -774,6 +846,9 @@ void launch_bc6h(const uint8_t* src, int64_t stride, int width, int height, uint
     if (s.slow_mode) {
         if (vec) hipLaunchKernelGGL((bc6h_kernel<true, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
         else     hipLaunchKernelGGL((bc6h_kernel<true, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
+    } else if (s.fastSkipTreshold <= 0) {
+        if (vec) hipLaunchKernelGGL((bc6h_one_region_kernel<true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
+        else     hipLaunchKernelGGL((bc6h_one_region_kernel<false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
     } else {
         if (vec) hipLaunchKernelGGL((bc6h_kernel<false, true>),  grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
         else     hipLaunchKernelGGL((bc6h_kernel<false, false>), grid, blk, 0, st, src, stride, bx, (int32_t)n, dst, s);
